@@ -1,0 +1,124 @@
+"""Pin the CPU oracle (oracle/midi_oracle.py) to vectors produced by the real reference
+(tests/gen_golden.py ran /root/reference/midi_model.py in fp32 on CPU)."""
+import numpy as np
+import pytest
+import torch
+
+import midi_model_amd as mm
+
+
+@pytest.fixture(scope="module")
+def tok():
+    return mm.MIDITokenizerV2()
+
+
+@pytest.fixture(scope="module")
+def tiny(orc, tok):
+    shp = orc.Shape(n_layer=4, n_head=4, n_embd=256, n_inner=512, vocab=tok.vocab_size)
+    sd = orc.make_state_dict(shp, seed=1)
+    batch = orc.synthetic_events(tok, 2, 17, seed=2)
+    batch[1, 14:] = tok.pad_id
+    return shp, sd, batch
+
+
+def test_forward_and_cache(orc, tiny, golden):
+    shp, sd, batch = tiny
+    g = golden("tiny_train.npz")
+    x = batch[:, :-1]
+    hid = orc.midi_forward(sd, shp, x)
+    np.testing.assert_allclose(hid.numpy(), g["hidden"], rtol=1e-4, atol=2e-5)
+    kv = orc.KV()
+    h = torch.cat([orc.midi_forward(sd, shp, x[:, :11], kv), orc.midi_forward(sd, shp, x[:, 11:], kv)], 1)
+    np.testing.assert_allclose(h.numpy(), g["hidden_cached"], rtol=1e-4, atol=2e-5)
+
+
+def test_loss_logits_grads(orc, tiny, golden):
+    shp, sd, batch = tiny
+    g = golden("tiny_train.npz")
+    sd = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    loss, logits = orc.training_loss(sd, shp, batch)
+    loss.backward()
+    assert abs(loss.item() - float(g["loss"])) < 2e-5
+    np.testing.assert_allclose(logits.detach()[:, :, ::16].numpy(), g["logits_sub"], rtol=1e-3, atol=2e-5)
+    np.testing.assert_allclose(torch.logsumexp(logits.detach(), -1).numpy(), g["logits_lse"], rtol=1e-5, atol=1e-5)
+    assert (logits.detach().argmax(-1).numpy() == g["logits_argmax"]).all()
+    names = [str(n) for n in g["grad_names"]]
+    norms = np.array([sd[n].grad.norm().item() for n in names])
+    np.testing.assert_allclose(norms, g["grad_norms"], rtol=2e-4, atol=1e-7)
+    for key in g.files:
+        if not key.startswith("grad:"):
+            continue
+        gr = sd[key[5:]].grad
+        ref = g[key]
+        got = gr.numpy() if gr.dim() == 1 else gr[:64:3, ::5].numpy()
+        np.testing.assert_allclose(got, ref, rtol=1e-3, atol=1e-7)
+    assert sd["net.embed_tokens.weight"].grad[0].abs().max() == 0  # padding_idx row gets no gradient
+    y = batch[:, 1:].reshape(-1, 8)
+    assert abs(orc.accuracy(logits.detach(), y).item() - float(g["acc"])) < 1e-7
+
+
+def test_optimizer_three_steps(orc, tiny, golden, tok):
+    shp, sd, _ = tiny
+    g = golden("tiny_train.npz")
+    sd = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    m = {k: torch.zeros_like(v) for k, v in sd.items()}
+    v2 = {k: torch.zeros_like(v) for k, v in sd.items()}
+    losses, gnorms, lrs = [], [], []
+    for step in range(3):
+        b = orc.synthetic_events(tok, 2, 17, seed=10 + step)
+        for p in sd.values():
+            p.grad = None
+        loss, _ = orc.training_loss(sd, shp, b)
+        loss.backward()
+        coef, total = orc.clip_coef([p.grad for p in sd.values()], 1.0)
+        lr = 1e-2 * orc.lr_lambda(step, 2, 10)
+        with torch.no_grad():
+            for k, p in sd.items():
+                orc.adamw_step(p, p.grad * coef, m[k], v2[k], step + 1, lr, 0.01 if orc.decays(k) else 0.0)
+        losses.append(loss.item()); gnorms.append(total.item()); lrs.append(lr)
+    np.testing.assert_allclose(losses, g["opt_losses"], rtol=2e-5)
+    np.testing.assert_allclose(gnorms, g["opt_gnorms"], rtol=2e-4)
+    np.testing.assert_allclose(lrs, g["opt_lrs"], rtol=1e-12)
+    names = [str(n) for n in g["grad_names"]]
+    pn = np.array([sd[n].detach().norm().item() for n in names])
+    np.testing.assert_allclose(pn, g["opt_param_norms"], rtol=1e-5)
+    for key in g.files:
+        if key.startswith("opt:"):
+            p = sd[key[4:]].detach()
+            got = p.numpy() if p.dim() == 1 else p[:64:3, ::5].numpy()
+            np.testing.assert_allclose(got, g[key], rtol=1e-4, atol=1e-6)
+
+
+def test_generate_and_sampler(orc, tiny, golden, tok):
+    shp, sd, _ = tiny
+    g = golden("tiny_generate.npz")
+    out = orc.generate(sd, shp, tok, None, batch_size=3, max_len=14, generator=torch.Generator().manual_seed(1234))
+    assert out.shape == g["sampled_b3"].shape and (out == g["sampled_b3"]).all()
+    out = orc.generate(sd, shp, tok, None, batch_size=2, max_len=14, top_k=1, generator=torch.Generator().manual_seed(0))
+    assert (out == g["greedy_b2"]).all()
+    out = orc.generate(sd, shp, tok, g["prompt"], batch_size=2, max_len=12, temp=0.9, top_p=0.9, top_k=8,
+                       generator=torch.Generator().manual_seed(77))
+    assert (out == g["prompt_b2"]).all()
+    pr = torch.softmax(3.0 * torch.randn((4, 1, tok.vocab_size), generator=torch.Generator().manual_seed(3)), -1)
+    s = orc.sample_top_p_k(pr, 0.9, 12, generator=torch.Generator().manual_seed(9))
+    assert (s.numpy() == g["sampler_out"]).all()
+    with pytest.raises(ValueError):
+        orc.generate(sd, shp, tok, np.zeros((3, 2, 8), dtype=np.int64), batch_size=2, max_len=4)
+
+
+def test_medium_forward(orc, golden, tok):
+    g = golden("medium_forward.npz")
+    shp = orc.Shape(vocab=tok.vocab_size)
+    sd = orc.make_state_dict(shp, seed=0)
+    assert sum(v.numel() for v in sd.values()) == int(g["n_params"]) == 233842688
+    assert [k for k, _ in orc.state_dict_keys(shp)] != []  # same key SET as the reference state_dict
+    assert set(sd.keys()) == set(str(k) for k in g["state_dict_keys"])
+    batch = orc.synthetic_events(tok, 1, 33, seed=4)
+    with torch.no_grad():
+        loss, logits = orc.training_loss(sd, shp, batch)
+        hidden = orc.midi_forward(sd, shp, batch[:, :-1]).reshape(-1, shp.n_embd)
+    assert abs(loss.item() - float(g["loss"])) < 5e-5
+    np.testing.assert_allclose(hidden[:, ::4].numpy(), g["hidden_sub"], rtol=1e-3, atol=1e-4)
+    np.testing.assert_allclose(logits[:, :, ::32].numpy(), g["logits_sub"], rtol=1e-3, atol=1e-4)
+    safe = g["logits_margin"] > 1e-3
+    assert (logits.argmax(-1).numpy() == g["logits_argmax"])[safe].all()
