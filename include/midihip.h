@@ -1,0 +1,161 @@
+/* midihip.h — C-ABI of libmidihip.so: the MI355X (gfx950) kernels behind the midi-model hot path.
+ *
+ * The reference (SkyTNT/midi-model) has no FFI of its own: its hot path is Python that reaches
+ * third-party native code through torch/transformers.  This header declares the
+ * boundary a maintainer binds instead (ctypes stub in INTEGRATION.md); every entry point names the
+ * reference call site it replaces.  TF: = transformers/ (5.15.0).
+ *
+ * Conventions
+ *  - plain C: raw DEVICE pointers + sizes, no torch types; the caller owns all memory.
+ *  - `dtype`: MH_F32 (parity/verification mode) or MH_BF16 (production); statistics (rstd, lse,
+ *    losses, norms) and optimiser scalars are always fp32.
+ *  - `stream` is a hipStream_t (NULL = default stream).  Calls only enqueue work.
+ *  - return 0 on success, <0 on error; mh_last_error() gives the message (thread-local).
+ *  - token ids are int64 (torch.long), as on the reference API.
+ *  - row-major everywhere; "ld*" are leading dimensions in ELEMENTS.
+ */
+#ifndef MIDIHIP_H
+#define MIDIHIP_H
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MH_F32 0
+#define MH_BF16 1
+
+#define MH_OK 0
+#define MH_ERR_ARG (-1)
+#define MH_ERR_LAUNCH (-2)
+#define MH_ERR_UNSUPPORTED (-3)
+
+const char* mh_last_error(void);
+int mh_version(void);
+
+/* ---- dense projections (MFMA) ------------------------------------------------------------------
+ * C[M,N] = alpha * A[M,K] * B[N,K]^T + beta * R[M,N]      (R may be NULL when beta == 0; R may alias C)
+ * Replaces every nn.Linear of the path: q/k/v/o_proj (TF:models/llama/modeling_llama.py:254-256,280),
+ * gate/up/down_proj (:174-176), lm_head (midi_model.py:107,135) and their autograd dgrad/wgrad.
+ * K, lda, ldb must be multiples of 16 bytes worth of elements; M, N arbitrary.
+ * `splitk` > 1 splits the contraction over grid.z and needs `workspace` of splitk*M*N floats.      */
+int mh_gemm_nt(const void* A, int64_t lda, const void* B, int64_t ldb, void* C, int64_t ldc, const void* R,
+               int64_t ldr, int64_t M, int64_t N, int64_t K, float alpha, float beta, int dtype, int splitk,
+               void* workspace, void* stream);
+/* out[C,R] = in[R,C]^T (operand re-layout for dgrad/wgrad). */
+int mh_transpose(const void* in, int64_t ldi, void* out, int64_t ldo, int64_t rows, int64_t cols, int dtype,
+                 void* stream);
+
+/* ---- embeddings --------------------------------------------------------------------------------
+ * out[m,:] = sum_j table[tok[m,j],:]   (midi_model.py:145-146: embed_tokens(x).sum(-2))             */
+int mh_embed_sum_fwd(const int64_t* tok, const void* table, void* out, int64_t M, int T, int64_t V, int D,
+                     int dtype, void* stream);
+/* out[m,0,:] = hidden[m,:]; out[m,j,:] = table[tok[m,j-1],:], j=1..T-1   (midi_model.py:126-131)   */
+int mh_concat_tok_fwd(const void* hidden, const int64_t* tok, int64_t ldtok, const void* table, void* out,
+                      int64_t M, int T, int64_t V, int D, int dtype, void* stream);
+/* dtable_f32[tok[m,j],:] += dout_row(m,j): scatter-add of embedding gradients into an fp32 [V,D] accumulator;
+ * rows with tok == pad_id are skipped (nn.Embedding padding_idx, TF:models/llama/modeling_llama.py:353).
+ * dout_row(m,j) starts at dout + (m*rows_per_m + j*jstride + j0)*D: (1,0,0) for the summed event embedding,
+ * (T,1,1) for the token-sequence embedding whose row 0 is the hidden state.                              */
+int mh_embed_scatter_bwd(const int64_t* tok, int64_t ldtok, int T, const void* dout, int rows_per_m, int jstride,
+                         int j0, float* dtable_f32, int64_t M, int64_t V, int D, int64_t pad_id, int dtype,
+                         void* stream);
+/* dst[i] (dtype) = (accumulate ? dst[i] : 0) + src_f32[i] */
+int mh_cast_from_f32(const float* src, void* dst, int64_t n, int accumulate, int dtype, void* stream);
+/* strided row copy: dst[m,:] = src[m*src_ld ...] (+ optional accumulate) — takes d(hidden) out of d(token seq). */
+int mh_copy_rows(const void* src, int64_t src_ld, void* dst, int64_t dst_ld, int64_t M, int D, int accumulate,
+                 int dtype, void* stream);
+
+/* ---- RMSNorm (TF:models/llama/modeling_llama.py:62-67) ---------------------------------------------
+ * y = w * T(x * rsqrt(mean(x^2)+eps));  rstd[M] (fp32) is saved for the backward.                   */
+int mh_rmsnorm_fwd(const void* x, const void* w, void* y, float* rstd, int64_t M, int D, float eps, int dtype,
+                   void* stream);
+/* dx = rmsnorm'(dy) (+ dres if non-NULL: the residual-stream gradient);  dw_partial[nblk,D] fp32 gets the
+ * per-block column sums of dy * xhat (reduce with mh_colsum).  nblk = mh_rmsnorm_bwd_blocks(M).        */
+int mh_rmsnorm_bwd_blocks(int64_t M);
+int mh_rmsnorm_bwd(const void* x, const void* w, const float* rstd, const void* dy, const void* dres, void* dx,
+                   float* dw_partial, int64_t M, int D, int dtype, void* stream);
+int mh_colsum(const float* partial, int64_t nblk, void* out, int D, int accumulate, int dtype, void* stream);
+
+/* ---- RoPE (TF:models/llama/modeling_llama.py:113-160; half-split rotate_half) --------------------------
+ * In place on the q and k thirds of qkv[M, 3*H*hd]; row m sits at position pos0 + (m % S).
+ * cos/sin: fp32 tables [npos, hd/2].  dir=+1 forward, -1 backward (transpose rotation).               */
+int mh_rope(void* qkv, const float* cos_t, const float* sin_t, int64_t M, int64_t S, int64_t pos0, int H, int hd,
+            int dir, int dtype, void* stream);
+
+/* ---- event-level causal attention, head_dim 64 (TF:integrations/sdpa_attention.py:79-166) -------------
+ * qkv[B*S, 3*H*64] (q|k|v thirds, RoPE already applied) -> o[B*S, H*64], lse[B,H,S] (natural log).
+ * bf16: MFMA flash kernel, needs the transposed copy vt[B,H,64,Sp] (Sp = S rounded up to 64, padding
+ * zero) written by mh_attn_prep_fwd.  fp32: plain verification kernel (vt ignored).                 */
+int mh_attn_prep_fwd(const void* qkv, void* vt, int64_t B, int64_t S, int H, int dtype, void* stream);
+int mh_attn_fwd(const void* qkv, const void* vt, void* o, float* lse, int64_t B, int64_t S, int H, float scale,
+                int dtype, void* stream);
+/* backward: dqkv[B*S,3*H*64] <- (qkv, o, do, lse).  scratch: delta[B,H,S] fp32; bf16 additionally
+ * qt,kt,dot: [B,H,64,Sp] transposed copies (zero padded) filled by mh_attn_prep_bwd.                  */
+int mh_attn_prep_bwd(const void* qkv, const void* o, const void* dout, float* delta, void* qt, void* kt, void* dot,
+                     int64_t B, int64_t S, int H, int dtype, void* stream);
+int mh_attn_bwd(const void* qkv, const void* dout, const float* lse, const float* delta, const void* qt,
+                const void* kt, const void* dot, void* dqkv, int64_t B, int64_t S, int H, float scale, int dtype,
+                void* stream);
+/* NOTE: lse and delta are laid out [B,H,Sp] with Sp = S rounded up to a multiple of 64 (entries past S unused).
+ * The *_plain variants run the exact-fp32-math thread-per-row kernels for either dtype; tests use them to
+ * cross-check the MFMA kernels on the device.                                                              */
+int mh_attn_fwd_plain(const void* qkv, void* o, float* lse, int64_t B, int64_t S, int H, float scale, int dtype,
+                      void* stream);
+int mh_attn_bwd_plain(const void* qkv, const void* dout, const float* lse, const float* delta, void* dqkv, int64_t B,
+                      int64_t S, int H, float scale, int dtype, void* stream);
+
+/* ---- token-level attention: sequences of T<=8 tokens, head_dim 256 (net_token) --------------------------
+ * qkv[N*T, 3*H*256] -> o[N*T, H*256], causal within each sequence of T rows.                           */
+int mh_tokattn_fwd(const void* qkv, void* o, int64_t N, int T, int H, float scale, int dtype, void* stream);
+int mh_tokattn_bwd(const void* qkv, const void* dout, void* dqkv, int64_t N, int T, int H, float scale, int dtype,
+                   void* stream);
+
+/* ---- SwiGLU (TF:models/llama/modeling_llama.py:174-176) -------------------------------------------------
+ * gu[M,2I] = [gate | up];  a = silu(gate) * up;  dgu = [da*up*silu'(gate) | da*silu(gate)]            */
+int mh_swiglu_fwd(const void* gu, void* a, int64_t M, int I, int dtype, void* stream);
+int mh_swiglu_bwd(const void* gu, const void* da, void* dgu, int64_t M, int I, int dtype, void* stream);
+
+/* ---- cross-entropy over the vocabulary (train.py:180-185) ------------------------------------------------
+ * logits[R, ldl] (V valid columns).  row_loss[r] = lse - logit[target] (0 when target == ignore).
+ * If dlogits != NULL: dlogits = (softmax - onehot) * (*scale_dev) for kept rows, 0 for ignored rows and for
+ * padding columns V..ldl-1 (dlogits may alias logits).  argmax_out (optional) gets the row argmax.       */
+int mh_cross_entropy(const void* logits, int64_t ldl, const int64_t* target, float* row_loss, void* dlogits,
+                     const float* scale_dev, int64_t* argmax_out, int64_t R, int V, int64_t ignore, int dtype,
+                     void* stream);
+/* out[0] = sum(x[0..n)) (deterministic tree); out[1] = number of x != 0 is NOT computed here.             */
+int mh_sum_f32(const float* x, int64_t n, float* out, void* stream);
+/* count[0] = #(target != ignore); inv[0] = 1/max(count,1)                                                 */
+int mh_count_valid(const int64_t* target, int64_t n, int64_t ignore, float* count, float* inv, void* stream);
+
+/* ---- optimiser (train.py:121-151 AdamW, Trainer gradient_clip_val=1.0 train.py:464) -----------------------
+ * mh_sumsq: out[0] = (accumulate ? out[0] : 0) + sum(g^2), deterministic two-stage reduction through the
+ * caller's 1024-float scratch `partial1024`.  mh_clip_coef: coef[0] = min(1, max_norm/(sqrt(sumsq)+1e-6)),
+ * norm[0] = sqrt(sumsq).  mh_adamw: torch.optim.AdamW single-tensor update with g scaled by *coef_dev. */
+int mh_sumsq(const void* g, int64_t n, float* partial1024, float* out, int accumulate, int dtype, void* stream);
+int mh_clip_coef(const float* sumsq, float max_norm, float* coef, float* norm, void* stream);
+int mh_adamw(void* p, const void* g, void* m, void* v, int64_t n, float lr, float beta1, float beta2, float eps,
+             float weight_decay, float bias_corr1, float bias_corr2, const float* coef_dev, int dtype, void* stream);
+
+/* ---- KV-cached single-event decode (midi_model.py:195-246; TF:cache_utils.py:127-147) -----------------------
+ * Cache layout per layer: k,v [B,H,Lmax,hd].  mh_kv_append: rotate q,k of qkv[B,3*H*hd] at position `pos`
+ * in place and store k,v rows at index pos.  mh_attn_decode: o[B,H*hd] = softmax(q K^T * scale) V over
+ * the first `len` cached rows (q_len == 1: no causal mask, sdpa_attention.py:120).  hd in {64,256}.     */
+int mh_kv_append(void* qkv, const float* cos_t, const float* sin_t, void* kcache, void* vcache, int64_t B, int H,
+                 int hd, int64_t Lmax, int64_t pos, int dtype, void* stream);
+int mh_attn_decode(const void* qkv, const void* kcache, const void* vcache, void* o, int64_t B, int H, int hd,
+                   int64_t Lmax, int64_t len, float scale, int dtype, void* stream);
+/* copy rotated K and V of a prefill (qkv[B*S,3*H*hd]) into the cache rows [0,S).                           */
+int mh_kv_store_prefill(const void* qkv, void* kcache, void* vcache, int64_t B, int64_t S, int H, int hd,
+                        int64_t Lmax, int dtype, void* stream);
+
+/* ---- grammar-masked softmax for the sampler (midi_model.py:202-223) -----------------------------------------
+ * probs[b,:] = softmax(logits[b,:]/temp) * mask_b, mask_b = ids in [lo[b],hi[b]) or, when lo[b] < 0, the
+ * `first_mask` table (event ids + EOS).  fp32 output, as torch.softmax on fp32 logits gives.              */
+int mh_masked_softmax(const void* logits, int64_t ldl, const int32_t* lo, const int32_t* hi,
+                      const uint8_t* first_mask, float* probs, int64_t B, int V, float temp, int dtype,
+                      void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,697 @@
+// Attention kernels that are NOT matrix-core shaped:
+//   * token-level attention of net_token: sequences of T<=8 tokens, head_dim 256 (one wave per head-sequence,
+//     everything in registers; HBM-bound: 12 KiB in / 4 KiB out per head-sequence in bf16)
+//   * single-query decode attention over a preallocated KV cache (HBM-bound KV stream)
+//   * KV-cache append / prefill store
+//   * the fp32 verification kernels of event-level attention (thread-per-row, exact fp32 VALU) and the
+//     prep kernels (delta = rowsum(dO*O), transposed operand copies for the MFMA flash kernels)
+#include "common.h"
+
+#define DISPATCH_T(dtype, CALL)                                    \
+  do {                                                             \
+    if ((dtype) == MH_BF16) { using T = bf16; CALL; }              \
+    else if ((dtype) == MH_F32) { using T = float; CALL; }         \
+    else { mh_set_error("bad dtype %d", (int)(dtype)); return MH_ERR_ARG; } \
+  } while (0)
+
+// ---------------------------------------------------------------------------------------------------
+// token-level attention.  lane l owns dims 4l..4l+3 of the 256-wide head for all T positions.
+// ---------------------------------------------------------------------------------------------------
+template <typename T> __device__ inline void ld4(const T* p, float (&o)[4]);
+template <> __device__ inline void ld4<float>(const float* p, float (&o)[4]) {
+  f32x4 v = *reinterpret_cast<const f32x4*>(p);
+  o[0] = v[0]; o[1] = v[1]; o[2] = v[2]; o[3] = v[3];
+}
+template <> __device__ inline void ld4<bf16>(const bf16* p, float (&o)[4]) {
+  bf16x4 v = *reinterpret_cast<const bf16x4*>(p);
+  o[0] = (float)v[0]; o[1] = (float)v[1]; o[2] = (float)v[2]; o[3] = (float)v[3];
+}
+template <typename T> __device__ inline void st4(T* p, const float (&o)[4]);
+template <> __device__ inline void st4<float>(float* p, const float (&o)[4]) {
+  *reinterpret_cast<f32x4*>(p) = f32x4{o[0], o[1], o[2], o[3]};
+}
+template <> __device__ inline void st4<bf16>(bf16* p, const float (&o)[4]) {
+  bf16x4 v;
+  v[0] = (bf16)o[0]; v[1] = (bf16)o[1]; v[2] = (bf16)o[2]; v[3] = (bf16)o[3];
+  *reinterpret_cast<bf16x4*>(p) = v;
+}
+
+constexpr int TK = 8;  // max tokens per sequence (the octet)
+
+template <typename T>
+__global__ __launch_bounds__(256) void tokattn_fwd_kernel(const T* __restrict__ qkv, T* __restrict__ o, int64_t NH, int Tn,
+                                                          int H, float scale) {
+  const int lane = threadIdx.x & 63;
+  const int64_t D = (int64_t)H * 256, D3 = 3 * D;
+  for (int64_t w = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); w < NH; w += (int64_t)gridDim.x * 4) {
+    const int64_t n = w / H;
+    const int h = (int)(w - n * H);
+    const T* base = qkv + n * Tn * D3 + (int64_t)h * 256 + lane * 4;
+    float q[TK][4], k[TK][4], v[TK][4];
+#pragma unroll
+    for (int t = 0; t < TK; ++t) {
+      if (t < Tn) {
+        ld4<T>(base + t * D3, q[t]);
+        ld4<T>(base + t * D3 + D, k[t]);
+        ld4<T>(base + t * D3 + 2 * D, v[t]);
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < TK; ++i) {
+      if (i >= Tn) break;
+      float s[TK];
+      float mx = -INFINITY;
+#pragma unroll
+      for (int j = 0; j <= i; ++j) {
+        float p = q[i][0] * k[j][0] + q[i][1] * k[j][1] + q[i][2] * k[j][2] + q[i][3] * k[j][3];
+        s[j] = wave_sum(p) * scale;
+        mx = fmaxf(mx, s[j]);
+      }
+      float den = 0.f;
+#pragma unroll
+      for (int j = 0; j <= i; ++j) {
+        s[j] = __expf(s[j] - mx);
+        den += s[j];
+      }
+      const float inv = 1.f / den;
+      float acc[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int j = 0; j <= i; ++j) {
+        const float p = s[j] * inv;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc[e] += p * v[j][e];
+      }
+      st4<T>(o + (n * Tn + i) * D + (int64_t)h * 256 + lane * 4, acc);
+    }
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void tokattn_bwd_kernel(const T* __restrict__ qkv, const T* __restrict__ dout,
+                                                          T* __restrict__ dqkv, int64_t NH, int Tn, int H, float scale) {
+  const int lane = threadIdx.x & 63;
+  const int64_t D = (int64_t)H * 256, D3 = 3 * D;
+  for (int64_t w = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); w < NH; w += (int64_t)gridDim.x * 4) {
+    const int64_t n = w / H;
+    const int h = (int)(w - n * H);
+    const int64_t off = (int64_t)h * 256 + lane * 4;
+    const T* base = qkv + n * Tn * D3 + off;
+    float q[TK][4], k[TK][4], v[TK][4], dO[TK][4];
+    float dq[TK][4], dk[TK][4], dv[TK][4];
+#pragma unroll
+    for (int t = 0; t < TK; ++t) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) dq[t][e] = dk[t][e] = dv[t][e] = 0.f;
+      if (t < Tn) {
+        ld4<T>(base + t * D3, q[t]);
+        ld4<T>(base + t * D3 + D, k[t]);
+        ld4<T>(base + t * D3 + 2 * D, v[t]);
+        ld4<T>(dout + (n * Tn + t) * D + off, dO[t]);
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < TK; ++i) {
+      if (i >= Tn) break;
+      float p[TK], dp[TK];
+      float mx = -INFINITY;
+#pragma unroll
+      for (int j = 0; j <= i; ++j) {
+        float a = q[i][0] * k[j][0] + q[i][1] * k[j][1] + q[i][2] * k[j][2] + q[i][3] * k[j][3];
+        float b = dO[i][0] * v[j][0] + dO[i][1] * v[j][1] + dO[i][2] * v[j][2] + dO[i][3] * v[j][3];
+        p[j] = wave_sum(a) * scale;
+        dp[j] = wave_sum(b);
+        mx = fmaxf(mx, p[j]);
+      }
+      float den = 0.f;
+#pragma unroll
+      for (int j = 0; j <= i; ++j) {
+        p[j] = __expf(p[j] - mx);
+        den += p[j];
+      }
+      const float inv = 1.f / den;
+      float dsum = 0.f;
+#pragma unroll
+      for (int j = 0; j <= i; ++j) {
+        p[j] *= inv;
+        dsum += p[j] * dp[j];
+      }
+#pragma unroll
+      for (int j = 0; j <= i; ++j) {
+        const float ds = p[j] * (dp[j] - dsum) * scale;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          dq[i][e] += ds * k[j][e];
+          dk[j][e] += ds * q[i][e];
+          dv[j][e] += p[j] * dO[i][e];
+        }
+      }
+    }
+    T* ob = dqkv + n * Tn * D3 + off;
+#pragma unroll
+    for (int t = 0; t < TK; ++t) {
+      if (t < Tn) {
+        st4<T>(ob + t * D3, dq[t]);
+        st4<T>(ob + t * D3 + D, dk[t]);
+        st4<T>(ob + t * D3 + 2 * D, dv[t]);
+      }
+    }
+  }
+}
+
+extern "C" int mh_tokattn_fwd(const void* qkv, void* o, int64_t N, int Tn, int H, float scale, int dtype, void* stream) {
+  MH_REQUIRE(N > 0 && Tn >= 1 && Tn <= TK && H >= 1, "tokattn_fwd: bad shape N=%ld T=%d H=%d", (long)N, Tn, H);
+  const int64_t NH = N * H;
+  int64_t g = (NH + 3) / 4;
+  if (g > 32768) g = 32768;
+  DISPATCH_T(dtype, (tokattn_fwd_kernel<T><<<(int)g, 256, 0, (hipStream_t)stream>>>((const T*)qkv, (T*)o, NH, Tn, H, scale)));
+  MH_LAUNCH_CHECK();
+  return MH_OK;
+}
+
+extern "C" int mh_tokattn_bwd(const void* qkv, const void* dout, void* dqkv, int64_t N, int Tn, int H, float scale,
+                              int dtype, void* stream) {
+  MH_REQUIRE(N > 0 && Tn >= 1 && Tn <= TK && H >= 1, "tokattn_bwd: bad shape");
+  const int64_t NH = N * H;
+  int64_t g = (NH + 3) / 4;
+  if (g > 32768) g = 32768;
+  DISPATCH_T(dtype, (tokattn_bwd_kernel<T><<<(int)g, 256, 0, (hipStream_t)stream>>>((const T*)qkv, (const T*)dout, (T*)dqkv,
+                                                                                    NH, Tn, H, scale)));
+  MH_LAUNCH_CHECK();
+  return MH_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// decode: KV cache [B,H,Lmax,HD]; append (with RoPE of q,k) and single-query attention
+// ---------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void kv_append_kernel(T* __restrict__ qkv, const float* __restrict__ cos_t,
+                                                        const float* __restrict__ sin_t, T* __restrict__ kc,
+                                                        T* __restrict__ vc, int64_t B, int H, int hd, int64_t Lmax,
+                                                        int64_t pos) {
+  // one thread per (b, h, pair index i < hd/2): rotate q and k, store k and v rows
+  const int half = hd / 2;
+  const int64_t total = B * H * half;
+  const int64_t D = (int64_t)H * hd;
+  for (int64_t it = (int64_t)blockIdx.x * 256 + threadIdx.x; it < total; it += (int64_t)gridDim.x * 256) {
+    const int i = (int)(it % half);
+    const int64_t bh = it / half;
+    const int h = (int)(bh % H);
+    const int64_t b = bh / H;
+    const float c = rnd<T>(cos_t[pos * half + i]), s = rnd<T>(sin_t[pos * half + i]);
+    T* row = qkv + b * 3 * D + (int64_t)h * hd;
+    const float q1 = to_f(row[i]), q2 = to_f(row[i + half]);
+    row[i] = from_f<T>(q1 * c - q2 * s);
+    row[i + half] = from_f<T>(q2 * c + q1 * s);
+    const float k1 = to_f(row[D + i]), k2 = to_f(row[D + i + half]);
+    const T kr1 = from_f<T>(k1 * c - k2 * s), kr2 = from_f<T>(k2 * c + k1 * s);
+    row[D + i] = kr1;
+    row[D + i + half] = kr2;
+    T* kd = kc + ((b * H + h) * Lmax + pos) * hd;
+    T* vd = vc + ((b * H + h) * Lmax + pos) * hd;
+    kd[i] = kr1;
+    kd[i + half] = kr2;
+    vd[i] = row[2 * D + i];
+    vd[i + half] = row[2 * D + i + half];
+  }
+}
+
+extern "C" int mh_kv_append(void* qkv, const float* cos_t, const float* sin_t, void* kcache, void* vcache, int64_t B,
+                            int H, int hd, int64_t Lmax, int64_t pos, int dtype, void* stream) {
+  MH_REQUIRE(B > 0 && H > 0 && hd % 2 == 0 && pos >= 0 && pos < Lmax, "kv_append: bad args (pos=%ld Lmax=%ld)", (long)pos,
+             (long)Lmax);
+  const int64_t total = B * H * (hd / 2);
+  DISPATCH_T(dtype, (kv_append_kernel<T><<<(int)((total + 255) / 256), 256, 0, (hipStream_t)stream>>>(
+                        (T*)qkv, cos_t, sin_t, (T*)kcache, (T*)vcache, B, H, hd, Lmax, pos)));
+  MH_LAUNCH_CHECK();
+  return MH_OK;
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void kv_store_prefill_kernel(const T* __restrict__ qkv, T* __restrict__ kc,
+                                                               T* __restrict__ vc, int64_t B, int64_t S, int H, int hd,
+                                                               int64_t Lmax) {
+  constexpr int N = Pack<T>::N;
+  const int cph = hd / N;
+  const int64_t total = B * S * H * cph;
+  const int64_t D = (int64_t)H * hd;
+  for (int64_t it = (int64_t)blockIdx.x * 256 + threadIdx.x; it < total; it += (int64_t)gridDim.x * 256) {
+    const int c = (int)(it % cph);
+    int64_t r = it / cph;
+    const int h = (int)(r % H);
+    r /= H;
+    const int64_t s = r % S, b = r / S;
+    const T* row = qkv + (b * S + s) * 3 * D + (int64_t)h * hd + c * N;
+    const int64_t dst = ((b * H + h) * Lmax + s) * hd + c * N;
+    st16(kc + dst, ld16(row + D));
+    st16(vc + dst, ld16(row + 2 * D));
+  }
+}
+
+extern "C" int mh_kv_store_prefill(const void* qkv, void* kcache, void* vcache, int64_t B, int64_t S, int H, int hd,
+                                   int64_t Lmax, int dtype, void* stream) {
+  MH_REQUIRE(B > 0 && S > 0 && S <= Lmax && hd % 8 == 0, "kv_store_prefill: bad args");
+  const int64_t total = B * S * H * (hd / (dtype == MH_BF16 ? 8 : 4));
+  int64_t g = (total + 255) / 256;
+  if (g > 16384) g = 16384;
+  DISPATCH_T(dtype, (kv_store_prefill_kernel<T><<<(int)g, 256, 0, (hipStream_t)stream>>>((const T*)qkv, (T*)kcache,
+                                                                                         (T*)vcache, B, S, H, hd, Lmax)));
+  MH_LAUNCH_CHECK();
+  return MH_OK;
+}
+
+// One block (4 waves) per (b,h).  LPK lanes cover one cached key row with 16-byte loads; every lane group
+// keeps an online-softmax state over its own subset of keys, merged at the end (groups, then waves).
+template <typename T, int HD>
+__global__ __launch_bounds__(256) void attn_decode_kernel(const T* __restrict__ qkv, const T* __restrict__ kc,
+                                                          const T* __restrict__ vc, T* __restrict__ o, int H,
+                                                          int64_t Lmax, int64_t len, float scale) {
+  constexpr int N = Pack<T>::N;
+  constexpr int LPK = HD / N;       // lanes per key row
+  constexpr int KPW = 64 / LPK;     // keys per wave per iteration
+  __shared__ float sh_m[4], sh_l[4];
+  __shared__ float sh_o[4][HD];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int64_t bh = blockIdx.x;
+  const int64_t b = bh / H;
+  const int h = (int)(bh - b * H);
+  const int64_t D = (int64_t)H * HD;
+  const int ch = lane % LPK, grp = lane / LPK;
+  Pack<T> qv = ld16(qkv + b * 3 * D + (int64_t)h * HD + ch * N);
+  float q[N];
+#pragma unroll
+  for (int e = 0; e < N; ++e) q[e] = qv.get(e) * scale;
+  float m = -INFINITY, l = 0.f, acc[N];
+#pragma unroll
+  for (int e = 0; e < N; ++e) acc[e] = 0.f;
+  const T* kb = kc + bh * Lmax * HD;
+  const T* vb = vc + bh * Lmax * HD;
+  for (int64_t j0 = (int64_t)wv * KPW; j0 < len; j0 += 4 * KPW) {
+    const int64_t j = j0 + grp;
+    const bool ok = j < len;
+    const int64_t jj = ok ? j : 0;
+    Pack<T> kv = ld16(kb + jj * HD + ch * N);
+    Pack<T> vv = ld16(vb + jj * HD + ch * N);
+    float s = 0.f;
+#pragma unroll
+    for (int e = 0; e < N; ++e) s += q[e] * kv.get(e);
+#pragma unroll
+    for (int x = 1; x < LPK; x <<= 1) s += __shfl_xor(s, x, 64);
+    if (ok) {
+      const float nm = fmaxf(m, s);
+      const float a = __expf(m - nm), p = __expf(s - nm);
+      l = l * a + p;
+#pragma unroll
+      for (int e = 0; e < N; ++e) acc[e] = acc[e] * a + p * vv.get(e);
+      m = nm;
+    }
+  }
+  // merge the KPW lane groups of the wave (lanes with equal `ch`)
+#pragma unroll
+  for (int x = LPK; x < 64; x <<= 1) {
+    const float om = __shfl_xor(m, x, 64), ol = __shfl_xor(l, x, 64);
+    const float nm = fmaxf(m, om);
+    const float a = (m == -INFINITY) ? 0.f : __expf(m - nm);
+    const float bsc = (om == -INFINITY) ? 0.f : __expf(om - nm);
+    l = l * a + ol * bsc;
+#pragma unroll
+    for (int e = 0; e < N; ++e) acc[e] = acc[e] * a + __shfl_xor(acc[e], x, 64) * bsc;
+    m = nm;
+  }
+  if (lane < LPK) {
+#pragma unroll
+    for (int e = 0; e < N; ++e) sh_o[wv][ch * N + e] = acc[e];
+    if (lane == 0) {
+      sh_m[wv] = m;
+      sh_l[wv] = l;
+    }
+  }
+  __syncthreads();
+  if (threadIdx.x < HD) {
+    const float gm = fmaxf(fmaxf(sh_m[0], sh_m[1]), fmaxf(sh_m[2], sh_m[3]));
+    float num = 0.f, den = 0.f;
+#pragma unroll
+    for (int w = 0; w < 4; ++w) {
+      const float f = (sh_m[w] == -INFINITY) ? 0.f : __expf(sh_m[w] - gm);
+      num += sh_o[w][threadIdx.x] * f;
+      den += sh_l[w] * f;
+    }
+    o[b * D + (int64_t)h * HD + threadIdx.x] = from_f<T>(num / den);
+  }
+}
+
+extern "C" int mh_attn_decode(const void* qkv, const void* kcache, const void* vcache, void* o, int64_t B, int H, int hd,
+                              int64_t Lmax, int64_t len, float scale, int dtype, void* stream) {
+  MH_REQUIRE(B > 0 && H > 0 && len > 0 && len <= Lmax, "attn_decode: bad args len=%ld Lmax=%ld", (long)len, (long)Lmax);
+  MH_REQUIRE(hd == 64 || hd == 256, "attn_decode: head_dim %d unsupported (64 or 256)", hd);
+  hipStream_t st = (hipStream_t)stream;
+  const int grid = (int)(B * H);
+#define LAUNCH_DEC(TT, HDV) \
+  attn_decode_kernel<TT, HDV><<<grid, 256, 0, st>>>((const TT*)qkv, (const TT*)kcache, (const TT*)vcache, (TT*)o, H, Lmax, len, scale)
+  if (dtype == MH_BF16) {
+    if (hd == 64) LAUNCH_DEC(bf16, 64); else LAUNCH_DEC(bf16, 256);
+  } else if (dtype == MH_F32) {
+    if (hd == 64) LAUNCH_DEC(float, 64); else LAUNCH_DEC(float, 256);
+  } else {
+    mh_set_error("attn_decode: bad dtype");
+    return MH_ERR_ARG;
+  }
+#undef LAUNCH_DEC
+  MH_LAUNCH_CHECK();
+  return MH_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// event-level attention, head_dim 64: plain verification kernels (thread per row, fp32 math).
+// Used for dtype fp32 (parity mode) — the bf16 production path is attention_mfma.hip.
+// ---------------------------------------------------------------------------------------------------
+constexpr int AHD = 64;
+
+template <typename T>
+__global__ __launch_bounds__(64) void attn_plain_fwd_kernel(const T* __restrict__ qkv, T* __restrict__ o,
+                                                            float* __restrict__ lse, int64_t S, int H, float scale) {
+  __shared__ float ks[32][AHD], vs[32][AHD];
+  const int64_t bh = blockIdx.y;
+  const int64_t b = bh / H;
+  const int h = (int)(bh - b * H);
+  const int64_t D = (int64_t)H * AHD, D3 = 3 * D;
+  const int64_t q0 = (int64_t)blockIdx.x * 64;
+  const int64_t qi = q0 + threadIdx.x;
+  const bool valid = qi < S;
+  float q[AHD], acc[AHD];
+  const T* qrow = qkv + (b * S + (valid ? qi : 0)) * D3 + (int64_t)h * AHD;
+#pragma unroll
+  for (int d = 0; d < AHD; ++d) {
+    q[d] = to_f(qrow[d]) * scale;
+    acc[d] = 0.f;
+  }
+  float m = -INFINITY, l = 0.f;
+  const int64_t kmax = (q0 + 63 < S - 1) ? q0 + 63 : S - 1;  // last key any row of this block can see
+  for (int64_t k0 = 0; k0 <= kmax; k0 += 32) {
+    __syncthreads();
+    for (int i = threadIdx.x; i < 32 * AHD; i += 64) {
+      const int r = i / AHD, d = i % AHD;
+      const int64_t kj = k0 + r;
+      const T* krow = qkv + (b * S + (kj < S ? kj : S - 1)) * D3 + D + (int64_t)h * AHD;
+      ks[r][d] = to_f(krow[d]);
+      vs[r][d] = to_f(krow[D + d]);
+    }
+    __syncthreads();
+    if (!valid) continue;
+    for (int r = 0; r < 32; ++r) {
+      const int64_t kj = k0 + r;
+      if (kj > qi) break;
+      float s = 0.f;
+#pragma unroll
+      for (int d = 0; d < AHD; ++d) s += q[d] * ks[r][d];
+      const float nm = fmaxf(m, s);
+      const float a = __expf(m - nm), p = __expf(s - nm);
+      l = l * a + p;
+#pragma unroll
+      for (int d = 0; d < AHD; ++d) acc[d] = acc[d] * a + p * vs[r][d];
+      m = nm;
+    }
+  }
+  if (valid) {
+    T* orow = o + (b * S + qi) * D + (int64_t)h * AHD;
+    const float inv = 1.f / l;
+#pragma unroll
+    for (int d = 0; d < AHD; ++d) orow[d] = from_f<T>(acc[d] * inv);
+    lse[bh * ((S + 63) / 64 * 64) + qi] = m + __logf(l);
+  }
+}
+
+// dQ: thread per query row
+template <typename T>
+__global__ __launch_bounds__(64) void attn_plain_bwd_dq_kernel(const T* __restrict__ qkv, const T* __restrict__ dout,
+                                                               const float* __restrict__ lse, const float* __restrict__ delta,
+                                                               T* __restrict__ dqkv, int64_t S, int H, float scale) {
+  __shared__ float ks[32][AHD], vs[32][AHD];
+  const int64_t bh = blockIdx.y;
+  const int64_t b = bh / H;
+  const int h = (int)(bh - b * H);
+  const int64_t D = (int64_t)H * AHD, D3 = 3 * D;
+  const int64_t q0 = (int64_t)blockIdx.x * 64;
+  const int64_t qi = q0 + threadIdx.x;
+  const bool valid = qi < S;
+  float q[AHD], dO[AHD], dq[AHD];
+  const int64_t qc = valid ? qi : 0;
+  const T* qrow = qkv + (b * S + qc) * D3 + (int64_t)h * AHD;
+  const T* drow = dout + (b * S + qc) * D + (int64_t)h * AHD;
+#pragma unroll
+  for (int d = 0; d < AHD; ++d) {
+    q[d] = to_f(qrow[d]);
+    dO[d] = to_f(drow[d]);
+    dq[d] = 0.f;
+  }
+  const int64_t Sp = (S + 63) / 64 * 64;
+  const float L = lse[bh * Sp + qc], dl = delta[bh * Sp + qc];
+  const int64_t kmax = (q0 + 63 < S - 1) ? q0 + 63 : S - 1;
+  for (int64_t k0 = 0; k0 <= kmax; k0 += 32) {
+    __syncthreads();
+    for (int i = threadIdx.x; i < 32 * AHD; i += 64) {
+      const int r = i / AHD, d = i % AHD;
+      const int64_t kj = k0 + r;
+      const T* krow = qkv + (b * S + (kj < S ? kj : S - 1)) * D3 + D + (int64_t)h * AHD;
+      ks[r][d] = to_f(krow[d]);
+      vs[r][d] = to_f(krow[D + d]);
+    }
+    __syncthreads();
+    if (!valid) continue;
+    for (int r = 0; r < 32; ++r) {
+      if (k0 + r > qi) break;
+      float s = 0.f, dp = 0.f;
+#pragma unroll
+      for (int d = 0; d < AHD; ++d) {
+        s += q[d] * ks[r][d];
+        dp += dO[d] * vs[r][d];
+      }
+      const float p = __expf(s * scale - L);
+      const float ds = p * (dp - dl) * scale;
+#pragma unroll
+      for (int d = 0; d < AHD; ++d) dq[d] += ds * ks[r][d];
+    }
+  }
+  if (valid) {
+    T* orow = dqkv + (b * S + qi) * D3 + (int64_t)h * AHD;
+#pragma unroll
+    for (int d = 0; d < AHD; ++d) orow[d] = from_f<T>(dq[d]);
+  }
+}
+
+// dK, dV: thread per key row, loops over the queries that see it
+template <typename T>
+__global__ __launch_bounds__(64) void attn_plain_bwd_dkv_kernel(const T* __restrict__ qkv, const T* __restrict__ dout,
+                                                                const float* __restrict__ lse, const float* __restrict__ delta,
+                                                                T* __restrict__ dqkv, int64_t S, int H, float scale) {
+  __shared__ float qs[32][AHD], ds_[32][AHD];
+  __shared__ float ls[32], dls[32];
+  const int64_t bh = blockIdx.y;
+  const int64_t b = bh / H;
+  const int h = (int)(bh - b * H);
+  const int64_t D = (int64_t)H * AHD, D3 = 3 * D;
+  const int64_t k0 = (int64_t)blockIdx.x * 64;
+  const int64_t kj = k0 + threadIdx.x;
+  const bool valid = kj < S;
+  float k[AHD], v[AHD], dk[AHD], dv[AHD];
+  const T* krow = qkv + (b * S + (valid ? kj : 0)) * D3 + D + (int64_t)h * AHD;
+#pragma unroll
+  for (int d = 0; d < AHD; ++d) {
+    k[d] = to_f(krow[d]);
+    v[d] = to_f(krow[D + d]);
+    dk[d] = dv[d] = 0.f;
+  }
+  for (int64_t q0 = k0 / 32 * 32; q0 < S; q0 += 32) {
+    __syncthreads();
+    for (int i = threadIdx.x; i < 32 * AHD; i += 64) {
+      const int r = i / AHD, d = i % AHD;
+      const int64_t qi = (q0 + r < S) ? q0 + r : S - 1;
+      qs[r][d] = to_f(qkv[(b * S + qi) * D3 + (int64_t)h * AHD + d]);
+      ds_[r][d] = to_f(dout[(b * S + qi) * D + (int64_t)h * AHD + d]);
+    }
+    if (threadIdx.x < 32) {
+      const int64_t qi = (q0 + threadIdx.x < S) ? q0 + threadIdx.x : S - 1;
+      ls[threadIdx.x] = lse[bh * ((S + 63) / 64 * 64) + qi];
+      dls[threadIdx.x] = delta[bh * ((S + 63) / 64 * 64) + qi];
+    }
+    __syncthreads();
+    if (!valid) continue;
+    for (int r = 0; r < 32; ++r) {
+      const int64_t qi = q0 + r;
+      if (qi >= S) break;
+      if (qi < kj) continue;
+      float s = 0.f, dp = 0.f;
+#pragma unroll
+      for (int d = 0; d < AHD; ++d) {
+        s += qs[r][d] * k[d];
+        dp += ds_[r][d] * v[d];
+      }
+      const float p = __expf(s * scale - ls[r]);
+      const float dsv = p * (dp - dls[r]) * scale;
+#pragma unroll
+      for (int d = 0; d < AHD; ++d) {
+        dv[d] += p * ds_[r][d];
+        dk[d] += dsv * qs[r][d];
+      }
+    }
+  }
+  if (valid) {
+    T* orow = dqkv + (b * S + kj) * D3 + D + (int64_t)h * AHD;
+#pragma unroll
+    for (int d = 0; d < AHD; ++d) {
+      orow[d] = from_f<T>(dk[d]);
+      orow[D + d] = from_f<T>(dv[d]);
+    }
+  }
+}
+
+// delta[b,h,s] = sum_d dO*O ; optionally the transposed copies X^T[b,h,d,s] (s contiguous, ld = Sp)
+template <typename T>
+__global__ __launch_bounds__(256) void attn_delta_kernel(const T* __restrict__ o, const T* __restrict__ dout,
+                                                         float* __restrict__ delta, int64_t B, int64_t S, int H) {
+  // 8 lanes per (row, head): 16-byte chunks of bf16 (or two of fp32)
+  const int64_t D = (int64_t)H * AHD;
+  const int64_t total = B * S * H;
+  const int sub = threadIdx.x & 7;
+  for (int64_t it = ((int64_t)blockIdx.x * 256 + threadIdx.x) >> 3; it < total; it += ((int64_t)gridDim.x * 256) >> 3) {
+    const int h = (int)(it % H);
+    const int64_t row = it / H;  // b*S + s
+    const T* po = o + row * D + (int64_t)h * AHD + sub * 8;
+    const T* pd = dout + row * D + (int64_t)h * AHD + sub * 8;
+    float s = 0.f;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) s += to_f(po[e]) * to_f(pd[e]);
+    s += __shfl_xor(s, 1, 64);
+    s += __shfl_xor(s, 2, 64);
+    s += __shfl_xor(s, 4, 64);
+    if (sub == 0) {
+      const int64_t b = row / S, sidx = row - b * S;
+      delta[(b * H + h) * ((S + 63) / 64 * 64) + sidx] = s;
+    }
+  }
+}
+
+// out[b,h,d,s] = in[(b*S+s)*ld + col0 + h*64 + d]   (64x64 tiles through LDS)
+template <typename T>
+__global__ __launch_bounds__(256) void attn_transpose_kernel(const T* __restrict__ in, int64_t ld, int64_t col0,
+                                                             T* __restrict__ out, int64_t S, int64_t Sp, int H) {
+  __shared__ T tile[64][64 + 4 / sizeof(T)];
+  const int64_t bh = blockIdx.y;
+  const int64_t b = bh / H;
+  const int h = (int)(bh - b * H);
+  const int64_t s0 = (int64_t)blockIdx.x * 64;
+  constexpr int N = Pack<T>::N, CPR = 64 / N, RPP = 256 / CPR;
+  const int ch = threadIdx.x % CPR, rr = threadIdx.x / CPR;
+  for (int p = 0; p < 64 / RPP; ++p) {
+    const int i = rr + p * RPP;
+    const int64_t s = s0 + i;
+    Pack<T> v;
+    if (s < S) {
+      v = ld16(in + (b * S + s) * ld + col0 + (int64_t)h * 64 + ch * N);
+    } else {
+#pragma unroll
+      for (int e = 0; e < N; ++e) v.set(e, 0.f);
+    }
+#pragma unroll
+    for (int e = 0; e < N; ++e) tile[i][ch * N + e] = v.v[e];
+  }
+  __syncthreads();
+  for (int p = 0; p < 64 / RPP; ++p) {
+    const int d = rr + p * RPP;
+    Pack<T> v;
+#pragma unroll
+    for (int e = 0; e < N; ++e) v.v[e] = tile[ch * N + e][d];
+    st16(out + (bh * 64 + d) * Sp + s0 + ch * N, v);
+  }
+}
+
+template <typename T>
+static int transpose_heads(const T* in, int64_t ld, int64_t col0, T* out, int64_t B, int64_t S, int H, hipStream_t st) {
+  const int64_t Sp = (S + 63) / 64 * 64;
+  dim3 grid((unsigned)(Sp / 64), (unsigned)(B * H));
+  attn_transpose_kernel<T><<<grid, 256, 0, st>>>(in, ld, col0, out, S, Sp, H);
+  MH_LAUNCH_CHECK();
+  return MH_OK;
+}
+
+extern "C" int mh_attn_prep_fwd(const void* qkv, void* vt, int64_t B, int64_t S, int H, int dtype, void* stream) {
+  MH_REQUIRE(B > 0 && S > 0 && H > 0 && B * H < 65536, "attn_prep_fwd: bad shape");
+  if (dtype != MH_BF16) return MH_OK;  // the fp32 verification kernels read qkv directly
+  const int64_t D = (int64_t)H * 64;
+  return transpose_heads<bf16>((const bf16*)qkv, 3 * D, 2 * D, (bf16*)vt, B, S, H, (hipStream_t)stream);
+}
+
+extern "C" int mh_attn_prep_bwd(const void* qkv, const void* o, const void* dout, float* delta, void* qt, void* kt,
+                                void* dot, int64_t B, int64_t S, int H, int dtype, void* stream) {
+  MH_REQUIRE(B > 0 && S > 0 && H > 0 && B * H < 65536, "attn_prep_bwd: bad shape");
+  hipStream_t st = (hipStream_t)stream;
+  const int64_t total = B * S * H;
+  int64_t g = (total * 8 + 255) / 256;
+  if (g > 16384) g = 16384;
+  DISPATCH_T(dtype, (attn_delta_kernel<T><<<(int)g, 256, 0, st>>>((const T*)o, (const T*)dout, delta, B, S, H)));
+  MH_LAUNCH_CHECK();
+  if (dtype != MH_BF16) return MH_OK;
+  const int64_t D = (int64_t)H * 64;
+  int rc;
+  if ((rc = transpose_heads<bf16>((const bf16*)qkv, 3 * D, 0, (bf16*)qt, B, S, H, st)) != MH_OK) return rc;
+  if ((rc = transpose_heads<bf16>((const bf16*)qkv, 3 * D, D, (bf16*)kt, B, S, H, st)) != MH_OK) return rc;
+  return transpose_heads<bf16>((const bf16*)dout, D, 0, (bf16*)dot, B, S, H, st);
+}
+
+// entry points shared with attention_mfma.hip (bf16 goes there)
+int mh_attn_fwd_mfma(const void* qkv, const void* vt, void* o, float* lse, int64_t B, int64_t S, int H, float scale,
+                     hipStream_t st);
+int mh_attn_bwd_mfma(const void* qkv, const void* dout, const float* lse, const float* delta, const void* qt,
+                     const void* kt, const void* dot, void* dqkv, int64_t B, int64_t S, int H, float scale, hipStream_t st);
+
+template <typename T>
+static int attn_plain_fwd(const void* qkv, void* o, float* lse, int64_t B, int64_t S, int H, float scale, hipStream_t st) {
+  dim3 grid((unsigned)((S + 63) / 64), (unsigned)(B * H));
+  attn_plain_fwd_kernel<T><<<grid, 64, 0, st>>>((const T*)qkv, (T*)o, lse, S, H, scale);
+  MH_LAUNCH_CHECK();
+  return MH_OK;
+}
+
+template <typename T>
+static int attn_plain_bwd(const void* qkv, const void* dout, const float* lse, const float* delta, void* dqkv, int64_t B,
+                          int64_t S, int H, float scale, hipStream_t st) {
+  dim3 grid((unsigned)((S + 63) / 64), (unsigned)(B * H));
+  attn_plain_bwd_dq_kernel<T><<<grid, 64, 0, st>>>((const T*)qkv, (const T*)dout, lse, delta, (T*)dqkv, S, H, scale);
+  MH_LAUNCH_CHECK();
+  attn_plain_bwd_dkv_kernel<T><<<grid, 64, 0, st>>>((const T*)qkv, (const T*)dout, lse, delta, (T*)dqkv, S, H, scale);
+  MH_LAUNCH_CHECK();
+  return MH_OK;
+}
+
+// `mh_attn_*_plain` force the thread-per-row kernels for either dtype (used by tests to cross-check the
+// MFMA kernels on the device itself).
+extern "C" int mh_attn_fwd_plain(const void* qkv, void* o, float* lse, int64_t B, int64_t S, int H, float scale,
+                                 int dtype, void* stream) {
+  MH_REQUIRE(B > 0 && S > 0 && H > 0 && B * H < 65536, "attn_fwd: bad shape");
+  DISPATCH_T(dtype, return attn_plain_fwd<T>(qkv, o, lse, B, S, H, scale, (hipStream_t)stream));
+}
+
+extern "C" int mh_attn_bwd_plain(const void* qkv, const void* dout, const float* lse, const float* delta, void* dqkv,
+                                 int64_t B, int64_t S, int H, float scale, int dtype, void* stream) {
+  MH_REQUIRE(B > 0 && S > 0 && H > 0 && B * H < 65536, "attn_bwd: bad shape");
+  DISPATCH_T(dtype, return attn_plain_bwd<T>(qkv, dout, lse, delta, dqkv, B, S, H, scale, (hipStream_t)stream));
+}
+
+extern "C" int mh_attn_fwd(const void* qkv, const void* vt, void* o, float* lse, int64_t B, int64_t S, int H, float scale,
+                           int dtype, void* stream) {
+  MH_REQUIRE(B > 0 && S > 0 && H > 0 && B * H < 65536, "attn_fwd: bad shape");
+  if (dtype == MH_BF16) return mh_attn_fwd_mfma(qkv, vt, o, lse, B, S, H, scale, (hipStream_t)stream);
+  if (dtype == MH_F32) return attn_plain_fwd<float>(qkv, o, lse, B, S, H, scale, (hipStream_t)stream);
+  mh_set_error("attn_fwd: bad dtype");
+  return MH_ERR_ARG;
+}
+
+extern "C" int mh_attn_bwd(const void* qkv, const void* dout, const float* lse, const float* delta, const void* qt,
+                           const void* kt, const void* dot, void* dqkv, int64_t B, int64_t S, int H, float scale,
+                           int dtype, void* stream) {
+  MH_REQUIRE(B > 0 && S > 0 && H > 0 && B * H < 65536, "attn_bwd: bad shape");
+  if (dtype == MH_BF16)
+    return mh_attn_bwd_mfma(qkv, dout, lse, delta, qt, kt, dot, dqkv, B, S, H, scale, (hipStream_t)stream);
+  if (dtype == MH_F32) return attn_plain_bwd<float>(qkv, dout, lse, delta, dqkv, B, S, H, scale, (hipStream_t)stream);
+  mh_set_error("attn_bwd: bad dtype");
+  return MH_ERR_ARG;
+}

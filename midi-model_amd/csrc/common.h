@@ -1,0 +1,88 @@
+// Shared device helpers for the gfx950 (MI355X, CDNA4) kernels of the midi-model hot path.
+// wave = 64 lanes everywhere; no other architecture is targeted.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/midihip.h"
+
+#define MH_WAVE 64
+
+typedef __bf16 bf16;
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((address_space(3))) void lds_void_t;
+typedef __attribute__((address_space(1))) const void glb_void_t;
+
+// ---- error plumbing (host) ----------------------------------------------------------------
+void mh_set_error(const char* fmt, ...);
+#define MH_REQUIRE(cond, ...)            \
+  do {                                   \
+    if (!(cond)) {                       \
+      mh_set_error(__VA_ARGS__);         \
+      return MH_ERR_ARG;                 \
+    }                                    \
+  } while (0)
+#define MH_LAUNCH_CHECK()                                            \
+  do {                                                               \
+    hipError_t e_ = hipGetLastError();                               \
+    if (e_ != hipSuccess) {                                          \
+      mh_set_error("%s:%d launch failed: %s", __FILE__, __LINE__, hipGetErrorString(e_)); \
+      return MH_ERR_LAUNCH;                                          \
+    }                                                                \
+  } while (0)
+
+// ---- 16-byte vectors of T ---------------------------------------------------------------------
+template <typename T> struct Pack;  // 16 bytes of T, convertible to/from fp32 lanes
+template <> struct Pack<float> {
+  static constexpr int N = 4;
+  f32x4 v;
+  __device__ float get(int i) const { return v[i]; }
+  __device__ void set(int i, float f) { v[i] = f; }
+};
+template <> struct Pack<bf16> {
+  static constexpr int N = 8;
+  bf16x8 v;
+  __device__ float get(int i) const { return (float)v[i]; }
+  __device__ void set(int i, float f) { v[i] = (bf16)f; }
+};
+template <typename T> __device__ inline Pack<T> ld16(const T* p) { return *reinterpret_cast<const Pack<T>*>(p); }
+template <typename T> __device__ inline void st16(T* p, const Pack<T>& v) { *reinterpret_cast<Pack<T>*>(p) = v; }
+
+template <typename T> __device__ inline float to_f(T x) { return (float)x; }
+template <typename T> __device__ inline T from_f(float x) { return (T)x; }
+// round an fp32 value through T (used where the reference rounds an intermediate to the activation dtype)
+template <typename T> __device__ inline float rnd(float x) { return (float)(T)x; }
+
+// ---- wave reductions --------------------------------------------------------------------------
+__device__ inline float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ inline float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+
+// ---- LDS tile format shared by the MFMA kernels -----------------------------------------------
+// A tile is ROWS x 128 bytes (64 bf16 or 32 fp32 along the contraction).  The eight 16-byte chunks of
+// a row are XOR-swizzled with ((row>>1)&7) so that the ds_read_b128 fragment reads of both MFMA
+// shapes (16x16: lane (i=l&15,g=l>>4) -> row i, chunk 4kk+g; 32x32: lane (i=l&31,hi=l>>5) -> row
+// pi(i), chunk 2s+hi) hit 16 distinct 16-byte slots per lane group (MI355X_MICROARCH §LDS).
+__device__ inline int lds_tile_off(int row, int chunk) { return row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4); }
+
+// Direct global->LDS staging (global_load_lds_dwordx4): one call moves 1 KiB = 8 tile rows per
+// wave.  The LDS image is lane-linear (base + lane*16), so the swizzle goes on the SOURCE chunk.
+// `lds_rows8` is the wave-uniform LDS address of the 8-row group; `src` the lane's global address.
+__device__ inline void glds16(const void* src, void* lds_rows8) {
+  __builtin_amdgcn_global_load_lds((glb_void_t*)src, (lds_void_t*)lds_rows8, 16, 0, 0);
+}
+
+// 32x32 MFMA row permutation: swap bits 2 and 3 of the row index.  Feeding operand row i from
+// tile row pi(i) makes accumulator registers 8t..8t+7 of lane half `hi` correspond to tile rows
+// 16t+8hi..16t+8hi+7, i.e. a contiguous 8-element run that is directly the next MFMA's operand.
+__device__ inline int pi32(int i) { return (i & ~12) | ((i & 4) << 1) | ((i & 8) >> 1); }

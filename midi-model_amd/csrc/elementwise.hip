@@ -1,0 +1,390 @@
+// HBM-bound kernels of the path: embeddings, RMSNorm, RoPE, SwiGLU and their backward passes.
+// All of them stream rows with 16-byte vector accesses (8 bf16 / 4 fp32 per lane), keep statistics in
+// fp32, and reduce across the 64-lane wave with shuffles.  Roofline: HBM (8 TB/s spec).
+#include "common.h"
+
+#define DISPATCH_T(dtype, CALL)                                    \
+  do {                                                             \
+    if ((dtype) == MH_BF16) { using T = bf16; CALL; }              \
+    else if ((dtype) == MH_F32) { using T = float; CALL; }         \
+    else { mh_set_error("bad dtype %d", (int)(dtype)); return MH_ERR_ARG; } \
+  } while (0)
+
+static inline int grid_for(int64_t items, int per_block, int cap = 1 << 20) {
+  int64_t g = (items + per_block - 1) / per_block;
+  if (g < 1) g = 1;
+  if (g > cap) g = cap;
+  return (int)g;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// embeddings
+// ---------------------------------------------------------------------------------------------------
+// one wave per event row: out[m,:] = sum_j table[tok[m,j],:]
+template <typename T>
+__global__ __launch_bounds__(256) void embed_sum_fwd_kernel(const int64_t* __restrict__ tok, const T* __restrict__ table,
+                                                            T* __restrict__ out, int64_t M, int TT, int D) {
+  constexpr int N = Pack<T>::N;
+  const int lane = threadIdx.x & 63;
+  const int64_t wave0 = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  for (int64_t m = wave0; m < M; m += (int64_t)gridDim.x * 4) {
+    for (int c = lane * N; c < D; c += 64 * N) {
+      float acc[N];
+#pragma unroll
+      for (int e = 0; e < N; ++e) acc[e] = 0.f;
+      for (int j = 0; j < TT; ++j) {
+        const int64_t id = tok[m * TT + j];
+        Pack<T> v = ld16(table + id * D + c);
+#pragma unroll
+        for (int e = 0; e < N; ++e) acc[e] += v.get(e);
+      }
+      Pack<T> o;
+#pragma unroll
+      for (int e = 0; e < N; ++e) o.set(e, acc[e]);
+      st16(out + m * D + c, o);
+    }
+  }
+}
+
+extern "C" int mh_embed_sum_fwd(const int64_t* tok, const void* table, void* out, int64_t M, int T_, int64_t V, int D,
+                                int dtype, void* stream) {
+  MH_REQUIRE(M > 0 && T_ > 0 && D % 8 == 0, "embed_sum_fwd: bad shape M=%ld T=%d D=%d", (long)M, T_, D);
+  DISPATCH_T(dtype, (embed_sum_fwd_kernel<T><<<grid_for(M, 4, 65536), 256, 0, (hipStream_t)stream>>>(
+                        tok, (const T*)table, (T*)out, M, T_, D)));
+  MH_LAUNCH_CHECK();
+  return MH_OK;
+}
+
+// out[m,0,:] = hidden[m,:]; out[m,j,:] = table[tok[m*ldtok + j-1],:]
+template <typename T>
+__global__ __launch_bounds__(256) void concat_tok_fwd_kernel(const T* __restrict__ hidden, const int64_t* __restrict__ tok,
+                                                             int64_t ldtok, const T* __restrict__ table,
+                                                             T* __restrict__ out, int64_t M, int TT, int D) {
+  constexpr int N = Pack<T>::N;
+  const int lane = threadIdx.x & 63;
+  const int64_t rows = M * TT;
+  for (int64_t r = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); r < rows; r += (int64_t)gridDim.x * 4) {
+    const int64_t m = r / TT;
+    const int j = (int)(r - m * TT);
+    const T* src = (j == 0) ? hidden + m * D : table + tok[m * ldtok + j - 1] * D;
+    for (int c = lane * N; c < D; c += 64 * N) st16(out + r * D + c, ld16(src + c));
+  }
+}
+
+extern "C" int mh_concat_tok_fwd(const void* hidden, const int64_t* tok, int64_t ldtok, const void* table, void* out,
+                                 int64_t M, int T_, int64_t V, int D, int dtype, void* stream) {
+  MH_REQUIRE(M > 0 && T_ > 0 && D % 8 == 0, "concat_tok_fwd: bad shape");
+  DISPATCH_T(dtype, (concat_tok_fwd_kernel<T><<<grid_for(M * T_, 4, 65536), 256, 0, (hipStream_t)stream>>>(
+                        (const T*)hidden, tok, ldtok, (const T*)table, (T*)out, M, T_, D)));
+  MH_LAUNCH_CHECK();
+  return MH_OK;
+}
+
+// scatter-add of embedding-row gradients into an fp32 [V,D] accumulator (hardware fp32 atomics)
+template <typename T>
+__global__ __launch_bounds__(256) void embed_scatter_bwd_kernel(const int64_t* __restrict__ tok, int64_t ldtok, int TT,
+                                                                const T* __restrict__ dout, int rows_per_m, int jstride,
+                                                                int j0, float* __restrict__ dtab, int64_t M, int D,
+                                                                int64_t pad_id) {
+  constexpr int N = Pack<T>::N;
+  const int lane = threadIdx.x & 63;
+  const int64_t items = M * TT;
+  for (int64_t it = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); it < items; it += (int64_t)gridDim.x * 4) {
+    const int64_t m = it / TT;
+    const int j = (int)(it - m * TT);
+    const int64_t id = tok[m * ldtok + j];
+    if (id == pad_id) continue;
+    const T* src = dout + (m * rows_per_m + (int64_t)j * jstride + j0) * (int64_t)D;
+    float* dst = dtab + id * D;
+    for (int c = lane * N; c < D; c += 64 * N) {
+      Pack<T> v = ld16(src + c);
+#pragma unroll
+      for (int e = 0; e < N; ++e) atomicAdd(dst + c + e, v.get(e));
+    }
+  }
+}
+
+extern "C" int mh_embed_scatter_bwd(const int64_t* tok, int64_t ldtok, int T_, const void* dout, int rows_per_m,
+                                    int jstride, int j0, float* dtable_f32, int64_t M, int64_t V, int D, int64_t pad_id, int dtype,
+                                    void* stream) {
+  MH_REQUIRE(M > 0 && T_ > 0 && D % 8 == 0, "embed_scatter_bwd: bad shape");
+  DISPATCH_T(dtype, (embed_scatter_bwd_kernel<T><<<grid_for(M * T_, 4, 16384), 256, 0, (hipStream_t)stream>>>(
+                        tok, ldtok, T_, (const T*)dout, rows_per_m, jstride, j0, dtable_f32, M, D, pad_id)));
+  MH_LAUNCH_CHECK();
+  return MH_OK;
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void cast_from_f32_kernel(const float* __restrict__ src, T* __restrict__ dst, int64_t n,
+                                                            int accumulate) {
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+    float v = src[i];
+    if (accumulate) v += to_f(dst[i]);
+    dst[i] = from_f<T>(v);
+  }
+}
+
+extern "C" int mh_cast_from_f32(const float* src, void* dst, int64_t n, int accumulate, int dtype, void* stream) {
+  MH_REQUIRE(n > 0, "cast_from_f32: empty");
+  DISPATCH_T(dtype, (cast_from_f32_kernel<T><<<grid_for(n, 256, 4096), 256, 0, (hipStream_t)stream>>>(src, (T*)dst, n,
+                                                                                                     accumulate)));
+  MH_LAUNCH_CHECK();
+  return MH_OK;
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void copy_rows_kernel(const T* __restrict__ src, int64_t src_ld, T* __restrict__ dst,
+                                                        int64_t dst_ld, int64_t M, int D, int accumulate) {
+  constexpr int N = Pack<T>::N;
+  const int lane = threadIdx.x & 63;
+  for (int64_t m = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); m < M; m += (int64_t)gridDim.x * 4) {
+    for (int c = lane * N; c < D; c += 64 * N) {
+      Pack<T> v = ld16(src + m * src_ld + c);
+      if (accumulate) {
+        Pack<T> o = ld16(dst + m * dst_ld + c);
+#pragma unroll
+        for (int e = 0; e < N; ++e) v.set(e, v.get(e) + o.get(e));
+      }
+      st16(dst + m * dst_ld + c, v);
+    }
+  }
+}
+
+extern "C" int mh_copy_rows(const void* src, int64_t src_ld, void* dst, int64_t dst_ld, int64_t M, int D, int accumulate,
+                            int dtype, void* stream) {
+  MH_REQUIRE(M > 0 && D % 8 == 0 && src_ld % 8 == 0 && dst_ld % 8 == 0, "copy_rows: bad shape");
+  DISPATCH_T(dtype, (copy_rows_kernel<T><<<grid_for(M, 4, 65536), 256, 0, (hipStream_t)stream>>>(
+                        (const T*)src, src_ld, (T*)dst, dst_ld, M, D, accumulate)));
+  MH_LAUNCH_CHECK();
+  return MH_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// RMSNorm: one wave per row, two passes over the row (second one is an L1/L2 hit)
+// ---------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void rmsnorm_fwd_kernel(const T* __restrict__ x, const T* __restrict__ w,
+                                                          T* __restrict__ y, float* __restrict__ rstd, int64_t M, int D,
+                                                          float eps) {
+  constexpr int N = Pack<T>::N;
+  const int lane = threadIdx.x & 63;
+  for (int64_t m = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); m < M; m += (int64_t)gridDim.x * 4) {
+    const T* xr = x + m * D;
+    float ss = 0.f;
+    for (int c = lane * N; c < D; c += 64 * N) {
+      Pack<T> v = ld16(xr + c);
+#pragma unroll
+      for (int e = 0; e < N; ++e) ss += v.get(e) * v.get(e);
+    }
+    ss = wave_sum(ss);
+    const float r = rsqrtf(ss / (float)D + eps);
+    if (lane == 0 && rstd != nullptr) rstd[m] = r;
+    for (int c = lane * N; c < D; c += 64 * N) {
+      Pack<T> v = ld16(xr + c), ww = ld16(w + c), o;
+#pragma unroll
+      for (int e = 0; e < N; ++e) o.set(e, ww.get(e) * rnd<T>(v.get(e) * r));
+      st16(y + m * D + c, o);
+    }
+  }
+}
+
+extern "C" int mh_rmsnorm_fwd(const void* x, const void* w, void* y, float* rstd, int64_t M, int D, float eps,
+                              int dtype, void* stream) {
+  MH_REQUIRE(M > 0 && D % 8 == 0, "rmsnorm_fwd: bad shape M=%ld D=%d", (long)M, D);
+  DISPATCH_T(dtype, (rmsnorm_fwd_kernel<T><<<grid_for(M, 4, 65536), 256, 0, (hipStream_t)stream>>>(
+                        (const T*)x, (const T*)w, (T*)y, rstd, M, D, eps)));
+  MH_LAUNCH_CHECK();
+  return MH_OK;
+}
+
+// backward.  g = dy*w, xhat = x*rstd, dx = rstd*(g - xhat*mean(g*xhat)) (+dres); dw += dy*xhat per column.
+// Each wave walks rows with a fixed stride, so a lane always owns the same columns and keeps its dw
+// partial sums in LDS-free registers via a [D] LDS accumulator per wave (D <= 8192).
+constexpr int RMS_BWD_MAX_BLOCKS = 1024;
+extern "C" int mh_rmsnorm_bwd_blocks(int64_t M) {
+  int64_t g = (M + 3) / 4;
+  return (int)(g < RMS_BWD_MAX_BLOCKS ? (g < 1 ? 1 : g) : RMS_BWD_MAX_BLOCKS);
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void rmsnorm_bwd_kernel(const T* __restrict__ x, const T* __restrict__ w,
+                                                          const float* __restrict__ rstd, const T* __restrict__ dy,
+                                                          const T* dres, T* dx, float* __restrict__ dw_partial,
+                                                          int64_t M, int D) {
+  constexpr int N = Pack<T>::N;
+  extern __shared__ __attribute__((aligned(16))) float dw_acc[];  // [4][D]
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  float* mine = dw_acc + wv * D;
+  for (int c = lane; c < D; c += 64) mine[c] = 0.f;
+  __syncthreads();
+  // (each lane only ever touches its own columns of `mine`, no barrier needed until the final reduce)
+  for (int64_t m = (int64_t)blockIdx.x * 4 + wv; m < M; m += (int64_t)gridDim.x * 4) {
+    const T* xr = x + m * D;
+    const T* gr = dy + m * D;
+    const float r = rstd[m];
+    float dot = 0.f;
+    for (int c = lane * N; c < D; c += 64 * N) {
+      Pack<T> xv = ld16(xr + c), gv = ld16(gr + c), wv_ = ld16(w + c);
+#pragma unroll
+      for (int e = 0; e < N; ++e) dot += gv.get(e) * wv_.get(e) * (xv.get(e) * r);
+    }
+    dot = wave_sum(dot) / (float)D;
+    for (int c = lane * N; c < D; c += 64 * N) {
+      Pack<T> xv = ld16(xr + c), gv = ld16(gr + c), wv_ = ld16(w + c), o;
+      Pack<T> rv;
+      if (dres != nullptr) rv = ld16(dres + m * D + c);
+#pragma unroll
+      for (int e = 0; e < N; ++e) {
+        const float xh = xv.get(e) * r;
+        float d = r * (gv.get(e) * wv_.get(e) - xh * dot);
+        if (dres != nullptr) d += rv.get(e);
+        o.set(e, d);
+        mine[c + e] += gv.get(e) * rnd<T>(xh);
+      }
+      st16(dx + m * D + c, o);
+    }
+  }
+  __syncthreads();
+  for (int c = threadIdx.x; c < D; c += 256)
+    dw_partial[(int64_t)blockIdx.x * D + c] = dw_acc[c] + dw_acc[D + c] + dw_acc[2 * D + c] + dw_acc[3 * D + c];
+}
+
+extern "C" int mh_rmsnorm_bwd(const void* x, const void* w, const float* rstd, const void* dy, const void* dres,
+                              void* dx, float* dw_partial, int64_t M, int D, int dtype, void* stream) {
+  MH_REQUIRE(M > 0 && D % 8 == 0 && D <= 8192, "rmsnorm_bwd: bad shape M=%ld D=%d", (long)M, D);
+  const int blocks = mh_rmsnorm_bwd_blocks(M);
+  const size_t shm = (size_t)4 * D * sizeof(float);
+  DISPATCH_T(dtype, (rmsnorm_bwd_kernel<T><<<blocks, 256, shm, (hipStream_t)stream>>>(
+                        (const T*)x, (const T*)w, rstd, (const T*)dy, (const T*)dres, (T*)dx, dw_partial, M, D)));
+  MH_LAUNCH_CHECK();
+  return MH_OK;
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ partial, int64_t nblk, T* __restrict__ out,
+                                                     int D, int accumulate) {
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  if (c >= D) return;
+  float s = 0.f;
+  for (int64_t b = 0; b < nblk; ++b) s += partial[b * D + c];
+  if (accumulate) s += to_f(out[c]);
+  out[c] = from_f<T>(s);
+}
+
+extern "C" int mh_colsum(const float* partial, int64_t nblk, void* out, int D, int accumulate, int dtype, void* stream) {
+  MH_REQUIRE(nblk > 0 && D > 0, "colsum: bad shape");
+  DISPATCH_T(dtype, (colsum_kernel<T><<<(D + 255) / 256, 256, 0, (hipStream_t)stream>>>(partial, nblk, (T*)out, D,
+                                                                                        accumulate)));
+  MH_LAUNCH_CHECK();
+  return MH_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// RoPE, in place on the q and k thirds of qkv[M, 3*H*hd].  Pair (i, i+hd/2); cos/sin tables are fp32
+// and are rounded to the activation dtype before use (the reference casts them, modeling_llama.py:126).
+// ---------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void rope_kernel(T* __restrict__ qkv, const float* __restrict__ cos_t,
+                                                   const float* __restrict__ sin_t, int64_t M, int64_t S, int64_t pos0,
+                                                   int H, int hd, float dir) {
+  constexpr int N = Pack<T>::N;
+  const int half = hd / 2;
+  const int cph = half / N;                 // 16-byte chunks per half head
+  const int64_t per_row = (int64_t)2 * H * cph;  // q and k
+  const int64_t total = M * per_row;
+  const int64_t D3 = (int64_t)3 * H * hd;
+  for (int64_t it = (int64_t)blockIdx.x * 256 + threadIdx.x; it < total; it += (int64_t)gridDim.x * 256) {
+    const int64_t m = it / per_row;
+    int rem = (int)(it - m * per_row);
+    const int ch = rem % cph;
+    rem /= cph;
+    const int h = rem % H;
+    const int part = rem / H;  // 0 = q, 1 = k
+    const int64_t pos = pos0 + (m % S);
+    T* p1 = qkv + m * D3 + (int64_t)part * H * hd + (int64_t)h * hd + ch * N;
+    T* p2 = p1 + half;
+    Pack<T> a = ld16(p1), b = ld16(p2), oa, ob;
+    const float* cp = cos_t + pos * half + ch * N;
+    const float* sp = sin_t + pos * half + ch * N;
+#pragma unroll
+    for (int e = 0; e < N; ++e) {
+      const float c = rnd<T>(cp[e]), s = dir * rnd<T>(sp[e]);
+      const float x1 = a.get(e), x2 = b.get(e);
+      oa.set(e, x1 * c - x2 * s);
+      ob.set(e, x2 * c + x1 * s);
+    }
+    st16(p1, oa);
+    st16(p2, ob);
+  }
+}
+
+extern "C" int mh_rope(void* qkv, const float* cos_t, const float* sin_t, int64_t M, int64_t S, int64_t pos0, int H,
+                       int hd, int dir, int dtype, void* stream) {
+  MH_REQUIRE(M > 0 && S > 0 && hd % 16 == 0, "rope: bad shape");
+  const int64_t total = M * 2 * H * (hd / 2 / (dtype == MH_BF16 ? 8 : 4));
+  DISPATCH_T(dtype, (rope_kernel<T><<<grid_for(total, 256, 16384), 256, 0, (hipStream_t)stream>>>(
+                        (T*)qkv, cos_t, sin_t, M, S, pos0, H, hd, dir >= 0 ? 1.f : -1.f)));
+  MH_LAUNCH_CHECK();
+  return MH_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// SwiGLU
+// ---------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void swiglu_fwd_kernel(const T* __restrict__ gu, T* __restrict__ a, int64_t M, int I) {
+  constexpr int N = Pack<T>::N;
+  const int cpr = I / N;
+  const int64_t total = M * cpr;
+  for (int64_t it = (int64_t)blockIdx.x * 256 + threadIdx.x; it < total; it += (int64_t)gridDim.x * 256) {
+    const int64_t m = it / cpr;
+    const int c = (int)(it - m * cpr) * N;
+    Pack<T> g = ld16(gu + m * 2 * I + c), u = ld16(gu + m * 2 * I + I + c), o;
+#pragma unroll
+    for (int e = 0; e < N; ++e) {
+      const float gv = g.get(e);
+      const float s = rnd<T>(gv / (1.f + __expf(-gv)));
+      o.set(e, s * u.get(e));
+    }
+    st16(a + m * I + c, o);
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void swiglu_bwd_kernel(const T* __restrict__ gu, const T* __restrict__ da,
+                                                         T* __restrict__ dgu, int64_t M, int I) {
+  constexpr int N = Pack<T>::N;
+  const int cpr = I / N;
+  const int64_t total = M * cpr;
+  for (int64_t it = (int64_t)blockIdx.x * 256 + threadIdx.x; it < total; it += (int64_t)gridDim.x * 256) {
+    const int64_t m = it / cpr;
+    const int c = (int)(it - m * cpr) * N;
+    Pack<T> g = ld16(gu + m * 2 * I + c), u = ld16(gu + m * 2 * I + I + c), d = ld16(da + m * I + c), og, ou;
+#pragma unroll
+    for (int e = 0; e < N; ++e) {
+      const float gv = g.get(e), dv = d.get(e);
+      const float sig = 1.f / (1.f + __expf(-gv));
+      const float silu = gv * sig;
+      og.set(e, dv * u.get(e) * (sig * (1.f + gv * (1.f - sig))));
+      ou.set(e, dv * silu);
+    }
+    st16(dgu + m * 2 * I + c, og);
+    st16(dgu + m * 2 * I + I + c, ou);
+  }
+}
+
+extern "C" int mh_swiglu_fwd(const void* gu, void* a, int64_t M, int I, int dtype, void* stream) {
+  MH_REQUIRE(M > 0 && I % 8 == 0, "swiglu_fwd: bad shape");
+  DISPATCH_T(dtype, (swiglu_fwd_kernel<T><<<grid_for(M * (I / 4), 256, 16384), 256, 0, (hipStream_t)stream>>>(
+                        (const T*)gu, (T*)a, M, I)));
+  MH_LAUNCH_CHECK();
+  return MH_OK;
+}
+
+extern "C" int mh_swiglu_bwd(const void* gu, const void* da, void* dgu, int64_t M, int I, int dtype, void* stream) {
+  MH_REQUIRE(M > 0 && I % 8 == 0, "swiglu_bwd: bad shape");
+  DISPATCH_T(dtype, (swiglu_bwd_kernel<T><<<grid_for(M * (I / 4), 256, 16384), 256, 0, (hipStream_t)stream>>>(
+                        (const T*)gu, (const T*)da, (T*)dgu, M, I)));
+  MH_LAUNCH_CHECK();
+  return MH_OK;
+}

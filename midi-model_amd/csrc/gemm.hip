@@ -1,0 +1,289 @@
+// Dense projections on the matrix cores: C = alpha * A[M,K] * B[N,K]^T + beta * R.
+//
+// gfx950 design (first structure; see DESIGN.md for the roofline and the planned 256^2 8-phase step):
+//   * 128x128 block tile, 4 waves (2x2), each wave 64x64 = 4x4 fragments of v_mfma_f32_16x16x32_bf16
+//     (fp32 verification mode: v_mfma_f32_16x16x4_f32, exact fp32).
+//   * K-step = 128 bytes per row (64 bf16 / 32 fp32).  Tiles go HBM -> LDS with global_load_lds_dwordx4
+//     (no VGPR round trip, no ds_write pass), double-buffered, one barrier per K-step.
+//   * LDS rows are 128 B with the 16-byte chunks XOR-swizzled (common.h) so every ds_read_b128 lane
+//     group touches 16 distinct slots; the swizzle is applied on the per-lane SOURCE address because the
+//     LDS-DMA destination is lane-linear.
+//   * Out-of-range rows / contraction tails read a 16-byte zero block instead of being predicated.
+//   * Block ids are remapped so each XCD (private L2) owns a contiguous run of tiles that share the A panel.
+//   * The MFMA is issued "swapped" (B rows as the MFMA row index) so each lane ends with 4 consecutive
+//     output columns -> 8/16-byte stores.
+//   * split-K (grid.z) for the weight-gradient shapes (small M,N, huge K): fp32 partials + reduce kernel.
+#include "common.h"
+
+__device__ __attribute__((aligned(16))) char g_zero16[16];
+
+template <typename T> struct Mma;
+template <> struct Mma<bf16> {
+  __device__ static inline f32x4 run(const Pack<bf16>& a, const Pack<bf16>& b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a.v, b.v, c, 0, 0, 0);
+  }
+};
+template <> struct Mma<float> {
+  // lane group g holds k = 4g..4g+3 of a 16-wide k block: four exact-fp32 16x16x4 MFMAs, element e
+  // pairing A's and B's e-th value (any consistent k assignment gives the same dot product).
+  __device__ static inline f32x4 run(const Pack<float>& a, const Pack<float>& b, f32x4 c) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) c = __builtin_amdgcn_mfma_f32_16x16x4f32(a.v[e], b.v[e], c, 0, 0, 0);
+    return c;
+  }
+};
+
+constexpr int BM = 128, BN = 128;
+constexpr int TILE_BYTES = 128 * 128;  // 128 rows x 128 B
+
+template <typename T>
+__device__ inline void stage_tile(const T* __restrict__ base, int64_t ld, int64_t row0, int64_t nrows, int64_t k0,
+                                  int64_t kend, char* lds_tile, int wave, int lane) {
+  constexpr int EPC = 16 / sizeof(T);  // elements per 16-byte chunk
+  const int rsub = lane >> 3, pc = lane & 7;
+#pragma unroll
+  for (int it = 0; it < 4; ++it) {
+    const int g8 = wave + 4 * it;  // 8-row group handled by this wave
+    const int r = g8 * 8 + rsub;
+    const int c = pc ^ ((r >> 1) & 7);
+    const int64_t grow = row0 + r;
+    const int64_t k = k0 + (int64_t)c * EPC;
+    const void* src = (grow < nrows && k < kend) ? (const void*)(base + grow * ld + k) : (const void*)g_zero16;
+    glds16(src, lds_tile + g8 * 1024);
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void gemm_nt_kernel(const T* __restrict__ A, int64_t lda, const T* __restrict__ B,
+                                                      int64_t ldb, T* C, int64_t ldc, const T* R, int64_t ldr, int64_t M, int64_t N,
+                                                      int64_t K, float alpha, float beta, int tiles_n, int nwg,
+                                                      int64_t k_per_split, float* __restrict__ ws) {
+  __shared__ __attribute__((aligned(16))) char smem[4 * TILE_BYTES];  // [stage][A|B]
+  constexpr int BK = 128 / sizeof(T);
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 1, wn = wave & 1;
+
+  // XCD-aware bijective remap: dispatcher places block b on XCD b%8; give each XCD a contiguous tile run.
+  const int bid = blockIdx.x;
+  const int q = nwg >> 3, r8 = nwg & 7, xcd = bid & 7;
+  const int swz = (xcd < r8 ? xcd * (q + 1) : r8 * (q + 1) + (xcd - r8) * q) + (bid >> 3);
+  const int tm = swz / tiles_n, tn = swz - tm * tiles_n;
+  const int64_t m0 = (int64_t)tm * BM, n0 = (int64_t)tn * BN;
+
+  const int64_t kbeg = (int64_t)blockIdx.z * k_per_split;
+  const int64_t kend = (kbeg + k_per_split < K) ? kbeg + k_per_split : K;
+  const int nt = (int)((kend - kbeg + BK - 1) / BK);
+
+  f32x4 acc[4][4];
+#pragma unroll
+  for (int a = 0; a < 4; ++a)
+#pragma unroll
+    for (int b = 0; b < 4; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  const int fi = lane & 15, fg = lane >> 4;
+
+  if (nt > 0) {
+    stage_tile<T>(A, lda, m0, M, kbeg, kend, smem, wave, lane);
+    stage_tile<T>(B, ldb, n0, N, kbeg, kend, smem + TILE_BYTES, wave, lane);
+  }
+  __syncthreads();
+  for (int t = 0; t < nt; ++t) {
+    char* cur = smem + (t & 1) * 2 * TILE_BYTES;
+    char* nxt = smem + ((t + 1) & 1) * 2 * TILE_BYTES;
+    if (t + 1 < nt) {
+      const int64_t k0 = kbeg + (int64_t)(t + 1) * BK;
+      stage_tile<T>(A, lda, m0, M, k0, kend, nxt, wave, lane);
+      stage_tile<T>(B, ldb, n0, N, k0, kend, nxt + TILE_BYTES, wave, lane);
+    }
+    const char* tA = cur;
+    const char* tB = cur + TILE_BYTES;
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+      Pack<T> fx[4], fw[4];
+#pragma unroll
+      for (int f = 0; f < 4; ++f) {
+        fw[f] = *reinterpret_cast<const Pack<T>*>(tB + lds_tile_off(wn * 64 + f * 16 + fi, kk * 4 + fg));
+        fx[f] = *reinterpret_cast<const Pack<T>*>(tA + lds_tile_off(wm * 64 + f * 16 + fi, kk * 4 + fg));
+      }
+#pragma unroll
+      for (int fn = 0; fn < 4; ++fn)
+#pragma unroll
+        for (int fm = 0; fm < 4; ++fm) acc[fn][fm] = Mma<T>::run(fw[fn], fx[fm], acc[fn][fm]);
+    }
+    __syncthreads();
+  }
+
+  // epilogue: lane (fi, fg) of fragment (fn, fm) holds C[m][n..n+3], m = ..+fi, n = ..+4*fg
+  const bool partial = (gridDim.z > 1);
+  float* wsz = partial ? ws + (int64_t)blockIdx.z * M * N : nullptr;
+  const bool vec_ok = partial ? ((N & 3) == 0)
+                              : ((ldc & 3) == 0 && ((uintptr_t)C & 15) == 0 &&
+                                 (R == nullptr || ((ldr & 3) == 0 && ((uintptr_t)R & 15) == 0)));
+#pragma unroll
+  for (int fm = 0; fm < 4; ++fm) {
+    const int64_t m = m0 + wm * 64 + fm * 16 + fi;
+    if (m >= M) continue;
+#pragma unroll
+    for (int fn = 0; fn < 4; ++fn) {
+      const int64_t n = n0 + wn * 64 + fn * 16 + fg * 4;
+      if (n >= N) continue;
+      f32x4 v = acc[fn][fm];
+      if (partial) {
+        float* dst = wsz + m * N + n;
+        if (vec_ok && n + 3 < N) {
+          *reinterpret_cast<f32x4*>(dst) = v;
+        } else {
+          for (int e = 0; e < 4 && n + e < N; ++e) dst[e] = v[e];
+        }
+        continue;
+      }
+      if (vec_ok && n + 3 < N) {
+        if (R != nullptr && beta != 0.f) {
+          if constexpr (sizeof(T) == 2) {
+            bf16x4 rv = *reinterpret_cast<const bf16x4*>(R + m * ldr + n);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = alpha * v[e] + beta * (float)rv[e];
+          } else {
+            f32x4 rv = *reinterpret_cast<const f32x4*>(R + m * ldr + n);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = alpha * v[e] + beta * rv[e];
+          }
+        } else {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] = alpha * v[e];
+        }
+        if constexpr (sizeof(T) == 2) {
+          bf16x4 o;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) o[e] = (bf16)v[e];
+          *reinterpret_cast<bf16x4*>(C + m * ldc + n) = o;
+        } else {
+          *reinterpret_cast<f32x4*>(C + m * ldc + n) = v;
+        }
+      } else {
+        for (int e = 0; e < 4 && n + e < N; ++e) {
+          float x = alpha * v[e];
+          if (R != nullptr && beta != 0.f) x += beta * to_f(R[m * ldr + n + e]);
+          C[m * ldc + n + e] = from_f<T>(x);
+        }
+      }
+    }
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ ws, T* __restrict__ C,
+                                                            int64_t ldc, const T* __restrict__ R, int64_t ldr,
+                                                            int64_t M, int64_t N, int splitk, float alpha,
+                                                            float beta) {
+  const int64_t total = M * N;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    float s = 0.f;
+    for (int z = 0; z < splitk; ++z) s += ws[(int64_t)z * total + i];
+    const int64_t m = i / N, n = i - m * N;
+    float x = alpha * s;
+    if (R != nullptr && beta != 0.f) x += beta * to_f(R[m * ldr + n]);
+    C[m * ldc + n] = from_f<T>(x);
+  }
+}
+
+template <typename T>
+static int gemm_launch(const void* A, int64_t lda, const void* B, int64_t ldb, void* C, int64_t ldc, const void* R,
+                       int64_t ldr, int64_t M, int64_t N, int64_t K, float alpha, float beta, int splitk,
+                       void* workspace, hipStream_t st) {
+  constexpr int EPC = 16 / sizeof(T);
+  constexpr int BK = 128 / sizeof(T);
+  MH_REQUIRE(M > 0 && N > 0 && K > 0, "gemm: empty problem M=%ld N=%ld K=%ld", (long)M, (long)N, (long)K);
+  MH_REQUIRE(K % EPC == 0 && lda % EPC == 0 && ldb % EPC == 0, "gemm: K/lda/ldb must be multiples of %d elements (K=%ld lda=%ld ldb=%ld)",
+             EPC, (long)K, (long)lda, (long)ldb);
+  MH_REQUIRE(((uintptr_t)A & 15) == 0 && ((uintptr_t)B & 15) == 0, "gemm: A/B must be 16-byte aligned");
+  MH_REQUIRE(beta == 0.f || R != nullptr, "gemm: beta != 0 needs R");
+  const int64_t tiles_m = (M + BM - 1) / BM, tiles_n = (N + BN - 1) / BN;
+  MH_REQUIRE(tiles_m * tiles_n < (1ll << 30), "gemm: too many tiles");
+  if (splitk < 1) splitk = 1;
+  int64_t kps = ((K + splitk - 1) / splitk + BK - 1) / BK * BK;
+  splitk = (int)((K + kps - 1) / kps);
+  MH_REQUIRE(splitk == 1 || workspace != nullptr, "gemm: split-K needs a workspace");
+  const int nwg = (int)(tiles_m * tiles_n);
+  dim3 grid(nwg, 1, splitk);
+  gemm_nt_kernel<T><<<grid, 256, 0, st>>>((const T*)A, lda, (const T*)B, ldb, (T*)C, ldc, (const T*)R, ldr, M, N, K,
+                                            alpha, beta, (int)tiles_n, nwg, kps, (float*)workspace);
+  MH_LAUNCH_CHECK();
+  if (splitk > 1) {
+    int64_t total = M * N;
+    int blocks = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
+    splitk_reduce_kernel<T><<<blocks, 256, 0, st>>>((const float*)workspace, (T*)C, ldc, (const T*)R, ldr, M, N,
+                                                    splitk, alpha, beta);
+    MH_LAUNCH_CHECK();
+  }
+  return MH_OK;
+}
+
+extern "C" int mh_gemm_nt(const void* A, int64_t lda, const void* B, int64_t ldb, void* C, int64_t ldc,
+                          const void* R, int64_t ldr, int64_t M, int64_t N, int64_t K, float alpha, float beta,
+                          int dtype, int splitk, void* workspace, void* stream) {
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == MH_BF16)
+    return gemm_launch<bf16>(A, lda, B, ldb, C, ldc, R, ldr, M, N, K, alpha, beta, splitk, workspace, st);
+  if (dtype == MH_F32)
+    return gemm_launch<float>(A, lda, B, ldb, C, ldc, R, ldr, M, N, K, alpha, beta, splitk, workspace, st);
+  mh_set_error("gemm: bad dtype %d", dtype);
+  return MH_ERR_ARG;
+}
+
+// ---- transpose: out[c][r] = in[r][c]; 64x64 tiles through LDS, 16-byte global accesses both ways ----
+template <typename T>
+__global__ __launch_bounds__(256) void transpose_kernel(const T* __restrict__ in, int64_t ldi, T* __restrict__ out,
+                                                        int64_t ldo, int64_t rows, int64_t cols) {
+  constexpr int EPC = 16 / sizeof(T);   // elements per 16-byte chunk
+  constexpr int CPR = 64 / EPC;         // chunks per 64-element tile row
+  constexpr int RPP = 256 / CPR;        // tile rows covered per pass
+  constexpr int LD = 64 + 4 / sizeof(T);  // +1 dword of padding per row
+  __shared__ T tile[64][LD];
+  const int64_t r0 = (int64_t)blockIdx.y * 64, c0 = (int64_t)blockIdx.x * 64;
+  const int t = threadIdx.x;
+  const int ch = t % CPR, rr = t / CPR;
+  const bool in_vec = (ldi % EPC == 0) && (((uintptr_t)in & 15) == 0);
+  const bool out_vec = (ldo % EPC == 0) && (((uintptr_t)out & 15) == 0);
+  for (int p = 0; p < 64 / RPP; ++p) {
+    const int i = rr + p * RPP;
+    const int64_t r = r0 + i, c = c0 + ch * EPC;
+    if (in_vec && r < rows && c + EPC <= cols) {
+      Pack<T> v = ld16(in + r * ldi + c);
+#pragma unroll
+      for (int e = 0; e < EPC; ++e) tile[i][ch * EPC + e] = v.v[e];
+    } else {
+      for (int e = 0; e < EPC; ++e)
+        tile[i][ch * EPC + e] = (r < rows && c + e < cols) ? in[r * ldi + c + e] : from_f<T>(0.f);
+    }
+  }
+  __syncthreads();
+  for (int p = 0; p < 64 / RPP; ++p) {
+    const int i = rr + p * RPP;  // output row within tile = input column
+    const int64_t c = c0 + i, r = r0 + ch * EPC;
+    if (c >= cols) continue;
+    if (out_vec && r + EPC <= rows) {
+      Pack<T> v;
+#pragma unroll
+      for (int e = 0; e < EPC; ++e) v.v[e] = tile[ch * EPC + e][i];
+      st16(out + c * ldo + r, v);
+    } else {
+      for (int e = 0; e < EPC && r + e < rows; ++e) out[c * ldo + r + e] = tile[ch * EPC + e][i];
+    }
+  }
+}
+
+extern "C" int mh_transpose(const void* in, int64_t ldi, void* out, int64_t ldo, int64_t rows, int64_t cols,
+                            int dtype, void* stream) {
+  MH_REQUIRE(rows > 0 && cols > 0, "transpose: empty");
+  dim3 grid((unsigned)((cols + 63) / 64), (unsigned)((rows + 63) / 64));
+  MH_REQUIRE(grid.y < 65536, "transpose: too many row tiles (%u)", grid.y);
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == MH_BF16)
+    transpose_kernel<bf16><<<grid, 256, 0, st>>>((const bf16*)in, ldi, (bf16*)out, ldo, rows, cols);
+  else
+    transpose_kernel<float><<<grid, 256, 0, st>>>((const float*)in, ldi, (float*)out, ldo, rows, cols);
+  MH_LAUNCH_CHECK();
+  return MH_OK;
+}

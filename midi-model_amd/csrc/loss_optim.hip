@@ -1,0 +1,275 @@
+// Cross-entropy over the vocabulary, gradient-norm clip + AdamW, and the grammar-masked softmax of the
+// sampler.  All HBM-bound row / flat-buffer streamers; reductions are deterministic (no float atomics).
+#include "common.h"
+
+#define DISPATCH_T(dtype, CALL)                                    \
+  do {                                                             \
+    if ((dtype) == MH_BF16) { using T = bf16; CALL; }              \
+    else if ((dtype) == MH_F32) { using T = float; CALL; }         \
+    else { mh_set_error("bad dtype %d", (int)(dtype)); return MH_ERR_ARG; } \
+  } while (0)
+
+// ---------------------------------------------------------------------------------------------------
+// cross entropy: one wave per row.  pass 1: online (max, sum exp, argmax, target logit); pass 2: gradient.
+// ---------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void cross_entropy_kernel(const T* logits, int64_t ldl, const int64_t* __restrict__ target,
+                                                            float* __restrict__ row_loss, T* dlogits,
+                                                            const float* __restrict__ scale_dev,
+                                                            int64_t* __restrict__ argmax_out, int64_t R, int V,
+                                                            int64_t ignore) {
+  const int lane = threadIdx.x & 63;
+  const float scale = (dlogits != nullptr && scale_dev != nullptr) ? scale_dev[0] : 1.f;
+  for (int64_t r = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); r < R; r += (int64_t)gridDim.x * 4) {
+    const T* row = logits + r * ldl;
+    float mx = -INFINITY, sum = 0.f;
+    int amax = 0x7fffffff;
+    for (int c = lane; c < V; c += 64) {
+      const float v = to_f(row[c]);
+      if (v > mx) {
+        sum = sum * __expf(mx - v) + 1.f;
+        mx = v;
+        amax = c;
+      } else {
+        sum += __expf(v - mx);
+      }
+    }
+    // combine the 64 (max,sum,argmax) triples
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      const float omx = __shfl_xor(mx, o, 64), osum = __shfl_xor(sum, o, 64);
+      const int oam = __shfl_xor(amax, o, 64);
+      const float nm = fmaxf(mx, omx);
+      const float s1 = (mx == -INFINITY) ? 0.f : sum * __expf(mx - nm);
+      const float s2 = (omx == -INFINITY) ? 0.f : osum * __expf(omx - nm);
+      if (omx > mx || (omx == mx && oam < amax)) amax = oam;
+      mx = nm;
+      sum = s1 + s2;
+    }
+    const float lse = mx + __logf(sum);
+    const int64_t tgt = target[r];
+    const bool keep = (tgt != ignore);
+    if (lane == 0) {
+      row_loss[r] = keep ? (lse - to_f(row[tgt])) : 0.f;
+      if (argmax_out != nullptr) argmax_out[r] = amax;
+    }
+    if (dlogits != nullptr) {
+      T* drow = dlogits + r * ldl;
+      for (int c = lane; c < (int)ldl; c += 64) {
+        float g = 0.f;
+        if (keep && c < V) {
+          g = __expf(to_f(row[c]) - lse);
+          if (c == (int)tgt) g -= 1.f;
+          g *= scale;
+        }
+        drow[c] = from_f<T>(g);
+      }
+    }
+  }
+}
+
+extern "C" int mh_cross_entropy(const void* logits, int64_t ldl, const int64_t* target, float* row_loss, void* dlogits,
+                                const float* scale_dev, int64_t* argmax_out, int64_t R, int V, int64_t ignore,
+                                int dtype, void* stream) {
+  MH_REQUIRE(R > 0 && V > 0 && ldl >= V, "cross_entropy: bad shape R=%ld V=%d ldl=%ld", (long)R, V, (long)ldl);
+  int64_t g = (R + 3) / 4;
+  if (g > 65536) g = 65536;
+  DISPATCH_T(dtype, (cross_entropy_kernel<T><<<(int)g, 256, 0, (hipStream_t)stream>>>(
+                        (const T*)logits, ldl, target, row_loss, (T*)dlogits, scale_dev, argmax_out, R, V, ignore)));
+  MH_LAUNCH_CHECK();
+  return MH_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// deterministic single-block reductions (inputs are at most a few MB)
+// ---------------------------------------------------------------------------------------------------
+__device__ inline float block_sum_1024(float v, float* sh) {
+  v = wave_sum(v);
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  if (lane == 0) sh[wv] = v;
+  __syncthreads();
+  float t = (threadIdx.x < 16) ? sh[threadIdx.x] : 0.f;
+  if (wv == 0) t = wave_sum(t);
+  return t;  // valid in wave 0
+}
+
+__global__ __launch_bounds__(1024) void sum_f32_kernel(const float* __restrict__ x, int64_t n, float* __restrict__ out) {
+  __shared__ float sh[16];
+  float s = 0.f;
+  for (int64_t i = threadIdx.x; i < n; i += 1024) s += x[i];
+  s = block_sum_1024(s, sh);
+  if (threadIdx.x == 0) out[0] = s;
+}
+
+extern "C" int mh_sum_f32(const float* x, int64_t n, float* out, void* stream) {
+  MH_REQUIRE(n > 0, "sum_f32: empty");
+  sum_f32_kernel<<<1, 1024, 0, (hipStream_t)stream>>>(x, n, out);
+  MH_LAUNCH_CHECK();
+  return MH_OK;
+}
+
+__global__ __launch_bounds__(1024) void count_valid_kernel(const int64_t* __restrict__ t, int64_t n, int64_t ignore,
+                                                           float* __restrict__ count, float* __restrict__ inv) {
+  __shared__ float sh[16];
+  float s = 0.f;
+  for (int64_t i = threadIdx.x; i < n; i += 1024) s += (t[i] != ignore) ? 1.f : 0.f;
+  s = block_sum_1024(s, sh);
+  if (threadIdx.x == 0) {
+    count[0] = s;
+    inv[0] = 1.f / fmaxf(s, 1.f);
+  }
+}
+
+extern "C" int mh_count_valid(const int64_t* target, int64_t n, int64_t ignore, float* count, float* inv, void* stream) {
+  MH_REQUIRE(n > 0 && n < (1 << 24), "count_valid: n out of range (fp32 counter)");
+  count_valid_kernel<<<1, 1024, 0, (hipStream_t)stream>>>(target, n, ignore, count, inv);
+  MH_LAUNCH_CHECK();
+  return MH_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// sum of squares of a flat gradient buffer: 1024 block partials, then one block folds them
+// ---------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void sumsq_partial_kernel(const T* __restrict__ g, int64_t n, float* __restrict__ partial) {
+  constexpr int N = Pack<T>::N;
+  __shared__ float sh[4];
+  float s = 0.f;
+  const int64_t nvec = n / N;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < nvec; i += (int64_t)gridDim.x * 256) {
+    Pack<T> v = ld16(g + i * N);
+#pragma unroll
+    for (int e = 0; e < N; ++e) s += v.get(e) * v.get(e);
+  }
+  if (blockIdx.x == 0)
+    for (int64_t i = nvec * N + threadIdx.x; i < n; i += 256) s += to_f(g[i]) * to_f(g[i]);
+  s = wave_sum(s);
+  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) partial[blockIdx.x] = sh[0] + sh[1] + sh[2] + sh[3];
+}
+
+__global__ __launch_bounds__(1024) void fold_partials_kernel(const float* __restrict__ partial, int n, float* __restrict__ out,
+                                                             int accumulate) {
+  __shared__ float sh[16];
+  float s = (threadIdx.x < n) ? partial[threadIdx.x] : 0.f;
+  s = block_sum_1024(s, sh);
+  if (threadIdx.x == 0) out[0] = accumulate ? out[0] + s : s;
+}
+
+extern "C" int mh_sumsq(const void* g, int64_t n, float* partial1024, float* out, int accumulate, int dtype, void* stream) {
+  MH_REQUIRE(n > 0 && ((uintptr_t)g & 15) == 0, "sumsq: empty or unaligned");
+  DISPATCH_T(dtype, (sumsq_partial_kernel<T><<<1024, 256, 0, (hipStream_t)stream>>>((const T*)g, n, partial1024)));
+  MH_LAUNCH_CHECK();
+  fold_partials_kernel<<<1, 1024, 0, (hipStream_t)stream>>>(partial1024, 1024, out, accumulate);
+  MH_LAUNCH_CHECK();
+  return MH_OK;
+}
+
+__global__ void clip_coef_kernel(const float* __restrict__ sumsq, float max_norm, float* __restrict__ coef,
+                                 float* __restrict__ norm) {
+  const float nrm = sqrtf(sumsq[0]);
+  norm[0] = nrm;
+  coef[0] = fminf(1.f, max_norm / (nrm + 1e-6f));
+}
+
+extern "C" int mh_clip_coef(const float* sumsq, float max_norm, float* coef, float* norm, void* stream) {
+  clip_coef_kernel<<<1, 1, 0, (hipStream_t)stream>>>(sumsq, max_norm, coef, norm);
+  MH_LAUNCH_CHECK();
+  return MH_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// AdamW (torch.optim.AdamW single-tensor semantics; gradient pre-scaled by the clip coefficient)
+// ---------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void adamw_kernel(T* __restrict__ p, const T* __restrict__ g, T* __restrict__ m,
+                                                    T* __restrict__ v, int64_t n, float lr, float b1, float b2, float eps,
+                                                    float wd, float bc1, float bc2, const float* __restrict__ coef_dev) {
+  constexpr int N = Pack<T>::N;
+  const float coef = coef_dev ? coef_dev[0] : 1.f;
+  const float step = lr / bc1, sq2 = sqrtf(bc2), decay = 1.f - lr * wd;
+  const int64_t nvec = n / N;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < nvec; i += (int64_t)gridDim.x * 256) {
+    Pack<T> pv = ld16(p + i * N), gv = ld16(g + i * N), mv = ld16(m + i * N), vv = ld16(v + i * N);
+#pragma unroll
+    for (int e = 0; e < N; ++e) {
+      const float gr = rnd<T>(gv.get(e) * coef);
+      float pe = rnd<T>(pv.get(e) * decay);
+      const float me = rnd<T>(mv.get(e) + (gr - mv.get(e)) * (1.f - b1));
+      const float ve = rnd<T>(rnd<T>(vv.get(e) * b2) + (1.f - b2) * gr * gr);
+      const float den = rnd<T>(rnd<T>(sqrtf(ve)) / sq2) + eps;
+      pe = pe - step * (me / rnd<T>(den));
+      pv.set(e, pe);
+      mv.set(e, me);
+      vv.set(e, ve);
+    }
+    st16(p + i * N, pv);
+    st16(m + i * N, mv);
+    st16(v + i * N, vv);
+  }
+  if (blockIdx.x == 0) {
+    for (int64_t i = nvec * N + threadIdx.x; i < n; i += 256) {
+      const float gr = rnd<T>(to_f(g[i]) * coef);
+      float pe = rnd<T>(to_f(p[i]) * decay);
+      const float me = rnd<T>(to_f(m[i]) + (gr - to_f(m[i])) * (1.f - b1));
+      const float ve = rnd<T>(rnd<T>(to_f(v[i]) * b2) + (1.f - b2) * gr * gr);
+      const float den = rnd<T>(rnd<T>(sqrtf(ve)) / sq2) + eps;
+      pe = pe - step * (me / rnd<T>(den));
+      p[i] = from_f<T>(pe);
+      m[i] = from_f<T>(me);
+      v[i] = from_f<T>(ve);
+    }
+  }
+}
+
+extern "C" int mh_adamw(void* p, const void* g, void* m, void* v, int64_t n, float lr, float beta1, float beta2, float eps,
+                        float weight_decay, float bias_corr1, float bias_corr2, const float* coef_dev, int dtype,
+                        void* stream) {
+  MH_REQUIRE(n > 0, "adamw: empty");
+  MH_REQUIRE((((uintptr_t)p | (uintptr_t)g | (uintptr_t)m | (uintptr_t)v) & 15) == 0, "adamw: buffers must be 16-byte aligned");
+  int64_t blocks = (n / 4 + 255) / 256;
+  if (blocks > 8192) blocks = 8192;
+  if (blocks < 1) blocks = 1;
+  DISPATCH_T(dtype, (adamw_kernel<T><<<(int)blocks, 256, 0, (hipStream_t)stream>>>(
+                        (T*)p, (const T*)g, (T*)m, (T*)v, n, lr, beta1, beta2, eps, weight_decay, bias_corr1, bias_corr2,
+                        coef_dev)));
+  MH_LAUNCH_CHECK();
+  return MH_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// sampler front end: probs = softmax(logits / temp) * grammar mask (one wave per row)
+// ---------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void masked_softmax_kernel(const T* __restrict__ logits, int64_t ldl,
+                                                             const int32_t* __restrict__ lo, const int32_t* __restrict__ hi,
+                                                             const uint8_t* __restrict__ first_mask,
+                                                             float* __restrict__ probs, int64_t B, int V, float inv_temp) {
+  const int lane = threadIdx.x & 63;
+  for (int64_t b = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); b < B; b += (int64_t)gridDim.x * 4) {
+    const T* row = logits + b * ldl;
+    float mx = -INFINITY;
+    for (int c = lane; c < V; c += 64) mx = fmaxf(mx, rnd<T>(to_f(row[c]) * inv_temp));
+    mx = wave_max(mx);
+    float sum = 0.f;
+    for (int c = lane; c < V; c += 64) sum += __expf(rnd<T>(to_f(row[c]) * inv_temp) - mx);
+    sum = wave_sum(sum);
+    const float inv = 1.f / sum;
+    const int l = lo[b], h = hi[b];
+    for (int c = lane; c < V; c += 64) {
+      const bool ok = (l < 0) ? (first_mask[c] != 0) : (c >= l && c < h);
+      probs[b * V + c] = ok ? __expf(rnd<T>(to_f(row[c]) * inv_temp) - mx) * inv : 0.f;
+    }
+  }
+}
+
+extern "C" int mh_masked_softmax(const void* logits, int64_t ldl, const int32_t* lo, const int32_t* hi,
+                                 const uint8_t* first_mask, float* probs, int64_t B, int V, float temp, int dtype,
+                                 void* stream) {
+  MH_REQUIRE(B > 0 && V > 0 && temp > 0.f, "masked_softmax: bad args");
+  DISPATCH_T(dtype, (masked_softmax_kernel<T><<<(int)((B + 3) / 4), 256, 0, (hipStream_t)stream>>>(
+                        (const T*)logits, ldl, lo, hi, first_mask, probs, B, V, 1.f / temp)));
+  MH_LAUNCH_CHECK();
+  return MH_OK;
+}

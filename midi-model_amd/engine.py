@@ -1,0 +1,264 @@
+"""Forward / backward / decode schedules of one LLaMA stack (event-level `net` or token-level `net_token`)
+as explicit sequences of C-ABI kernel launches — no autograd graph, no tracing compiler.
+
+Block wiring follows TF:models/llama/modeling_llama.py:295-324 (pre-norm residual layer) and :367-417
+(model: layers + final norm); see SURVEY.md §8 a5-a9.  Weights of a layer are views into the model's flat
+parameter buffer, with q|k|v and gate|up stored contiguously so each pair is ONE projection GEMM.
+"""
+from __future__ import annotations
+
+import math
+from dataclasses import dataclass, field
+from typing import Callable, List, Optional
+
+import torch
+
+from . import ops
+
+
+@dataclass
+class StackSpec:
+    name: str            # "net" | "net_token"
+    D: int
+    H: int
+    I: int
+    L: int
+    eps: float
+    theta: float
+    kind: str            # "event" (causal flash attention, head_dim 64) | "token" (<=8-token sequences, head_dim 256)
+
+    @property
+    def hd(self) -> int:
+        return self.D // self.H
+
+    @property
+    def scale(self) -> float:
+        return self.hd ** -0.5
+
+
+@dataclass
+class LayerTensors:
+    wqkv: torch.Tensor = None   # [3D, D]
+    wo: torch.Tensor = None     # [D, D]
+    wgu: torch.Tensor = None    # [2I, D]
+    wd: torch.Tensor = None     # [D, I]
+    n1: torch.Tensor = None     # [D]
+    n2: torch.Tensor = None     # [D]
+
+
+@dataclass
+class StackTensors:
+    """One of: weights, transposed weights ([in,out] copies for dgrad), gradients."""
+    embed: torch.Tensor = None  # [V, D]
+    layers: List[LayerTensors] = field(default_factory=list)
+    norm: torch.Tensor = None   # [D]
+
+
+class RopeTable:
+    """fp32 cos/sin of pos * theta^(-2i/hd), [npos, hd/2] (TF:models/llama/modeling_llama.py:113-127)."""
+
+    def __init__(self, hd: int, theta: float, device, npos: int = 0):
+        self.hd, self.theta, self.device = hd, theta, device
+        self.cos = self.sin = None
+        self.n = 0
+        if npos:
+            self.ensure(npos)
+
+    def ensure(self, npos: int):
+        if npos <= self.n:
+            return
+        npos = max(npos, 2 * self.n, 64)
+        inv_freq = 1.0 / (self.theta ** (torch.arange(0, self.hd, 2, dtype=torch.int64).float() / self.hd))
+        ang = torch.arange(npos).float()[:, None] * inv_freq[None, :]
+        self.cos = ang.cos().contiguous().to(self.device)
+        self.sin = ang.sin().contiguous().to(self.device)
+        self.n = npos
+
+
+def _empty(shape, like: torch.Tensor, dtype=None):
+    return torch.empty(shape, dtype=dtype or like.dtype, device=like.device)
+
+
+def _check_heads(spec: StackSpec):
+    want = 64 if spec.kind == "event" else 256
+    if spec.hd != want:
+        raise NotImplementedError(
+            f"{spec.name}: head_dim {spec.hd} is not implemented by the HIP attention kernels "
+            f"(event-level net needs 64, token-level net needs 256)")
+
+
+def linear_wgrad(dy: torch.Tensor, x: torch.Tensor, dw: torch.Tensor, accumulate: bool):
+    """dw[N,K] (+)= dy[M,N]^T @ x[M,K]: the contraction runs over the M rows, so both operands are re-laid
+    out contraction-major first (mh_transpose), then the same NT kernel runs with split-K."""
+    M = dy.shape[0]
+    dyT = ops.transpose(dy)            # [N, Mp]
+    xT = ops.transpose(x)              # [K, Mp]
+    ops.gemm_nt(dyT, xT, dw, K=dyT.shape[1], beta=1.0 if accumulate else 0.0)
+
+
+# --------------------------------------------------------------------------------------------------
+# training / prefill forward
+# --------------------------------------------------------------------------------------------------
+def stack_forward(spec: StackSpec, W: StackTensors, x: torch.Tensor, nseq: int, slen: int, rope: RopeTable,
+                  save: bool, kv_out: Optional[list] = None):
+    """x [nseq*slen, D] (inputs_embeds) -> last_hidden_state [nseq*slen, D].
+    save=True keeps what the backward needs; kv_out (prefill) receives each layer's post-RoPE qkv."""
+    _check_heads(spec)
+    M, D = x.shape
+    assert M == nseq * slen
+    H, I = spec.H, spec.I
+    rope.ensure(slen)
+    saved = []
+    for lw in W.layers:
+        h1 = _empty((M, D), x)
+        rstd1 = _empty((M,), x, torch.float32)
+        ops.rmsnorm_fwd(x, lw.n1, h1, rstd1, spec.eps)
+        qkv = _empty((M, 3 * D), x)
+        ops.gemm_nt(h1, lw.wqkv, qkv)
+        ops.rope_(qkv, rope.cos, rope.sin, slen, 0, H, spec.hd, +1)
+        o = _empty((M, D), x)
+        lse = None
+        if spec.kind == "event":
+            lse = _empty((nseq * H * ops.round_up(slen, 64),), x, torch.float32)
+            ops.attn_fwd(qkv, o, lse, nseq, slen, H, spec.scale)
+        else:
+            ops.tokattn_fwd(qkv, o, nseq, slen, H, spec.scale)
+        if kv_out is not None:
+            kv_out.append(qkv)
+        x2 = _empty((M, D), x)
+        ops.gemm_nt(o, lw.wo, x2, beta=1.0, res=x)
+        h2 = _empty((M, D), x)
+        rstd2 = _empty((M,), x, torch.float32)
+        ops.rmsnorm_fwd(x2, lw.n2, h2, rstd2, spec.eps)
+        gu = _empty((M, 2 * I), x)
+        ops.gemm_nt(h2, lw.wgu, gu)
+        a = _empty((M, I), x)
+        ops.swiglu_fwd(gu, a)
+        x3 = _empty((M, D), x)
+        ops.gemm_nt(a, lw.wd, x3, beta=1.0, res=x2)
+        if save:
+            saved.append((x, rstd1, h1, qkv, o, lse, x2, rstd2, h2, gu, a))
+        x = x3
+    y = _empty((M, D), x)
+    rstdf = _empty((M,), x, torch.float32)
+    ops.rmsnorm_fwd(x, W.norm, y, rstdf, spec.eps)
+    return y, ((saved, x, rstdf, nseq, slen) if save else None)
+
+
+def stack_backward(spec: StackSpec, W: StackTensors, WT: StackTensors, G: StackTensors, ctx, dy: torch.Tensor,
+                   rope: RopeTable, accumulate: bool, on_layer_done: Optional[Callable[[int], None]] = None):
+    """dy = d loss / d last_hidden_state  ->  d loss / d inputs_embeds; parameter gradients go to G
+    (overwritten, or added to when `accumulate`).  `on_layer_done(i)` fires when layer i's gradients are
+    final (layers finish in reverse order) — the data-parallel reducer hangs its bucket launches on it."""
+    saved, x_last, rstdf, nseq, slen = ctx
+    M, D = dy.shape
+    H, I = spec.H, spec.I
+    dx = _empty((M, D), dy)
+    ops.rmsnorm_bwd(x_last, W.norm, rstdf, dy, None, dx, G.norm, accumulate)
+    for li in range(len(W.layers) - 1, -1, -1):
+        lw, lt, lg = W.layers[li], WT.layers[li], G.layers[li]
+        x, rstd1, h1, qkv, o, lse, x2, rstd2, h2, gu, a = saved[li]
+        # ---- MLP ----
+        da = _empty((M, I), dy)
+        ops.gemm_nt(dx, lt.wd, da)                      # lt.wd = wd^T [I, D]
+        linear_wgrad(dx, a, lg.wd, accumulate)
+        dgu = _empty((M, 2 * I), dy)
+        ops.swiglu_bwd(gu, da, dgu)
+        del da
+        dh2 = _empty((M, D), dy)
+        ops.gemm_nt(dgu, lt.wgu, dh2)                   # lt.wgu = wgu^T [D, 2I]
+        linear_wgrad(dgu, h2, lg.wgu, accumulate)
+        del dgu
+        dx2 = _empty((M, D), dy)
+        ops.rmsnorm_bwd(x2, lw.n2, rstd2, dh2, dx, dx2, lg.n2, accumulate)
+        # ---- attention ----
+        do = dh2                                        # reuse
+        ops.gemm_nt(dx2, lt.wo, do)                     # lt.wo = wo^T [D, D]
+        linear_wgrad(dx2, o, lg.wo, accumulate)
+        dqkv = _empty((M, 3 * D), dy)
+        if spec.kind == "event":
+            ops.attn_bwd(qkv, o, do, lse, dqkv, nseq, slen, H, spec.scale)
+        else:
+            ops.tokattn_bwd(qkv, do, dqkv, nseq, slen, H, spec.scale)
+        ops.rope_(dqkv, rope.cos, rope.sin, slen, 0, H, spec.hd, -1)
+        dh1 = do
+        ops.gemm_nt(dqkv, lt.wqkv, dh1)                 # lt.wqkv = wqkv^T [D, 3D]
+        linear_wgrad(dqkv, h1, lg.wqkv, accumulate)
+        del dqkv
+        ops.rmsnorm_bwd(x, lw.n1, rstd1, dh1, dx2, dx, lg.n1, accumulate)
+        saved[li] = None
+        if on_layer_done is not None:
+            on_layer_done(li)
+    return dx
+
+
+# --------------------------------------------------------------------------------------------------
+# KV-cached decode (one new position per sequence)
+# --------------------------------------------------------------------------------------------------
+class KVState:
+    """Preallocated per-layer K/V buffers [B,H,Lmax,hd] replacing DynamicCache's torch.cat growth
+    (TF:cache_utils.py:127-147).  Attached to whatever cache object the caller passes (app.py hands us
+    HF DynamicCache instances it created itself, app.py:56,64)."""
+
+    def __init__(self, spec: StackSpec, B: int, capacity: int, like: torch.Tensor):
+        self.spec, self.B, self.cap, self.len = spec, B, capacity, 0
+        shape = (spec.L, B, spec.H, capacity, spec.hd)
+        self.k = torch.empty(shape, dtype=like.dtype, device=like.device)
+        self.v = torch.empty(shape, dtype=like.dtype, device=like.device)
+
+    def reserve(self, need: int):
+        if need <= self.cap:
+            return
+        cap = max(need, 2 * self.cap)
+        for nm in ("k", "v"):
+            old = getattr(self, nm)
+            new = torch.empty((self.spec.L, self.B, self.spec.H, cap, self.spec.hd), dtype=old.dtype, device=old.device)
+            new[:, :, :, : self.len].copy_(old[:, :, :, : self.len])
+            setattr(self, nm, new)
+        self.cap = cap
+
+
+def stack_prefill(spec: StackSpec, W: StackTensors, x: torch.Tensor, nseq: int, slen: int, rope: RopeTable, kv: KVState):
+    """Causal forward over a whole prompt from an EMPTY cache, storing K/V rows [0, slen)."""
+    assert kv.len == 0
+    kv.reserve(slen)
+    qkvs: list = []
+    y, _ = stack_forward(spec, W, x, nseq, slen, rope, save=False, kv_out=qkvs)
+    for li, qkv in enumerate(qkvs):
+        ops.kv_store_prefill(qkv, kv.k[li], kv.v[li], nseq, slen, spec.H, spec.hd, kv.cap)
+    kv.len = slen
+    return y
+
+
+def stack_decode(spec: StackSpec, W: StackTensors, x: torch.Tensor, rope: RopeTable, kv: KVState):
+    """x [B, D]: one new position per sequence at index kv.len (q_len == 1 => no causal mask,
+    TF:integrations/sdpa_attention.py:120)."""
+    _check_heads(spec)
+    B, D = x.shape
+    H, I, hd = spec.H, spec.I, spec.hd
+    pos = kv.len
+    kv.reserve(pos + 1)
+    rope.ensure(pos + 1)
+    for li, lw in enumerate(W.layers):
+        h1 = _empty((B, D), x)
+        ops.rmsnorm_fwd(x, lw.n1, h1, None, spec.eps)
+        qkv = _empty((B, 3 * D), x)
+        ops.gemm_nt(h1, lw.wqkv, qkv)
+        ops.kv_append(qkv, rope.cos, rope.sin, kv.k[li], kv.v[li], B, H, hd, kv.cap, pos)
+        o = h1
+        ops.attn_decode(qkv, kv.k[li], kv.v[li], o, B, H, hd, kv.cap, pos + 1, spec.scale)
+        x2 = _empty((B, D), x)
+        ops.gemm_nt(o, lw.wo, x2, beta=1.0, res=x)
+        h2 = o
+        ops.rmsnorm_fwd(x2, lw.n2, h2, None, spec.eps)
+        gu = _empty((B, 2 * I), x)
+        ops.gemm_nt(h2, lw.wgu, gu)
+        a = _empty((B, I), x)
+        ops.swiglu_fwd(gu, a)
+        x3 = _empty((B, D), x)
+        ops.gemm_nt(a, lw.wd, x3, beta=1.0, res=x2)
+        x = x3
+    y = _empty((B, D), x)
+    ops.rmsnorm_fwd(x, W.norm, y, None, spec.eps)
+    kv.len = pos + 1
+    return y

@@ -1,0 +1,81 @@
+"""ctypes binding of libmidihip.so.  The prototypes are read from include/midihip.h (the single source
+of truth for the C-ABI), so a symbol the header declares but the library lacks is an import-time error.
+
+There is NO fallback: if the shared object is missing or a call fails, a RuntimeError is raised.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+import re
+from typing import Dict, List, Tuple
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+HEADER = os.path.join(os.path.dirname(HERE), "include", "midihip.h")
+LIB_PATH = os.path.join(HERE, "libmidihip.so")
+
+MH_F32, MH_BF16 = 0, 1
+
+_CTYPES = {"int": ctypes.c_int, "int64_t": ctypes.c_int64, "float": ctypes.c_float}
+
+
+def parse_header(path: str = HEADER) -> Dict[str, Tuple[str, List[Tuple[str, str]]]]:
+    """-> {name: (return_type, [(ctype, argname), ...])} for every prototype in the header."""
+    src = open(path).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    src = re.sub(r"//[^\n]*", "", src)
+    protos = {}
+    for m in re.finditer(r"(const\s+char\s*\*|int)\s+(mh_\w+)\s*\(([^)]*)\)\s*;", src):
+        ret, name, args = m.group(1), m.group(2), m.group(3).strip()
+        parsed = []
+        if args and args != "void":
+            for a in args.split(","):
+                a = " ".join(a.split())
+                mm = re.match(r"(.*?)(\w+)$", a)
+                parsed.append((mm.group(1).strip(), mm.group(2)))
+        protos[name] = ("str" if "char" in ret else "int", parsed)
+    return protos
+
+
+def _to_ctype(t: str):
+    if "*" in t:
+        return ctypes.c_void_p
+    t = t.replace("const", "").strip()
+    return _CTYPES[t]
+
+
+class _Lib:
+    def __init__(self) -> None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                f"{LIB_PATH} is missing: the HIP kernels are the only implementation of this path. "
+                "Build them with `python -c 'import __graft_entry__ as g; g.build()'` (needs hipcc).")
+        self.cdll = ctypes.CDLL(LIB_PATH)
+        self.protos = parse_header()
+        for name, (ret, args) in self.protos.items():
+            try:
+                fn = getattr(self.cdll, name)
+            except AttributeError as e:
+                raise RuntimeError(f"libmidihip.so does not export {name} declared in include/midihip.h") from e
+            fn.argtypes = [_to_ctype(t) for t, _ in args]
+            fn.restype = ctypes.c_char_p if ret == "str" else ctypes.c_int
+
+    def call(self, name: str, *args) -> None:
+        rc = getattr(self.cdll, name)(*args)
+        if rc != 0:
+            msg = self.cdll.mh_last_error()
+            raise RuntimeError(f"{name} failed ({rc}): {msg.decode() if msg else '?'}")
+
+
+_lib = None
+
+
+def lib() -> _Lib:
+    global _lib
+    if _lib is None:
+        _lib = _Lib()
+    return _lib
+
+
+def available() -> bool:
+    return os.path.exists(LIB_PATH)

@@ -1,0 +1,478 @@
+"""``MIDIModel`` with the reference's surface (midi_model.py:99-250) on the HIP kernels.
+
+Same constructor, attributes (``tokenizer, net, net_token, lm_head, config, device, dtype``), the same
+140 parameter names/shapes (so ``state_dict`` / ``load_state_dict`` / ``.to()`` interoperate with
+reference checkpoints), and the same methods: ``forward``, ``forward_token``, ``sample_top_p_k``,
+``generate``.  Underneath, all parameters live in ONE flat buffer (q|k|v and gate|up adjacent, so each pair
+is one projection; gradients mirror the layout so the data-parallel reducer and the fused AdamW work on
+contiguous ranges), and every tensor op is a launch from ``engine.py`` / ``ops.py``.
+
+There is no CPU implementation: calling the compute methods without a ROCm device raises.
+"""
+from __future__ import annotations
+
+import json
+import math
+import os
+from typing import List, Optional, Tuple
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from . import engine, ops
+from .config import MIDIModelConfig, NetConfig
+from .engine import KVState, LayerTensors, RopeTable, StackSpec, StackTensors
+
+
+class _W(nn.Module):
+    """A module that owns one ``weight`` (stands in for nn.Linear / nn.Embedding / RMSNorm in the key tree)."""
+
+    def __init__(self, *shape: int):
+        super().__init__()
+        self.weight = nn.Parameter(torch.empty(*shape))
+
+
+class _Attn(nn.Module):
+    def __init__(self, D: int):
+        super().__init__()
+        self.q_proj, self.k_proj, self.v_proj, self.o_proj = _W(D, D), _W(D, D), _W(D, D), _W(D, D)
+
+
+class _MLP(nn.Module):
+    def __init__(self, D: int, I: int):
+        super().__init__()
+        self.gate_proj, self.up_proj, self.down_proj = _W(I, D), _W(I, D), _W(D, I)
+
+
+class _Layer(nn.Module):
+    def __init__(self, D: int, I: int):
+        super().__init__()
+        self.self_attn = _Attn(D)
+        self.mlp = _MLP(D, I)
+        self.input_layernorm = _W(D)
+        self.post_attention_layernorm = _W(D)
+
+
+class _Stack(nn.Module):
+    def __init__(self, cfg: NetConfig):
+        super().__init__()
+        self.config = cfg
+        D, I = cfg.hidden_size, cfg.intermediate_size
+        self.embed_tokens = _W(cfg.vocab_size, D)
+        self.layers = nn.ModuleList([_Layer(D, I) for _ in range(cfg.num_hidden_layers)])
+        self.norm = _W(D)
+
+
+_MATS = ("self_attn.q_proj", "self_attn.k_proj", "self_attn.v_proj", "self_attn.o_proj",
+         "mlp.gate_proj", "mlp.up_proj", "mlp.down_proj")
+
+
+class MIDIModel(nn.Module):
+    config_class = MIDIModelConfig
+
+    def __init__(self, config: MIDIModelConfig, *args, **kwargs):
+        super().__init__()
+        self.config = config
+        self.tokenizer = config.tokenizer
+        self.net = _Stack(config.net_config)
+        self.net_token = _Stack(config.net_token_config)
+        self.lm_head = _W(self.tokenizer.vocab_size, config.n_embd)
+        self._specs = {
+            "net": self._spec("net", config.net_config, "event"),
+            "net_token": self._spec("net_token", config.net_token_config, "token"),
+        }
+        self._flat = None
+        self._flat_grad = None
+        self._wt = None
+        self._wt_version = -1
+        self._ropes = {}
+        self._tables = None
+        self._reset_parameters()
+        self._repack()
+
+    # ------------------------------------------------------------------------------------------ set-up
+    @staticmethod
+    def _spec(name: str, c: NetConfig, kind: str) -> StackSpec:
+        return StackSpec(name, c.hidden_size, c.num_attention_heads, c.intermediate_size, c.num_hidden_layers,
+                         float(c.rms_norm_eps), float(c.rope_theta), kind)
+
+    def _reset_parameters(self):
+        """HF LLaMA init for the two stacks (N(0, 0.02), pad row zero, norms one; modeling_llama post_init) and
+        torch's default nn.Linear init for lm_head (the reference never calls post_init on MIDIModel itself)."""
+        with torch.no_grad():
+            for st in (self.net, self.net_token):
+                for n, p in st.named_parameters():
+                    if p.dim() == 1:
+                        p.fill_(1.0)
+                    else:
+                        p.normal_(0.0, 0.02)
+                pad = st.config.pad_token_id
+                if pad is not None:
+                    st.embed_tokens.weight[pad].zero_()
+            bound = 1.0 / math.sqrt(self.lm_head.weight.shape[1])
+            self.lm_head.weight.uniform_(-bound, bound)
+
+    def _layout(self) -> List[Tuple[str, nn.Parameter, str]]:
+        """Flat order: all matrices in forward order, then all norm vectors (the no-weight-decay group)."""
+        named = dict(self.named_parameters())
+        mats, norms = [], []
+        for pre, st in (("net", self.net), ("net_token", self.net_token)):
+            mats.append(f"{pre}.embed_tokens.weight")
+            for i in range(len(st.layers)):
+                mats += [f"{pre}.layers.{i}.{m}.weight" for m in _MATS]
+                norms += [f"{pre}.layers.{i}.input_layernorm.weight", f"{pre}.layers.{i}.post_attention_layernorm.weight"]
+            norms.append(f"{pre}.norm.weight")
+        mats.append("lm_head.weight")
+        assert len(mats) + len(norms) == len(named)
+        return [(n, named[n], "mat") for n in mats] + [(n, named[n], "norm") for n in norms]
+
+    def _repack(self):
+        """(Re)build the flat parameter buffer on the parameters' current device/dtype and re-point every
+        Parameter at its slice.  Runs after construction and after every ``.to()/.cuda()/.bfloat16()``."""
+        layout = self._layout()
+        p0 = layout[0][1]
+        total = sum(p.numel() for _, p, _ in layout)
+        flat = torch.empty(total, dtype=p0.dtype, device=p0.device)
+        off = 0
+        self._offsets = {}
+        with torch.no_grad():
+            for name, p, grp in layout:
+                n = p.numel()
+                assert off % 8 == 0, "every tensor must start 16-byte aligned"
+                flat[off:off + n].copy_(p.detach().reshape(-1).to(flat.dtype))
+                p.data = flat[off:off + n].view(p.shape)
+                p.grad = None
+                self._offsets[name] = (off, n, grp)
+                off += n
+        self._flat = flat
+        self._n_mat = sum(n for (_, n, g) in self._offsets.values() if g == "mat")
+        self._flat_grad = None
+        self._wt = None
+        self._wt_version = -1
+        self._ropes = {}
+        self._tables = None
+        self._W = {k: self._stack_views(k, flat) for k in ("net", "net_token")}
+
+    def _apply(self, fn, recurse=True):
+        out = super()._apply(fn, recurse)
+        if getattr(self, "_flat", None) is not None or hasattr(self, "_offsets"):
+            self._repack()
+        return out
+
+    def _stack_views(self, pre: str, flat: torch.Tensor) -> StackTensors:
+        spec = self._specs[pre]
+        D, I = spec.D, spec.I
+
+        def view(name, rows, cols=None):
+            off, _, _ = self._offsets[name]
+            n = rows * (cols or 1)
+            t = flat[off:off + n]
+            return t.view(rows, cols) if cols else t
+
+        V = self.tokenizer.vocab_size
+        st = StackTensors(embed=view(f"{pre}.embed_tokens.weight", V, D), norm=view(f"{pre}.norm.weight", D))
+        for i in range(spec.L):
+            b = f"{pre}.layers.{i}."
+            st.layers.append(LayerTensors(
+                wqkv=view(b + "self_attn.q_proj.weight", 3 * D, D), wo=view(b + "self_attn.o_proj.weight", D, D),
+                wgu=view(b + "mlp.gate_proj.weight", 2 * I, D), wd=view(b + "mlp.down_proj.weight", D, I),
+                n1=view(b + "input_layernorm.weight", D), n2=view(b + "post_attention_layernorm.weight", D)))
+        return st
+
+    # ------------------------------------------------------------------------------------- properties
+    @property
+    def device(self) -> torch.device:
+        return self._flat.device
+
+    @property
+    def dtype(self) -> torch.dtype:
+        return self._flat.dtype
+
+    @property
+    def vocab_padded(self) -> int:
+        return ops.round_up(self.tokenizer.vocab_size, 64)
+
+    def _require_gpu(self):
+        if self._flat.device.type != "cuda":
+            raise RuntimeError("MIDIModel compute needs a ROCm device: move the model with .to('cuda'). "
+                               "This implementation has no CPU path (the reference's CPU path is the oracle's job).")
+        if self._flat.dtype not in (torch.float32, torch.bfloat16):
+            raise RuntimeError(f"unsupported parameter dtype {self._flat.dtype} (float32 or bfloat16)")
+
+    def rope(self, pre: str) -> RopeTable:
+        if pre not in self._ropes:
+            spec = self._specs[pre]
+            self._ropes[pre] = RopeTable(spec.hd, spec.theta, self.device)
+        return self._ropes[pre]
+
+    # ---------------------------------------------------------------- gradients + transposed weights
+    def grad_buffer(self) -> torch.Tensor:
+        """Flat gradient buffer mirroring the parameter layout; every p.grad is a view of it."""
+        if self._flat_grad is None:
+            self._flat_grad = torch.zeros_like(self._flat)
+            for name, p in self.named_parameters():
+                off, n, _ = self._offsets[name]
+                p.grad = self._flat_grad[off:off + n].view(p.shape)
+            self._G = {k: self._stack_views(k, self._flat_grad) for k in ("net", "net_token")}
+            off, n, _ = self._offsets["lm_head.weight"]
+            self._g_lm = self._flat_grad[off:off + n].view(self.lm_head.weight.shape)
+        return self._flat_grad
+
+    def _version(self) -> int:
+        return sum(p._version for p in self.parameters())
+
+    def transposed(self):
+        """[in, out] copies of every projection matrix (the dgrad operands), refreshed when parameters changed."""
+        ver = self._version()
+        if self._wt is not None and self._wt_version == ver:
+            return self._wt
+        if self._wt is None:
+            buf = torch.empty(self._n_mat, dtype=self.dtype, device=self.device)
+            views = {k: self._stack_views_T(k, buf) for k in ("net", "net_token")}
+            lmT = torch.zeros((self.config.n_embd, self.vocab_padded), dtype=self.dtype, device=self.device)
+            self._wt = (views, lmT)
+        views, lmT = self._wt
+        for k in ("net", "net_token"):
+            for lw, lt in zip(self._W[k].layers, views[k].layers):
+                ops.transpose(lw.wqkv, lt.wqkv)
+                ops.transpose(lw.wo, lt.wo)
+                ops.transpose(lw.wgu, lt.wgu)
+                ops.transpose(lw.wd, lt.wd)
+        ops.transpose(self.lm_head.weight.data, lmT)
+        self._wt_version = ver
+        return self._wt
+
+    def _stack_views_T(self, pre: str, buf: torch.Tensor) -> StackTensors:
+        spec = self._specs[pre]
+        D, I = spec.D, spec.I
+
+        def view(name, rows, cols):
+            off, _, _ = self._offsets[name]
+            return buf[off:off + rows * cols].view(rows, cols)
+
+        st = StackTensors()
+        for i in range(spec.L):
+            b = f"{pre}.layers.{i}."
+            st.layers.append(LayerTensors(
+                wqkv=view(b + "self_attn.q_proj.weight", D, 3 * D), wo=view(b + "self_attn.o_proj.weight", D, D),
+                wgu=view(b + "mlp.gate_proj.weight", D, 2 * I), wd=view(b + "mlp.down_proj.weight", I, D)))
+        return st
+
+    # ------------------------------------------------------------------------------ reference methods
+    def load_merge_lora(self, model_id):
+        raise NotImplementedError("LoRA merge (midi_model.py:109-114) needs `peft`; out of scope of the HIP path")
+
+    def forward(self, x: torch.Tensor, cache=None) -> torch.Tensor:
+        """x (B, S, 8) int64 -> hidden (B, S, n_embd)   [midi_model.py:137-150]
+
+        Without ``cache`` the call is differentiable (an autograd node that runs the explicit backward
+        schedule).  With ``cache`` (any object; HF DynamicCache instances are accepted) K/V go to
+        preallocated buffers attached to it: an empty cache is prefilled causally, afterwards one event per
+        call is decoded."""
+        self._require_gpu()
+        if x.dim() != 3:
+            raise ValueError(f"expected (batch, events, tokens) ids, got shape {tuple(x.shape)}")
+        B, S, T = x.shape
+        x = x.to(device=self.device, dtype=torch.long).contiguous()
+        if cache is None:
+            from .autograd import NetFn
+            params = self._stack_params("net")
+            return NetFn.apply(self, x, *params)
+        spec = self._specs["net"]
+        st = getattr(cache, "_mh_state", None)
+        with torch.no_grad():
+            e = torch.empty((B * S, spec.D), dtype=self.dtype, device=self.device)
+            ops.embed_sum_fwd(x.view(B * S, T), self._W["net"].embed, e)
+            if st is None or st.len == 0:
+                if st is None:
+                    st = KVState(spec, B, max(ops.round_up(S + 64, 64), 256), e)
+                    cache._mh_state = st
+                y = engine.stack_prefill(spec, self._W["net"], e, B, S, self.rope("net"), st)
+                return y.view(B, S, spec.D)
+            if st.B != B:
+                raise ValueError(f"cache was built for batch {st.B}, got {B}")
+            outs = []
+            for s in range(S):  # chunked continuation: one event at a time
+                xs = e.view(B, S, spec.D)[:, s].contiguous() if S > 1 else e
+                outs.append(engine.stack_decode(spec, self._W["net"], xs, self.rope("net"), st))
+            return outs[0].view(B, 1, spec.D) if S == 1 else torch.stack(outs, dim=1)
+
+    def forward_token(self, hidden_state=None, x=None, cache=None) -> torch.Tensor:
+        """hidden_state (N, n_embd) and/or x (N, t) int64 -> logits (N, [1]+t, vocab)   [midi_model.py:116-135]"""
+        self._require_gpu()
+        if hidden_state is None and x is None:
+            raise ValueError("forward_token needs hidden_state and/or x")
+        if x is not None:
+            x = x.to(device=self.device, dtype=torch.long)
+        if cache is None:
+            from .autograd import TokFn
+            params = self._stack_params("net_token") + [self.lm_head.weight]
+            return TokFn.apply(self, hidden_state, x, *params)
+        spec = self._specs["net_token"]
+        st = getattr(cache, "_mh_state", None)
+        V, Vp = self.tokenizer.vocab_size, self.vocab_padded
+        with torch.no_grad():
+            rows = []
+            N = (hidden_state if hidden_state is not None else x).shape[0]
+            if hidden_state is not None:
+                rows.append(hidden_state.to(self.dtype).contiguous())
+            if x is not None:
+                for j in range(x.shape[1]):
+                    rows.append(self._W["net_token"].embed[x[:, j]])  # gather of N rows (indexing only)
+            if st is None:
+                st = KVState(spec, N, self.tokenizer.max_token_seq, rows[0])
+                cache._mh_state = st
+            outs = []
+            for r in rows:
+                h = engine.stack_decode(spec, self._W["net_token"], r.contiguous(), self.rope("net_token"), st)
+                lg = torch.empty((N, Vp), dtype=self.dtype, device=self.device)
+                ops.gemm_nt(h, self.lm_head.weight.data, lg[:, :V])
+                outs.append(lg[:, :V])
+            return torch.stack(outs, dim=1)
+
+    def _stack_params(self, pre: str) -> List[nn.Parameter]:
+        st = getattr(self, pre)
+        out = [st.embed_tokens.weight]
+        for l in st.layers:
+            out += [l.self_attn.q_proj.weight, l.self_attn.k_proj.weight, l.self_attn.v_proj.weight,
+                    l.self_attn.o_proj.weight, l.mlp.gate_proj.weight, l.mlp.up_proj.weight, l.mlp.down_proj.weight,
+                    l.input_layernorm.weight, l.post_attention_layernorm.weight]
+        out.append(st.norm.weight)
+        return out
+
+    def sample_top_p_k(self, probs, p, k, generator=None):
+        """midi_model.py:152-165, op for op (torch.sort / cumsum / multinomial), so a seeded
+        ``torch.Generator`` is consumed exactly as the reference consumes it."""
+        probs_sort, probs_idx = torch.sort(probs, dim=-1, descending=True)
+        probs_sum = torch.cumsum(probs_sort, dim=-1)
+        mask = probs_sum - probs_sort > p
+        probs_sort[mask] = 0.0
+        mask = torch.zeros(probs_sort.shape[-1], device=probs_sort.device)
+        mask[:k] = 1
+        probs_sort = probs_sort * mask
+        probs_sort.div_(probs_sort.sum(dim=-1, keepdim=True))
+        shape = probs_sort.shape
+        next_token = torch.multinomial(probs_sort.reshape(-1, shape[-1]), num_samples=1,
+                                       generator=generator).reshape(*shape[:-1], 1)
+        return torch.gather(probs_idx, -1, next_token).reshape(*shape[:-1])
+
+    # ------------------------------------------------------------------------------------- generation
+    def _grammar(self):
+        if self._tables is None:
+            first, lo, hi, arity = self.tokenizer.grammar_tables()
+            dev = self.device
+            self._tables = (torch.tensor(first, dtype=torch.uint8, device=dev),
+                            torch.tensor(lo, dtype=torch.int32, device=dev),
+                            torch.tensor(hi, dtype=torch.int32, device=dev), arity)
+        return self._tables
+
+    @torch.inference_mode()
+    def generate(self, prompt=None, batch_size=1, max_len=512, temp=1.0, top_p=0.98, top_k=20, generator=None,
+                 ban_eos: bool = False):
+        """midi_model.py:167-250 with the host-bound parts moved to the device: grammar masks come from
+        per-event-id range tables (no Python loop over the batch), K/V live in preallocated buffers, and the
+        only device->host traffic is ONE copy of the B sampled event ids per event (the reference does B
+        ``.item()`` calls).  The number of sampling calls per event follows the reference's break rule exactly,
+        so a seeded generator yields the reference's stream.  ``ban_eos`` (ours; throughput runs) removes EOS
+        from the first-token mask."""
+        self._require_gpu()
+        tok = self.tokenizer
+        T, V, Vp = tok.max_token_seq, tok.vocab_size, self.vocab_padded
+        dev = self.device
+        if prompt is None:
+            inp = torch.full((batch_size, 1, T), tok.pad_id, dtype=torch.long, device=dev)
+            inp[:, 0, 0] = tok.bos_id
+        else:
+            prompt = np.asarray(prompt)
+            if prompt.ndim == 2:
+                prompt = np.repeat(prompt[None, :], repeats=batch_size, axis=0)
+            elif prompt.shape[0] == 1:
+                prompt = np.repeat(prompt, repeats=batch_size, axis=0)
+            elif prompt.ndim != 3 or prompt.shape[0] != batch_size:
+                raise ValueError(f"invalid shape for prompt, {prompt.shape}")
+            prompt = prompt[..., :T]
+            if prompt.shape[-1] < T:
+                prompt = np.pad(prompt, ((0, 0), (0, 0), (0, T - prompt.shape[-1])), mode="constant",
+                                constant_values=tok.pad_id)
+            inp = torch.from_numpy(np.ascontiguousarray(prompt)).to(dtype=torch.long, device=dev)
+        B = batch_size
+        cur_len = inp.shape[1]
+        total = max(max_len, cur_len)
+        out = torch.full((B, total, T), tok.pad_id, dtype=torch.long, device=dev)
+        out[:, :cur_len] = inp
+        first_mask, lo_tab, hi_tab, arity = self._grammar()
+        if ban_eos:
+            first_mask = first_mask.clone()
+            first_mask[tok.eos_id] = 0
+        spec, tspec = self._specs["net"], self._specs["net_token"]
+        Wn, Wt = self._W["net"], self._W["net_token"]
+        kv1 = KVState(spec, B, ops.round_up(total + 1, 64), self._flat)
+        kv2 = KVState(tspec, B, T, self._flat)
+        neg1 = torch.full((B,), -1, dtype=torch.int32, device=dev)
+        probs = torch.empty((B, 1, V), dtype=torch.float32, device=dev)
+        logits = torch.empty((B, Vp), dtype=self.dtype, device=dev)
+        past_len = 0
+        lm_w = self.lm_head.weight.data
+        while cur_len < max_len:
+            S_new = cur_len - past_len
+            e = torch.empty((B * S_new, spec.D), dtype=self.dtype, device=dev)
+            ops.embed_sum_fwd(out[:, past_len:cur_len].reshape(B * S_new, T), Wn.embed, e)
+            if past_len == 0:
+                hidden = engine.stack_prefill(spec, Wn, e, B, S_new, self.rope("net"), kv1).view(B, S_new, spec.D)[:, -1].contiguous()
+            else:
+                hidden = engine.stack_decode(spec, Wn, e, self.rope("net"), kv1)
+            kv2.len = 0
+            seq = torch.full((B, T), tok.pad_id, dtype=torch.long, device=dev)
+            x_in = hidden
+            n_steps = T
+            ev_dev = None
+            end_all = False
+            i = 0
+            while i < n_steps:
+                h = engine.stack_decode(tspec, Wt, x_in, self.rope("net_token"), kv2)
+                ops.gemm_nt(h, lm_w, logits[:, :V])
+                if i == 0:
+                    lo, hi = neg1, neg1
+                else:
+                    lo, hi = lo_tab[ev_dev, i].contiguous(), hi_tab[ev_dev, i].contiguous()
+                ops.masked_softmax(logits, lo, hi, first_mask, probs.view(B, V), V, temp)
+                samples = self.sample_top_p_k(probs, top_p, top_k, generator=generator)  # (B, 1)
+                seq[:, i] = samples[:, 0]
+                if i == 0:
+                    ev_dev = samples[:, 0]
+                    ids = ev_dev.tolist()  # the one host sync per event
+                    alive = [a for a in (arity[t] for t in ids if t != tok.eos_id)]
+                    end_all = len(alive) == 0
+                    # reference break rule: the inner loop stops after position i iff every live row's event has
+                    # exactly i parameters (vacuously true at i == 1 when no row is live)
+                    if end_all:
+                        n_steps = 2
+                    elif all(a == alive[0] for a in alive):
+                        n_steps = alive[0] + 1
+                    else:
+                        n_steps = T
+                x_in = Wt.embed[samples[:, 0]]
+                i += 1
+            out[:, cur_len] = seq
+            past_len = cur_len
+            cur_len += 1
+            if end_all:
+                break
+        return out[:, :cur_len].cpu().numpy()
+
+    # ------------------------------------------------------------------------------------ persistence
+    def save_pretrained(self, save_directory: str):
+        from safetensors.torch import save_file
+        os.makedirs(save_directory, exist_ok=True)
+        self.config.save_pretrained(save_directory)
+        save_file({k: v.detach().cpu().contiguous() for k, v in self.state_dict().items()},
+                  os.path.join(save_directory, "model.safetensors"))
+
+    @classmethod
+    def from_pretrained(cls, directory: str):
+        from safetensors.torch import load_file
+        cfg = MIDIModelConfig.from_json_file(os.path.join(directory, "config.json"))
+        model = cls(cfg)
+        model.load_state_dict(load_file(os.path.join(directory, "model.safetensors")), strict=False)
+        return model

@@ -1,0 +1,239 @@
+"""Tensor-level wrappers over the C-ABI (include/midihip.h).  torch is only the memory/stream plumbing
+here: every function passes raw device pointers of caller-owned tensors to libmidihip.so on the current
+HIP stream.  Nothing in this module computes on the host and nothing falls back to torch math.
+"""
+from __future__ import annotations
+
+from typing import Optional
+
+import torch
+
+from .lib import MH_BF16, MH_F32, lib
+
+_DT = {torch.float32: MH_F32, torch.bfloat16: MH_BF16}
+
+
+def dt(t: torch.Tensor) -> int:
+    try:
+        return _DT[t.dtype]
+    except KeyError:
+        raise TypeError(f"unsupported dtype {t.dtype}: the HIP path computes in float32 or bfloat16") from None
+
+
+def _stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _p(t: Optional[torch.Tensor]) -> int:
+    if t is None:
+        return 0
+    if not t.is_cuda:
+        raise RuntimeError("HIP kernels need device tensors (there is no CPU implementation of this path)")
+    return t.data_ptr()
+
+
+def _rowmajor(t: torch.Tensor) -> int:
+    """leading dimension (elements) of a 2-D row-major view"""
+    assert t.dim() == 2 and t.stride(1) == 1, f"need a row-major 2-D view, got strides {t.stride()}"
+    return t.stride(0)
+
+
+def round_up(x: int, m: int) -> int:
+    return (x + m - 1) // m * m
+
+
+# ---------------------------------------------------------------------------------------------- GEMM
+def _pick_splitk(M: int, N: int, K: int) -> int:
+    tiles = ((M + 127) // 128) * ((N + 127) // 128)
+    if tiles >= 256 or K < 2048:
+        return 1
+    return int(max(1, min(64, 768 // tiles, K // 1024)))
+
+
+def gemm_nt(a: torch.Tensor, b: torch.Tensor, out: torch.Tensor, *, K: Optional[int] = None, alpha: float = 1.0,
+            beta: float = 0.0, res: Optional[torch.Tensor] = None, splitk: int = 0) -> torch.Tensor:
+    """out[M,N] = alpha * a[M,K] @ b[N,K]^T + beta * res   (res defaults to `out` when beta != 0)."""
+    M, N = out.shape
+    K = a.shape[1] if K is None else K
+    assert a.shape[0] == M and b.shape[0] == N and a.shape[1] >= K and b.shape[1] >= K, (a.shape, b.shape, out.shape, K)
+    assert a.dtype == b.dtype == out.dtype
+    if beta != 0.0 and res is None:
+        res = out
+    if splitk <= 0:
+        splitk = _pick_splitk(M, N, K)
+    ws = None
+    if splitk > 1:
+        ws = torch.empty((splitk, M, N), dtype=torch.float32, device=out.device)
+    lib().call("mh_gemm_nt", _p(a), _rowmajor(a), _p(b), _rowmajor(b), _p(out), _rowmajor(out), _p(res),
+               _rowmajor(res) if res is not None else 0, M, N, K, alpha, beta, dt(out), splitk, _p(ws), _stream())
+    return out
+
+
+def transpose(x: torch.Tensor, out: Optional[torch.Tensor] = None, pad_to: int = 8) -> torch.Tensor:
+    """x[R,C] -> out[C, ld>=R]; a fresh `out` has ld = R rounded up to `pad_to` with zeroed padding."""
+    R, C = x.shape
+    if out is None:
+        Rp = round_up(R, pad_to)
+        out = torch.empty((C, Rp), dtype=x.dtype, device=x.device)
+        if Rp != R:
+            out[:, R:].zero_()
+    lib().call("mh_transpose", _p(x), _rowmajor(x), _p(out), _rowmajor(out), R, C, dt(x), _stream())
+    return out
+
+
+# ---------------------------------------------------------------------------------------- embeddings
+def embed_sum_fwd(tok: torch.Tensor, table: torch.Tensor, out: torch.Tensor) -> torch.Tensor:
+    M, T = tok.shape
+    assert tok.dtype == torch.int64 and tok.is_contiguous() and table.is_contiguous()
+    lib().call("mh_embed_sum_fwd", _p(tok), _p(table), _p(out), M, T, table.shape[0], table.shape[1], dt(table), _stream())
+    return out
+
+
+def concat_tok_fwd(hidden: torch.Tensor, tok: torch.Tensor, table: torch.Tensor, out: torch.Tensor, T: int) -> torch.Tensor:
+    """out[M,T,D]: row 0 = hidden, rows 1..T-1 = table[tok[:, :T-1]]; tok may be a strided [M, >=T-1] view."""
+    M = hidden.shape[0]
+    assert tok.dtype == torch.int64 and tok.stride(1) == 1
+    lib().call("mh_concat_tok_fwd", _p(hidden), _p(tok), tok.stride(0), _p(table), _p(out), M, T, table.shape[0],
+               table.shape[1], dt(table), _stream())
+    return out
+
+
+def embed_scatter_bwd(tok: torch.Tensor, T: int, dout: torch.Tensor, rows_per_m: int, jstride: int, j0: int,
+                      dtable_f32: torch.Tensor, pad_id: int) -> None:
+    M = tok.shape[0]
+    assert tok.dtype == torch.int64 and tok.stride(1) == 1 and dtable_f32.dtype == torch.float32
+    V, D = dtable_f32.shape
+    lib().call("mh_embed_scatter_bwd", _p(tok), tok.stride(0), T, _p(dout), rows_per_m, jstride, j0, _p(dtable_f32), M, V, D,
+               pad_id, dt(dout), _stream())
+
+
+def cast_from_f32(src: torch.Tensor, dst: torch.Tensor, accumulate: bool) -> None:
+    assert src.dtype == torch.float32 and src.numel() == dst.numel() and dst.is_contiguous()
+    lib().call("mh_cast_from_f32", _p(src), _p(dst), src.numel(), int(accumulate), dt(dst), _stream())
+
+
+def copy_rows(src: torch.Tensor, src_ld: int, dst: torch.Tensor, dst_ld: int, M: int, D: int, accumulate: bool = False) -> None:
+    lib().call("mh_copy_rows", _p(src), src_ld, _p(dst), dst_ld, M, D, int(accumulate), dt(dst), _stream())
+
+
+# ------------------------------------------------------------------------------------------- RMSNorm
+def rmsnorm_fwd(x, w, y, rstd, eps: float):
+    M, D = x.shape
+    lib().call("mh_rmsnorm_fwd", _p(x), _p(w), _p(y), _p(rstd), M, D, eps, dt(x), _stream())
+    return y
+
+
+def rmsnorm_bwd(x, w, rstd, dy, dres, dx, dw: torch.Tensor, accumulate: bool):
+    """dx = d(norm)(dy) + dres; dw (+)= column sums."""
+    M, D = x.shape
+    nblk = lib().cdll.mh_rmsnorm_bwd_blocks(M)
+    partial = torch.empty((nblk, D), dtype=torch.float32, device=x.device)
+    lib().call("mh_rmsnorm_bwd", _p(x), _p(w), _p(rstd), _p(dy), _p(dres), _p(dx), _p(partial), M, D, dt(x), _stream())
+    lib().call("mh_colsum", _p(partial), nblk, _p(dw), D, int(accumulate), dt(dw), _stream())
+    return dx
+
+
+# ---------------------------------------------------------------------------------------------- RoPE
+def rope_(qkv: torch.Tensor, cos_t: torch.Tensor, sin_t: torch.Tensor, S: int, pos0: int, H: int, hd: int, direction: int = 1):
+    M = qkv.shape[0]
+    assert qkv.is_contiguous() and qkv.shape[1] == 3 * H * hd
+    assert cos_t.shape[0] >= pos0 + min(S, M), "RoPE table too short"
+    lib().call("mh_rope", _p(qkv), _p(cos_t), _p(sin_t), M, S, pos0, H, hd, direction, dt(qkv), _stream())
+    return qkv
+
+
+# ----------------------------------------------------------------------------------------- attention
+def attn_fwd(qkv, o, lse, B: int, S: int, H: int, scale: float):
+    vt = None
+    if qkv.dtype == torch.bfloat16:
+        Sp = round_up(S, 64)
+        vt = torch.empty((B * H * 64 * Sp,), dtype=qkv.dtype, device=qkv.device)
+        lib().call("mh_attn_prep_fwd", _p(qkv), _p(vt), B, S, H, dt(qkv), _stream())
+    lib().call("mh_attn_fwd", _p(qkv), _p(vt), _p(o), _p(lse), B, S, H, scale, dt(qkv), _stream())
+    return o
+
+
+def attn_bwd(qkv, o, dout, lse, dqkv, B: int, S: int, H: int, scale: float):
+    Sp = round_up(S, 64)
+    delta = torch.empty((B * H * Sp,), dtype=torch.float32, device=qkv.device)
+    qt = kt = dot = None
+    if qkv.dtype == torch.bfloat16:
+        n = B * H * 64 * Sp
+        buf = torch.empty((3, n), dtype=qkv.dtype, device=qkv.device)
+        qt, kt, dot = buf[0], buf[1], buf[2]
+    lib().call("mh_attn_prep_bwd", _p(qkv), _p(o), _p(dout), _p(delta), _p(qt), _p(kt), _p(dot), B, S, H, dt(qkv), _stream())
+    lib().call("mh_attn_bwd", _p(qkv), _p(dout), _p(lse), _p(delta), _p(qt), _p(kt), _p(dot), _p(dqkv), B, S, H, scale,
+               dt(qkv), _stream())
+    return dqkv
+
+
+def tokattn_fwd(qkv, o, N: int, T: int, H: int, scale: float):
+    lib().call("mh_tokattn_fwd", _p(qkv), _p(o), N, T, H, scale, dt(qkv), _stream())
+    return o
+
+
+def tokattn_bwd(qkv, dout, dqkv, N: int, T: int, H: int, scale: float):
+    lib().call("mh_tokattn_bwd", _p(qkv), _p(dout), _p(dqkv), N, T, H, scale, dt(qkv), _stream())
+    return dqkv
+
+
+# -------------------------------------------------------------------------------------------- SwiGLU
+def swiglu_fwd(gu, a):
+    M, I2 = gu.shape
+    lib().call("mh_swiglu_fwd", _p(gu), _p(a), M, I2 // 2, dt(gu), _stream())
+    return a
+
+
+def swiglu_bwd(gu, da, dgu):
+    M, I2 = gu.shape
+    lib().call("mh_swiglu_bwd", _p(gu), _p(da), _p(dgu), M, I2 // 2, dt(gu), _stream())
+    return dgu
+
+
+# ---------------------------------------------------------------------------------------------- loss
+def cross_entropy(logits, V: int, target, row_loss, dlogits=None, scale_dev=None, argmax_out=None, ignore: int = 0):
+    R = logits.shape[0]
+    lib().call("mh_cross_entropy", _p(logits), _rowmajor(logits), _p(target), _p(row_loss), _p(dlogits), _p(scale_dev),
+               _p(argmax_out), R, V, ignore, dt(logits), _stream())
+
+
+def sum_f32(x, out):
+    lib().call("mh_sum_f32", _p(x), x.numel(), _p(out), _stream())
+
+
+def count_valid(target, ignore: int, count, inv):
+    lib().call("mh_count_valid", _p(target), target.numel(), ignore, _p(count), _p(inv), _stream())
+
+
+# ----------------------------------------------------------------------------------------- optimiser
+def sumsq(g, partial1024, out, accumulate: bool):
+    lib().call("mh_sumsq", _p(g), g.numel(), _p(partial1024), _p(out), int(accumulate), dt(g), _stream())
+
+
+def clip_coef(sumsq_t, max_norm: float, coef, norm):
+    lib().call("mh_clip_coef", _p(sumsq_t), max_norm, _p(coef), _p(norm), _stream())
+
+
+def adamw(p, g, m, v, lr, b1, b2, eps, wd, bc1, bc2, coef_dev):
+    lib().call("mh_adamw", _p(p), _p(g), _p(m), _p(v), p.numel(), lr, b1, b2, eps, wd, bc1, bc2, _p(coef_dev), dt(p), _stream())
+
+
+# -------------------------------------------------------------------------------------------- decode
+def kv_append(qkv, cos_t, sin_t, kc, vc, B: int, H: int, hd: int, Lmax: int, pos: int):
+    lib().call("mh_kv_append", _p(qkv), _p(cos_t), _p(sin_t), _p(kc), _p(vc), B, H, hd, Lmax, pos, dt(qkv), _stream())
+
+
+def attn_decode(qkv, kc, vc, o, B: int, H: int, hd: int, Lmax: int, length: int, scale: float):
+    lib().call("mh_attn_decode", _p(qkv), _p(kc), _p(vc), _p(o), B, H, hd, Lmax, length, scale, dt(qkv), _stream())
+    return o
+
+
+def kv_store_prefill(qkv, kc, vc, B: int, S: int, H: int, hd: int, Lmax: int):
+    lib().call("mh_kv_store_prefill", _p(qkv), _p(kc), _p(vc), B, S, H, hd, Lmax, dt(qkv), _stream())
+
+
+def masked_softmax(logits, lo, hi, first_mask, probs, V: int, temp: float):
+    B = logits.shape[0]
+    lib().call("mh_masked_softmax", _p(logits), _rowmajor(logits), _p(lo), _p(hi), _p(first_mask), _p(probs), B, V, temp,
+               dt(logits), _stream())
+    return probs

@@ -1,0 +1,350 @@
+"""The data-parallel training step of the reference (train.py:106-206, Trainer wiring :461-474) on HIP.
+
+``TrainMIDIModel`` keeps the reference's names (``training_step``, ``validation_step``,
+``configure_optimizers``, ``compute_accuracy``) but, with no Lightning underneath, the step is explicit:
+
+    loss = model.training_step(batch)      # forward + backward; gradients land in one flat buffer
+    model.optimizer_step()                 # every `accumulate_grad_batches` micro-batches:
+                                           #   [all-reduce done] -> global-norm clip(1.0) -> fused AdamW -> LR schedule
+
+Forward/backward are the explicit schedules of ``engine.py``; lm_head + cross-entropy run chunked so the
+(B*S*8, vocab) logits tensor (1.8 GB in bf16 at B=16, S=2048) is never materialised.  Data parallelism is one
+process per GPU: gradients are averaged with bucketed asynchronous all-reduces (torch.distributed "nccl" =
+RCCL over xGMI; "gloo" in the CPU tests) issued on a side stream as backward finishes each contiguous range of
+the flat gradient buffer, so communication overlaps the rest of backward (reference: DDP inside Lightning).
+"""
+from __future__ import annotations
+
+import math
+import random
+from typing import Callable, List, Optional, Tuple
+
+import torch
+
+from . import engine, ops
+from .config import MIDIModelConfig
+from .model import MIDIModel
+
+
+def lr_lambda(step: int, warmup: float, max_step: float) -> float:
+    """get_linear_schedule_with_warmup (train.py:93-103)."""
+    if step < warmup:
+        return float(step) / float(max(1, warmup))
+    return max(0.0, float(max_step - step) / float(max(1, max_step - warmup)))
+
+
+class GradReducer:
+    """Bucketed, overlapped gradient averaging over a flat buffer.
+
+    ``ready(lo, hi)`` announces that flat[lo:hi] holds final gradients; announcements arrive back to front
+    (backward order).  Adjacent ranges are merged until ``bucket_bytes`` is reached, then one all-reduce(SUM)
+    of the merged range is launched asynchronously on the communication stream; ``finish()`` flushes the tail,
+    waits for everything and leaves gradients divided by world size.  Device-agnostic (CPU tensors + gloo in
+    the tests, HIP tensors + RCCL on the GPU)."""
+
+    def __init__(self, flat_grad: torch.Tensor, group=None, bucket_bytes: int = 32 << 20):
+        import torch.distributed as dist
+        self.dist = dist
+        self.flat = flat_grad
+        self.group = group
+        self.world = dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
+        self.bucket_elems = max(1, bucket_bytes // flat_grad.element_size())
+        self.pending: Optional[Tuple[int, int]] = None
+        self.works: list = []
+        self.launched: List[Tuple[int, int]] = []
+        self.comm_stream = torch.cuda.Stream() if flat_grad.is_cuda else None
+
+    def ready(self, lo: int, hi: int):
+        if self.world == 1:
+            return
+        if self.pending is None:
+            self.pending = (lo, hi)
+        else:
+            plo, phi = self.pending
+            if hi == plo:
+                self.pending = (lo, phi)
+            elif lo == phi:
+                self.pending = (plo, hi)
+            else:  # not adjacent: ship what we have
+                self._launch(plo, phi)
+                self.pending = (lo, hi)
+        plo, phi = self.pending
+        if phi - plo >= self.bucket_elems:
+            self._launch(plo, phi)
+            self.pending = None
+
+    def _launch(self, lo: int, hi: int):
+        buf = self.flat[lo:hi]
+        self.launched.append((lo, hi))
+        if self.comm_stream is not None:
+            self.comm_stream.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(self.comm_stream):
+                buf.div_(self.world)
+                self.works.append(self.dist.all_reduce(buf, op=self.dist.ReduceOp.SUM, group=self.group, async_op=True))
+        else:
+            buf.div_(self.world)
+            self.works.append(self.dist.all_reduce(buf, op=self.dist.ReduceOp.SUM, group=self.group, async_op=True))
+
+    def finish(self):
+        if self.world == 1:
+            return
+        if self.pending is not None:
+            self._launch(*self.pending)
+            self.pending = None
+        for w in self.works:
+            w.wait()
+        if self.comm_stream is not None:
+            torch.cuda.current_stream().wait_stream(self.comm_stream)
+        self.works.clear()
+        self.launched.clear()
+
+
+class TrainMIDIModel(MIDIModel):
+    def __init__(self, config: MIDIModelConfig, lr=2e-4, weight_decay=0.01, warmup=1e3, max_step=1e6,
+                 sample_seq=False, gen_example_interval=1, example_batch=8, accumulate_grad_batches=2,
+                 gradient_clip_val=1.0, ce_chunk_rows=32768, bucket_mb=32):
+        super().__init__(config)
+        self.lr, self.weight_decay, self.warmup, self.max_step = lr, weight_decay, warmup, max_step
+        self.sample_seq = sample_seq
+        self.gen_example_interval, self.example_batch = gen_example_interval, example_batch
+        self.accumulate_grad_batches = accumulate_grad_batches
+        self.gradient_clip_val = gradient_clip_val
+        self.ce_chunk_rows = ce_chunk_rows
+        self.bucket_mb = bucket_mb
+        self.betas, self.eps = (0.9, 0.99), 1e-8
+        self.global_step = 0       # optimiser steps taken
+        self._micro = 0            # micro-batches since the last optimiser step
+        self._opt = None
+        self._reducer = None
+        self.last_grad_norm = None
+        self.process_group = None
+
+    # ----------------------------------------------------------------------------------- optimiser
+    def configure_optimizers(self):
+        """AdamW(lr, betas=(0.9, 0.99), eps=1e-8); weight decay on every parameter whose NAME contains neither
+        'bias' nor 'norm' (train.py:121-151) — in the flat layout that is exactly the matrix region."""
+        self._require_gpu()
+        flat = self._flat
+        self._opt = {
+            "m": torch.zeros_like(flat), "v": torch.zeros_like(flat),
+            "sumsq": torch.zeros(1, dtype=torch.float32, device=flat.device),
+            "partial": torch.empty(1024, dtype=torch.float32, device=flat.device),
+            "coef": torch.ones(1, dtype=torch.float32, device=flat.device),
+            "norm": torch.zeros(1, dtype=torch.float32, device=flat.device),
+        }
+        for name, (off, n, grp) in self._offsets.items():
+            assert (grp == "norm") == any(nd in name for nd in ("bias", "norm")), name
+        return self._opt
+
+    def current_lr(self) -> float:
+        return self.lr * lr_lambda(self.global_step, self.warmup, self.max_step)
+
+    def optimizer_step(self):
+        """clip_grad_norm_(1.0) -> AdamW -> scheduler.step(), all on device (no host sync)."""
+        if self._opt is None:
+            self.configure_optimizers()
+        if self._reducer is not None:
+            self._reducer.finish()
+        o = self._opt
+        g = self.grad_buffer()
+        if self.gradient_clip_val is not None and self.gradient_clip_val > 0:
+            ops.sumsq(g, o["partial"], o["sumsq"], False)
+            ops.clip_coef(o["sumsq"], float(self.gradient_clip_val), o["coef"], o["norm"])
+            self.last_grad_norm = o["norm"]
+            coef = o["coef"]
+        else:
+            coef = None
+        lr = self.current_lr()
+        step = self.global_step + 1
+        bc1, bc2 = 1.0 - self.betas[0] ** step, 1.0 - self.betas[1] ** step
+        nm = self._n_mat
+        flat = self._flat
+        ops.adamw(flat[:nm], g[:nm], o["m"][:nm], o["v"][:nm], lr, self.betas[0], self.betas[1], self.eps,
+                  self.weight_decay, bc1, bc2, coef)
+        ops.adamw(flat[nm:], g[nm:], o["m"][nm:], o["v"][nm:], lr, self.betas[0], self.betas[1], self.eps, 0.0,
+                  bc1, bc2, coef)
+        self._wt_version = -1  # the kernels wrote through raw pointers: transposed weight copies are stale
+        self.global_step += 1
+        self._micro = 0
+
+    def zero_grad(self, set_to_none: bool = False):
+        if self._flat_grad is not None:
+            self._flat_grad.zero_()
+        self._micro = 0
+
+    # --------------------------------------------------------------------------------- fused step
+    def _loss_and_backward(self, batch: torch.Tensor, backward: bool, want_acc: bool = False):
+        """train.py:168-188 (+ its backward).  batch (B, S+1, 8) int64.  Returns (loss[1] fp32 device tensor, acc)."""
+        self._require_gpu()
+        tok = self.tokenizer
+        dev, dty = self.device, self.dtype
+        batch = batch.to(device=dev, dtype=torch.long)
+        x = batch[:, :-1].contiguous()
+        y = batch[:, 1:].contiguous()
+        B, S, T = x.shape
+        spec, tspec = self._specs["net"], self._specs["net_token"]
+        Wn, Wt = self._W["net"], self._W["net_token"]
+        D = spec.D
+        V, Vp = tok.vocab_size, self.vocab_padded
+        M = B * S
+
+        # ---- forward: event-level net
+        e = torch.empty((M, D), dtype=dty, device=dev)
+        ops.embed_sum_fwd(x.view(M, T), Wn.embed, e)
+        hidden, ctx_net = engine.stack_forward(spec, Wn, e, B, S, self.rope("net"), save=backward)
+        del e
+        sel = None
+        if self.sample_seq:  # train.py:172-175: keep the last position + up to 127 random others
+            idx = [-1] + random.sample(list(range(S - 2)), min(127, (S - 2) // 2))
+            sel = torch.tensor([i % S for i in idx], dtype=torch.long, device=dev)
+            hidden_t = hidden.view(B, S, D)[:, sel].reshape(-1, D).contiguous()
+            y_t = y[:, sel].reshape(-1, T).contiguous()
+        else:
+            hidden_t = hidden
+            y_t = y.view(M, T)
+        N = hidden_t.shape[0]
+        R = N * T
+
+        # ---- forward: token-level net over [hidden ; embed(y[:, :7])]
+        seq = torch.empty((N, T, D), dtype=dty, device=dev)
+        ops.concat_tok_fwd(hidden_t, y_t, Wt.embed, seq, T)
+        h, ctx_tok = engine.stack_forward(tspec, Wt, seq.view(R, D), N, T, self.rope("net_token"), save=backward)
+        del seq
+
+        # ---- lm_head + cross-entropy (+ their backward), chunked over rows
+        targets = y_t.reshape(R)
+        cnt = torch.empty(1, dtype=torch.float32, device=dev)
+        inv = torch.empty(1, dtype=torch.float32, device=dev)
+        ops.count_valid(targets, tok.pad_id, cnt, inv)
+        row_loss = torch.empty(R, dtype=torch.float32, device=dev)
+        argmax = torch.empty(R, dtype=torch.long, device=dev) if want_acc else None
+        lm_w = self.lm_head.weight.data
+        accumulate = backward and self._micro > 0
+        if backward:
+            self.grad_buffer()
+            views, lmT = self.transposed()
+            dh = torch.empty((R, D), dtype=dty, device=dev)
+        chunk = max(T, (self.ce_chunk_rows // T) * T)
+        logits = torch.empty((min(chunk, R), Vp), dtype=dty, device=dev)
+        first = True
+        for r0 in range(0, R, chunk):
+            r1 = min(R, r0 + chunk)
+            lg = logits[: r1 - r0]
+            ops.gemm_nt(h[r0:r1], lm_w, lg[:, :V])
+            ops.cross_entropy(lg, V, targets[r0:r1], row_loss[r0:r1], lg if backward else None, inv,
+                              argmax[r0:r1] if want_acc else None, tok.pad_id)
+            if backward:
+                ops.gemm_nt(lg, lmT, dh[r0:r1])                       # d h = dlogits @ W_lm
+                dlT = ops.transpose(lg)                               # [Vp, rows]
+                hT = ops.transpose(h[r0:r1])                          # [D, rows]
+                ops.gemm_nt(dlT[:V], hT, self._g_lm, K=dlT.shape[1], beta=0.0 if (first and not accumulate) else 1.0)
+                first = False
+        loss_sum = torch.empty(1, dtype=torch.float32, device=dev)
+        ops.sum_f32(row_loss, loss_sum)
+        loss = loss_sum * inv
+        acc = None
+        if want_acc:
+            keep = targets != tok.pad_id
+            acc = ((argmax == targets) & keep).sum().float() / keep.sum()
+        if not backward:
+            return loss, acc
+
+        # ---- backward, announcing finished gradient ranges to the reducer back to front
+        red = self._reducer_for_step()
+        off_lm, n_lm, _ = self._offsets["lm_head.weight"]
+        self._announce(red, off_lm, off_lm + n_lm)
+
+        def tok_done(li: int):
+            self._announce(red, *self._layer_range("net_token", li))
+
+        dseq = engine.stack_backward(tspec, Wt, views["net_token"], self._G["net_token"], ctx_tok, dh,
+                                     self.rope("net_token"), accumulate, tok_done)
+        del dh, ctx_tok
+        acc32 = torch.zeros((V, D), dtype=torch.float32, device=dev)
+        ops.embed_scatter_bwd(y_t, T - 1, dseq, T, 1, 1, acc32, tok.pad_id)
+        ops.cast_from_f32(acc32, self._G["net_token"].embed, accumulate)
+        o, n, _ = self._offsets["net_token.embed_tokens.weight"]
+        self._announce(red, o, o + n)
+        dhid_t = torch.empty((N, D), dtype=dty, device=dev)
+        ops.copy_rows(dseq, T * D, dhid_t, D, N, D)
+        del dseq
+        if sel is not None:
+            dhidden = torch.zeros((B, S, D), dtype=dty, device=dev)
+            dhidden.index_add_(1, sel, dhid_t.view(B, -1, D))
+            dhidden = dhidden.view(M, D)
+        else:
+            dhidden = dhid_t
+
+        def net_done(li: int):
+            self._announce(red, *self._layer_range("net", li))
+
+        dx = engine.stack_backward(spec, Wn, views["net"], self._G["net"], ctx_net, dhidden, self.rope("net"),
+                                   accumulate, net_done)
+        acc32.zero_()
+        ops.embed_scatter_bwd(x.view(M, T), T, dx, 1, 0, 0, acc32, tok.pad_id)
+        ops.cast_from_f32(acc32, self._G["net"].embed, accumulate)
+        o, n, _ = self._offsets["net.embed_tokens.weight"]
+        self._announce(red, o, o + n)
+        self._announce(red, self._n_mat, self._flat.numel())  # all norm vectors
+        self._micro += 1
+        return loss, acc
+
+    def _layer_range(self, pre: str, li: int) -> Tuple[int, int]:
+        lo = self._offsets[f"{pre}.layers.{li}.self_attn.q_proj.weight"][0]
+        o, n, _ = self._offsets[f"{pre}.layers.{li}.mlp.down_proj.weight"]
+        return lo, o + n
+
+    def _reducer_for_step(self):
+        import torch.distributed as dist
+        if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(self.process_group) == 1:
+            return None
+        # exchange only on the micro-batch that completes an accumulation window (DDP no_sync otherwise)
+        if (self._micro + 1) % max(1, self.accumulate_grad_batches) != 0:
+            return None
+        if self._reducer is None or self._reducer.flat is not self._flat_grad:
+            self._reducer = GradReducer(self._flat_grad, self.process_group, self.bucket_mb << 20)
+        return self._reducer
+
+    @staticmethod
+    def _announce(red, lo: int, hi: int):
+        if red is not None:
+            red.ready(lo, hi)
+
+    # ------------------------------------------------------------------------- reference-named API
+    def training_step(self, batch, batch_idx: int = 0):
+        loss, _ = self._loss_and_backward(batch, backward=True)
+        return loss
+
+    @torch.no_grad()
+    def validation_step(self, batch, batch_idx: int = 0):
+        """train.py:190-206: returns (loss, acc); with a process group the two scalars are averaged over ranks
+        (``sync_dist=True``)."""
+        loss, acc = self._loss_and_backward(batch, backward=False, want_acc=True)
+        import torch.distributed as dist
+        if dist.is_available() and dist.is_initialized() and dist.get_world_size(self.process_group) > 1:
+            pair = torch.stack([loss.reshape(()), acc.reshape(())])
+            dist.all_reduce(pair, group=self.process_group)
+            pair /= dist.get_world_size(self.process_group)
+            loss, acc = pair[0:1], pair[1]
+        return loss, acc
+
+    def compute_accuracy(self, logits, labels):
+        """train.py:153-166 on materialised logits (API compatibility; the fused path gets argmax from the CE kernel)."""
+        out = torch.argmax(logits, dim=-1).flatten()
+        labels = labels.flatten()
+        mask = labels != self.tokenizer.pad_id
+        return (out[mask] == labels[mask]).float().sum() / mask.sum()
+
+    def fit_step(self, batch):
+        """One micro-batch + (on the accumulation boundary) one optimiser step; returns the loss tensor."""
+        loss = self.training_step(batch)
+        if self._micro % max(1, self.accumulate_grad_batches) == 0:
+            self.optimizer_step()
+        return loss
+
+    def broadcast_parameters(self, src: int = 0):
+        """DDP constructor behaviour: rank `src`'s weights everywhere (one flat broadcast)."""
+        import torch.distributed as dist
+        if dist.is_available() and dist.is_initialized() and dist.get_world_size(self.process_group) > 1:
+            dist.broadcast(self._flat, src=src, group=self.process_group)
+            self._wt_version = -1

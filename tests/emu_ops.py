@@ -1,0 +1,290 @@
+"""TEST-ONLY fake backend: torch-CPU stand-ins for every function of ``midi_model_amd.ops`` so the HOST logic
+(kernel schedules of engine.py, the flat parameter/gradient layout, the fused training step, the decode loop,
+the gradient reducer) can be exercised in the GPU-less container.  The product never imports this file; on a
+GPU box the same tests run against the real HIP kernels (tests marked ``gpu``).
+
+Each stand-in follows the C-ABI contract of include/midihip.h for its entry point (argument meaning, in-place
+behaviour, buffer layouts such as lse[B,H,Sp]).
+"""
+from __future__ import annotations
+
+import contextlib
+import math
+
+import torch
+import torch.nn.functional as F
+
+
+def round_up(x, m):
+    return (x + m - 1) // m * m
+
+
+def gemm_nt(a, b, out, *, K=None, alpha=1.0, beta=0.0, res=None, splitk=0):
+    K = a.shape[1] if K is None else K
+    M, N = out.shape
+    acc = a[:M, :K].float() @ b[:N, :K].float().T
+    r = alpha * acc
+    if beta != 0.0:
+        r = r + beta * (out if res is None else res).float()
+    out.copy_(r.to(out.dtype))
+    return out
+
+
+def transpose(x, out=None, pad_to=8):
+    R, C = x.shape
+    if out is None:
+        out = torch.zeros((C, round_up(R, pad_to)), dtype=x.dtype)
+    out[:C, :R] = x.T
+    return out
+
+
+def embed_sum_fwd(tok, table, out):
+    out.copy_(table[tok].float().sum(1).to(out.dtype))
+    return out
+
+
+def concat_tok_fwd(hidden, tok, table, out, T):
+    out[:, 0] = hidden
+    if T > 1:
+        out[:, 1:] = table[tok[:, : T - 1]]
+    return out
+
+
+def embed_scatter_bwd(tok, T, dout, rows_per_m, jstride, j0, dtable_f32, pad_id):
+    M = tok.shape[0]
+    D = dtable_f32.shape[1]
+    d = dout.reshape(-1, D).float()
+    for j in range(T):
+        ids = tok[:, j]
+        rows = torch.arange(M) * rows_per_m + j * jstride + j0
+        keep = ids != pad_id
+        dtable_f32.index_add_(0, ids[keep], d[rows[keep]])
+
+
+def cast_from_f32(src, dst, accumulate):
+    flat = dst.view(-1)
+    flat.copy_(((flat.float() if accumulate else 0) + src.view(-1)).to(dst.dtype))
+
+
+def copy_rows(src, src_ld, dst, dst_ld, M, D, accumulate=False):
+    s = torch.as_strided(src, (M, D), (src_ld, 1), src.storage_offset())
+    d = torch.as_strided(dst, (M, D), (dst_ld, 1), dst.storage_offset())
+    d.copy_((s.float() + (d.float() if accumulate else 0)).to(dst.dtype))
+
+
+def rmsnorm_fwd(x, w, y, rstd, eps):
+    xf = x.float()
+    r = torch.rsqrt(xf.pow(2).mean(-1) + eps)
+    if rstd is not None:
+        rstd.copy_(r)
+    y.copy_((w.float() * (xf * r[:, None]).to(x.dtype).float()).to(y.dtype))
+    return y
+
+
+def rmsnorm_bwd(x, w, rstd, dy, dres, dx, dw, accumulate):
+    xf, g = x.float(), dy.float() * w.float()
+    xh = xf * rstd[:, None]
+    c = (g * xh).mean(-1, keepdim=True)
+    d = rstd[:, None] * (g - xh * c)
+    if dres is not None:
+        d = d + dres.float()
+    dwn = (dy.float() * xh.to(x.dtype).float()).sum(0)
+    dx.copy_(d.to(dx.dtype))
+    dw.copy_(((dw.float() if accumulate else 0) + dwn).to(dw.dtype))
+    return dx
+
+
+def rope_(qkv, cos_t, sin_t, S, pos0, H, hd, direction=1):
+    M = qkv.shape[0]
+    D = H * hd
+    pos = pos0 + (torch.arange(M) % S)
+    c = cos_t[pos].to(qkv.dtype).float()[:, None, :]
+    s = direction * sin_t[pos].to(qkv.dtype).float()[:, None, :]
+    for part in range(2):
+        v = qkv[:, part * D:(part + 1) * D].float().view(M, H, hd)
+        x1, x2 = v[..., : hd // 2], v[..., hd // 2:]
+        o = torch.cat([x1 * c - x2 * s, x2 * c + x1 * s], -1)
+        qkv[:, part * D:(part + 1) * D] = o.reshape(M, D).to(qkv.dtype)
+    return qkv
+
+
+def _split(qkv, B, S, H, hd):
+    D = H * hd
+    q, k, v = (qkv[:, i * D:(i + 1) * D].float().view(B, S, H, hd).transpose(1, 2) for i in range(3))
+    return q, k, v
+
+
+def _causal_scores(q, k, scale):
+    S = q.shape[-2]
+    s = (q @ k.transpose(-1, -2)) * scale
+    mask = torch.triu(torch.ones(S, S, dtype=torch.bool), 1)
+    return s.masked_fill(mask, float("-inf"))
+
+
+def attn_fwd(qkv, o, lse, B, S, H, scale):
+    q, k, v = _split(qkv, B, S, H, 64)
+    s = _causal_scores(q, k, scale)
+    p = torch.softmax(s, -1)
+    o.copy_((p @ v).transpose(1, 2).reshape(B * S, H * 64).to(o.dtype))
+    Sp = round_up(S, 64)
+    lse.view(B, H, Sp)[:, :, :S] = torch.logsumexp(s, -1)
+    return o
+
+
+def _attn_grads(q, k, v, do, scale):
+    s = _causal_scores(q, k, scale)
+    p = torch.softmax(s, -1)
+    dv = p.transpose(-1, -2) @ do
+    dp = do @ v.transpose(-1, -2)
+    ds = p * (dp - (p * dp).sum(-1, keepdim=True)) * scale
+    return ds @ k, ds.transpose(-1, -2) @ q, dv
+
+
+def attn_bwd(qkv, o, dout, lse, dqkv, B, S, H, scale):
+    q, k, v = _split(qkv, B, S, H, 64)
+    do = dout.float().view(B, S, H, 64).transpose(1, 2)
+    dq, dk, dv = _attn_grads(q, k, v, do, scale)
+    D = H * 64
+    for i, t in enumerate((dq, dk, dv)):
+        dqkv[:, i * D:(i + 1) * D] = t.transpose(1, 2).reshape(B * S, D).to(dqkv.dtype)
+    return dqkv
+
+
+def tokattn_fwd(qkv, o, N, T, H, scale):
+    q, k, v = _split(qkv, N, T, H, 256)
+    p = torch.softmax(_causal_scores(q, k, scale), -1)
+    o.copy_((p @ v).transpose(1, 2).reshape(N * T, H * 256).to(o.dtype))
+    return o
+
+
+def tokattn_bwd(qkv, dout, dqkv, N, T, H, scale):
+    q, k, v = _split(qkv, N, T, H, 256)
+    do = dout.float().view(N, T, H, 256).transpose(1, 2)
+    dq, dk, dv = _attn_grads(q, k, v, do, scale)
+    D = H * 256
+    for i, t in enumerate((dq, dk, dv)):
+        dqkv[:, i * D:(i + 1) * D] = t.transpose(1, 2).reshape(N * T, D).to(dqkv.dtype)
+    return dqkv
+
+
+def swiglu_fwd(gu, a):
+    I = gu.shape[1] // 2
+    g, u = gu[:, :I].float(), gu[:, I:].float()
+    a.copy_((F.silu(g).to(gu.dtype).float() * u).to(a.dtype))
+    return a
+
+
+def swiglu_bwd(gu, da, dgu):
+    I = gu.shape[1] // 2
+    g, u, d = gu[:, :I].float(), gu[:, I:].float(), da.float()
+    sig = torch.sigmoid(g)
+    dgu[:, :I] = (d * u * (sig * (1 + g * (1 - sig)))).to(dgu.dtype)
+    dgu[:, I:] = (d * g * sig).to(dgu.dtype)
+    return dgu
+
+
+def cross_entropy(logits, V, target, row_loss, dlogits=None, scale_dev=None, argmax_out=None, ignore=0):
+    lg = logits[:, :V].float()
+    lse = torch.logsumexp(lg, -1)
+    keep = target != ignore
+    tl = lg.gather(1, target[:, None]).squeeze(1)
+    row_loss.copy_(torch.where(keep, lse - tl, torch.zeros_like(lse)))
+    if argmax_out is not None:
+        argmax_out.copy_(lg.argmax(-1))
+    if dlogits is not None:
+        g = torch.softmax(lg, -1)
+        g[torch.arange(g.shape[0]), target] -= 1
+        g = g * (scale_dev[0] if scale_dev is not None else 1.0)
+        g[~keep] = 0
+        dlogits.zero_()
+        dlogits[:, :V] = g.to(dlogits.dtype)
+
+
+def sum_f32(x, out):
+    out[0] = x.sum()
+
+
+def count_valid(target, ignore, count, inv):
+    c = (target != ignore).sum().float()
+    count[0] = c
+    inv[0] = 1.0 / max(c.item(), 1.0)
+
+
+def sumsq(g, partial1024, out, accumulate):
+    s = g.float().pow(2).sum()
+    out[0] = (out[0] if accumulate else 0) + s
+
+
+def clip_coef(sumsq_t, max_norm, coef, norm):
+    n = sumsq_t[0].sqrt()
+    norm[0] = n
+    coef[0] = min(1.0, max_norm / (n.item() + 1e-6))
+
+
+def adamw(p, g, m, v, lr, b1, b2, eps, wd, bc1, bc2, coef_dev):
+    T = p.dtype
+    r = lambda t: t.to(T).float()
+    gr = r(g.float() * (coef_dev[0] if coef_dev is not None else 1.0))
+    pe = r(p.float() * (1 - lr * wd))
+    me = r(m.float() + (gr - m.float()) * (1 - b1))
+    ve = r(r(v.float() * b2) + (1 - b2) * gr * gr)
+    den = r(r(r(ve.sqrt()) / math.sqrt(bc2)) + eps)
+    p.copy_((pe - (lr / bc1) * (me / den)).to(T))
+    m.copy_(me.to(T))
+    v.copy_(ve.to(T))
+
+
+def kv_append(qkv, cos_t, sin_t, kc, vc, B, H, hd, Lmax, pos):
+    rope_(qkv, cos_t, sin_t, 1, pos, H, hd, 1)
+    D = H * hd
+    kc[:, :, pos] = qkv[:, D:2 * D].view(B, H, hd)
+    vc[:, :, pos] = qkv[:, 2 * D:].view(B, H, hd)
+
+
+def attn_decode(qkv, kc, vc, o, B, H, hd, Lmax, length, scale):
+    q = qkv[:, : H * hd].float().view(B, H, 1, hd)
+    k, v = kc[:, :, :length].float(), vc[:, :, :length].float()
+    p = torch.softmax((q @ k.transpose(-1, -2)) * scale, -1)
+    o.copy_((p @ v).reshape(B, H * hd).to(o.dtype))
+    return o
+
+
+def kv_store_prefill(qkv, kc, vc, B, S, H, hd, Lmax):
+    D = H * hd
+    kc[:, :, :S] = qkv[:, D:2 * D].view(B, S, H, hd).transpose(1, 2)
+    vc[:, :, :S] = qkv[:, 2 * D:].view(B, S, H, hd).transpose(1, 2)
+
+
+def masked_softmax(logits, lo, hi, first_mask, probs, V, temp):
+    T = logits.dtype
+    p = torch.softmax((logits[:, :V].float() / temp).to(T).float(), -1)
+    ids = torch.arange(V)[None, :]
+    rng = (ids >= lo[:, None]) & (ids < hi[:, None])
+    mask = torch.where(lo[:, None] < 0, first_mask[None, :].bool().expand_as(rng), rng)
+    probs.copy_(p * mask)
+    return probs
+
+
+_NAMES = [n for n, f in list(globals().items()) if callable(f) and not n.startswith("_") and n not in
+          ("contextlib", "math", "torch", "F", "install", "round_up")]
+
+
+@contextlib.contextmanager
+def install():
+    """Patch midi_model_amd.ops with the CPU stand-ins and lift the device check of MIDIModel."""
+    import midi_model_amd.ops as real
+    import midi_model_amd.model as model
+    saved = {n: getattr(real, n) for n in _NAMES if hasattr(real, n)}
+    missing = [n for n in dir(real) if not n.startswith("_") and callable(getattr(real, n)) and n not in saved
+               and n not in ("lib", "dt", "round_up", "Optional")]
+    assert not missing, f"emulator lacks stand-ins for {missing}"
+    req = model.MIDIModel._require_gpu
+    try:
+        for n in saved:
+            setattr(real, n, globals()[n])
+        model.MIDIModel._require_gpu = lambda self: None
+        yield
+    finally:
+        for n, f in saved.items():
+            setattr(real, n, f)
+        model.MIDIModel._require_gpu = req

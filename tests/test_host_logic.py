@@ -1,0 +1,212 @@
+"""Host-side logic on CPU: the kernel schedules (engine.py), the flat parameter layout, the autograd nodes,
+the fused training step + optimiser, the KV-cached decode loop and generate(), all driven through the
+test-only fake backend (tests/emu_ops.py) and checked against the reference-generated golden vectors.
+The same checks run on the real HIP kernels in test_model_gpu.py."""
+import numpy as np
+import pytest
+import torch
+
+import midi_model_amd as mm
+from midi_model_amd.train import TrainMIDIModel, lr_lambda
+
+import emu_ops
+
+
+def tiny_config():
+    return mm.MIDIModelConfig.get_config("v2", True, 4, 4, 256, 512)
+
+
+@pytest.fixture(scope="module")
+def tok():
+    return mm.MIDITokenizerV2()
+
+
+@pytest.fixture()
+def tiny(orc, tok):
+    shp = orc.Shape(n_layer=4, n_head=4, n_embd=256, n_inner=512, vocab=tok.vocab_size)
+    sd = orc.make_state_dict(shp, seed=1)
+    batch = orc.synthetic_events(tok, 2, 17, seed=2)
+    batch[1, 14:] = tok.pad_id
+    return shp, sd, batch
+
+
+def test_state_dict_surface(golden):
+    g = golden("medium_forward.npz")
+    model = mm.MIDIModel(mm.MIDIModelConfig.from_name("tv2o-medium"))
+    keys = list(model.state_dict().keys())
+    assert set(keys) == set(str(k) for k in g["state_dict_keys"]) and len(keys) == 140
+    assert sum(p.numel() for p in model.parameters()) == int(g["n_params"])
+    # parameters are views of ONE flat buffer; q|k|v and gate|up are adjacent
+    q, k = model.net.layers[0].self_attn.q_proj.weight, model.net.layers[0].self_attn.k_proj.weight
+    assert k.data_ptr() == q.data_ptr() + q.numel() * q.element_size()
+    g_, u = model.net.layers[3].mlp.gate_proj.weight, model.net.layers[3].mlp.up_proj.weight
+    assert u.data_ptr() == g_.data_ptr() + g_.numel() * g_.element_size()
+    assert model.net.embed_tokens.weight[0].abs().max() == 0  # pad row
+    # .to() keeps the layout, load_state_dict writes through
+    model = model.to(torch.bfloat16)
+    assert model.dtype == torch.bfloat16 and model.lm_head.weight.dtype == torch.bfloat16
+    w = model.net_token.layers[2].mlp.down_proj.weight
+    assert model._flat.data_ptr() <= w.data_ptr() < model._flat.data_ptr() + model._flat.numel() * 2
+
+
+def test_no_cpu_compute_path():
+    model = mm.MIDIModel(tiny_config())
+    with pytest.raises(RuntimeError, match="ROCm device"):
+        model.forward(torch.zeros((1, 2, 8), dtype=torch.long))
+    with pytest.raises(ValueError):
+        with emu_ops.install():
+            model.generate(np.zeros((3, 2, 8), dtype=np.int64), batch_size=2, max_len=4)
+
+
+def test_api_path_forward_backward(orc, tiny, golden):
+    shp, sd, batch = tiny
+    g = golden("tiny_train.npz")
+    with emu_ops.install():
+        model = mm.MIDIModel(tiny_config())
+        model.load_state_dict(sd, strict=True)
+        x, y = batch[:, :-1].contiguous(), batch[:, 1:].contiguous()
+        hidden = model.forward(x)
+        np.testing.assert_allclose(hidden.detach().numpy(), g["hidden"], rtol=1e-4, atol=3e-5)
+        h2 = hidden.reshape(-1, hidden.shape[-1])
+        y2 = y.reshape(-1, y.shape[-1])
+        logits = model.forward_token(h2, y2[:, :-1])
+        loss = torch.nn.functional.cross_entropy(logits.reshape(-1, model.tokenizer.vocab_size), y2.reshape(-1),
+                                                 reduction="mean", ignore_index=model.tokenizer.pad_id)
+        loss.backward()
+    assert abs(loss.item() - float(g["loss"])) < 3e-5
+    np.testing.assert_allclose(logits.detach()[:, :, ::16].numpy(), g["logits_sub"], rtol=1e-3, atol=3e-5)
+    named = dict(model.named_parameters())
+    names = [str(n) for n in g["grad_names"]]
+    norms = np.array([named[n].grad.norm().item() for n in names])
+    np.testing.assert_allclose(norms, g["grad_norms"], rtol=5e-4, atol=1e-7)
+
+
+def test_cached_forward_matches_reference(tiny, golden):
+    shp, sd, batch = tiny
+    g = golden("tiny_train.npz")
+
+    class AnyCache:  # forward() accepts whatever cache object the caller made (HF DynamicCache in app.py)
+        pass
+
+    with emu_ops.install(), torch.no_grad():
+        model = mm.MIDIModel(tiny_config())
+        model.load_state_dict(sd)
+        x = batch[:, :-1]
+        c = AnyCache()
+        ha = model.forward(x[:, :11], cache=c)
+        hb = model.forward(x[:, 11:], cache=c)
+        h = torch.cat([ha, hb], 1)
+    np.testing.assert_allclose(h.numpy(), g["hidden_cached"], rtol=1e-4, atol=3e-5)
+
+
+def test_fused_step_grads_and_optimizer(orc, tiny, golden, tok):
+    shp, sd, batch = tiny
+    g = golden("tiny_train.npz")
+    with emu_ops.install():
+        model = TrainMIDIModel(tiny_config(), lr=1e-2, warmup=2, max_step=10, accumulate_grad_batches=1)
+        model.load_state_dict(sd)
+        loss = model.training_step(batch)
+        assert abs(loss.item() - float(g["loss"])) < 3e-5
+        named = dict(model.named_parameters())
+        names = [str(n) for n in g["grad_names"]]
+        norms = np.array([named[n].grad.norm().item() for n in names])
+        np.testing.assert_allclose(norms, g["grad_norms"], rtol=5e-4, atol=1e-7)
+        for key in g.files:
+            if key.startswith("grad:"):
+                gr = named[key[5:]].grad
+                got = gr.numpy() if gr.dim() == 1 else gr[:64:3, ::5].numpy()
+                np.testing.assert_allclose(got, g[key], rtol=2e-3, atol=2e-7)
+        vloss, acc = model.validation_step(batch)
+        assert abs(vloss.item() - float(g["loss"])) < 3e-5 and abs(acc.item() - float(g["acc"])) < 1e-6
+
+        # three optimiser steps against the reference's torch.optim.AdamW + clip_grad_norm_ + LambdaLR
+        model = TrainMIDIModel(tiny_config(), lr=1e-2, warmup=2, max_step=10, accumulate_grad_batches=1)
+        model.load_state_dict(sd)
+        losses, gn, lrs = [], [], []
+        for step in range(3):
+            b = orc.synthetic_events(tok, 2, 17, seed=10 + step)
+            lrs.append(model.current_lr())
+            losses.append(model.fit_step(b).item())
+            gn.append(model.last_grad_norm.item())
+        np.testing.assert_allclose(losses, g["opt_losses"], rtol=5e-5)
+        np.testing.assert_allclose(gn, g["opt_gnorms"], rtol=5e-4)
+        np.testing.assert_allclose(lrs, g["opt_lrs"], rtol=1e-12)
+        named = dict(model.named_parameters())
+        pn = np.array([named[n].detach().norm().item() for n in names])
+        np.testing.assert_allclose(pn, g["opt_param_norms"], rtol=2e-5)
+        for key in g.files:
+            if key.startswith("opt:"):
+                p = named[key[4:]].detach()
+                got = p.numpy() if p.dim() == 1 else p[:64:3, ::5].numpy()
+                np.testing.assert_allclose(got, g[key], rtol=2e-4, atol=2e-6)
+
+
+def test_grad_accumulation_sums_micro_batches(orc, tiny, tok):
+    """accumulate_grad_batches=2: the second micro-batch ADDS to the first one's gradients (each micro-batch
+    loss is its own token mean, as under Lightning), and only then the optimiser runs."""
+    shp, sd, _ = tiny
+    b = orc.synthetic_events(tok, 4, 9, seed=21)
+    with emu_ops.install():
+        singles = []
+        for half in (b[:2], b[2:]):
+            m1 = TrainMIDIModel(tiny_config(), accumulate_grad_batches=1)
+            m1.load_state_dict(sd)
+            m1.training_step(half)
+            singles.append(m1.grad_buffer().clone())
+        m2 = TrainMIDIModel(tiny_config(), accumulate_grad_batches=2, lr=1e-2, warmup=0)
+        m2.load_state_dict(sd)
+        before = m2._flat.clone()
+        m2.fit_step(b[:2])
+        assert torch.equal(m2._flat, before) and m2.global_step == 0  # no optimiser step inside the window
+        m2.training_step(b[2:])
+        g2 = m2.grad_buffer().clone()
+        m2.optimizer_step()
+        assert m2.global_step == 1 and not torch.equal(m2._flat, before)
+    np.testing.assert_allclose(g2.numpy(), (singles[0] + singles[1]).numpy(), rtol=1e-4, atol=1e-7)
+
+
+def test_generate_matches_reference(tiny, golden, tok):
+    shp, sd, _ = tiny
+    g = golden("tiny_generate.npz")
+    with emu_ops.install():
+        model = mm.MIDIModel(tiny_config())
+        model.load_state_dict(sd)
+        out = model.generate(None, batch_size=3, max_len=14, generator=torch.Generator().manual_seed(1234))
+        assert out.shape == g["sampled_b3"].shape and (out == g["sampled_b3"]).all()
+        out = model.generate(None, batch_size=2, max_len=14, top_k=1, generator=torch.Generator().manual_seed(0))
+        assert (out == g["greedy_b2"]).all()
+        out = model.generate(g["prompt"], batch_size=2, max_len=12, temp=0.9, top_p=0.9, top_k=8,
+                             generator=torch.Generator().manual_seed(77))
+        assert (out == g["prompt_b2"]).all()
+        pr = torch.softmax(3.0 * torch.randn((4, 1, tok.vocab_size), generator=torch.Generator().manual_seed(3)), -1)
+        s = model.sample_top_p_k(pr, 0.9, 12, generator=torch.Generator().manual_seed(9))
+        assert (s.numpy() == g["sampler_out"]).all()
+        # ban_eos: every row runs to max_len and never emits EOS as an event id
+        out = model.generate(None, batch_size=2, max_len=10, generator=torch.Generator().manual_seed(5), ban_eos=True)
+        assert out.shape == (2, 10, 8) and (out[:, 1:, 0] != tok.eos_id).all()
+
+
+def test_forward_token_decode_path(tiny, orc):
+    """the reference calling convention of the inner loop: hidden first, then one token id at a time"""
+    shp, sd, batch = tiny
+
+    class C:
+        pass
+
+    with emu_ops.install(), torch.no_grad():
+        model = mm.MIDIModel(tiny_config())
+        model.load_state_dict(sd)
+        hid = torch.randn(3, 256, generator=torch.Generator().manual_seed(0))
+        toks = batch[0, 1:4, :4].contiguous()  # (3, 4) ids
+        c = C()
+        outs = [model.forward_token(hid, None, cache=c)]
+        for j in range(4):
+            outs.append(model.forward_token(None, toks[:, j:j + 1], cache=c))
+        got = torch.cat(outs, 1)
+    want = orc.midi_forward_token(sd, shp, hid, toks)
+    np.testing.assert_allclose(got.numpy(), want.numpy(), rtol=1e-3, atol=3e-5)
+
+
+def test_lr_schedule():
+    assert lr_lambda(0, 1000, 1e6) == 0.0 and lr_lambda(500, 1000, 1e6) == 0.5
+    assert lr_lambda(1000, 1000, 1e6) == 1.0 and lr_lambda(10 ** 6, 1000, 1e6) == 0.0
