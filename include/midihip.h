@@ -37,10 +37,13 @@ int mh_version(void);
  * Replaces every nn.Linear of the path: q/k/v/o_proj (TF:models/llama/modeling_llama.py:254-256,280),
  * gate/up/down_proj (:174-176), lm_head (midi_model.py:107,135) and their autograd dgrad/wgrad.
  * K, lda, ldb must be multiples of 16 bytes worth of elements; M, N arbitrary.
- * `splitk` > 1 splits the contraction over grid.z and needs `workspace` of splitk*M*N floats.      */
+ * `splitk` > 1 splits the contraction over grid.z: the kernel then only stores fp32 partial products in
+ * `workspace` (splitk*M*N floats) and mh_gemm_splitk_reduce folds them into C (applying alpha/beta/R).   */
 int mh_gemm_nt(const void* A, int64_t lda, const void* B, int64_t ldb, void* C, int64_t ldc, const void* R,
                int64_t ldr, int64_t M, int64_t N, int64_t K, float alpha, float beta, int dtype, int splitk,
                void* workspace, void* stream);
+int mh_gemm_splitk_reduce(const void* workspace, void* C, int64_t ldc, const void* R, int64_t ldr, int64_t M,
+                          int64_t N, int splitk, float alpha, float beta, int dtype, void* stream);
 /* out[C,R] = in[R,C]^T (operand re-layout for dgrad/wgrad). */
 int mh_transpose(const void* in, int64_t ldi, void* out, int64_t ldo, int64_t rows, int64_t cols, int dtype,
                  void* stream);

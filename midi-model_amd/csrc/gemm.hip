@@ -202,22 +202,36 @@ static int gemm_launch(const void* A, int64_t lda, const void* B, int64_t ldb, v
   const int64_t tiles_m = (M + BM - 1) / BM, tiles_n = (N + BN - 1) / BN;
   MH_REQUIRE(tiles_m * tiles_n < (1ll << 30), "gemm: too many tiles");
   if (splitk < 1) splitk = 1;
-  int64_t kps = ((K + splitk - 1) / splitk + BK - 1) / BK * BK;
-  splitk = (int)((K + kps - 1) / kps);
+  // every z-slice gets a BK-aligned k range; slices past K (possible after the rounding) store zero partials
+  const int64_t kps = ((K + splitk - 1) / splitk + BK - 1) / BK * BK;
   MH_REQUIRE(splitk == 1 || workspace != nullptr, "gemm: split-K needs a workspace");
   const int nwg = (int)(tiles_m * tiles_n);
   dim3 grid(nwg, 1, splitk);
   gemm_nt_kernel<T><<<grid, 256, 0, st>>>((const T*)A, lda, (const T*)B, ldb, (T*)C, ldc, (const T*)R, ldr, M, N, K,
                                             alpha, beta, (int)tiles_n, nwg, kps, (float*)workspace);
   MH_LAUNCH_CHECK();
-  if (splitk > 1) {
-    int64_t total = M * N;
-    int blocks = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
-    splitk_reduce_kernel<T><<<blocks, 256, 0, st>>>((const float*)workspace, (T*)C, ldc, (const T*)R, ldr, M, N,
-                                                    splitk, alpha, beta);
-    MH_LAUNCH_CHECK();
-  }
   return MH_OK;
+}
+
+template <typename T>
+static int splitk_reduce_launch(const void* workspace, void* C, int64_t ldc, const void* R, int64_t ldr, int64_t M,
+                                int64_t N, int splitk, float alpha, float beta, hipStream_t st) {
+  MH_REQUIRE(M > 0 && N > 0 && splitk >= 1 && workspace != nullptr, "splitk_reduce: bad args");
+  const int64_t total = M * N;
+  const int blocks = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
+  splitk_reduce_kernel<T><<<blocks, 256, 0, st>>>((const float*)workspace, (T*)C, ldc, (const T*)R, ldr, M, N, splitk,
+                                                  alpha, beta);
+  MH_LAUNCH_CHECK();
+  return MH_OK;
+}
+
+extern "C" int mh_gemm_splitk_reduce(const void* workspace, void* C, int64_t ldc, const void* R, int64_t ldr, int64_t M,
+                                     int64_t N, int splitk, float alpha, float beta, int dtype, void* stream) {
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == MH_BF16) return splitk_reduce_launch<bf16>(workspace, C, ldc, R, ldr, M, N, splitk, alpha, beta, st);
+  if (dtype == MH_F32) return splitk_reduce_launch<float>(workspace, C, ldc, R, ldr, M, N, splitk, alpha, beta, st);
+  mh_set_error("splitk_reduce: bad dtype %d", dtype);
+  return MH_ERR_ARG;
 }
 
 extern "C" int mh_gemm_nt(const void* A, int64_t lda, const void* B, int64_t ldb, void* C, int64_t ldc,

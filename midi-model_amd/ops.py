@@ -64,9 +64,22 @@ def gemm_nt(a: torch.Tensor, b: torch.Tensor, out: torch.Tensor, *, K: Optional[
     ws = None
     if splitk > 1:
         ws = torch.empty((splitk, M, N), dtype=torch.float32, device=out.device)
+    prof = gemm_profile
+    if prof is not None:  # bench.py: HIP events on the launch stream around every projection GEMM
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
     lib().call("mh_gemm_nt", _p(a), _rowmajor(a), _p(b), _rowmajor(b), _p(out), _rowmajor(out), _p(res),
                _rowmajor(res) if res is not None else 0, M, N, K, alpha, beta, dt(out), splitk, _p(ws), _stream())
+    if prof is not None:
+        e1.record()
+        prof.append((e0, e1, 2.0 * M * N * K, (M, N, K, splitk)))
+    if splitk > 1:
+        lib().call("mh_gemm_splitk_reduce", _p(ws), _p(out), _rowmajor(out), _p(res),
+                   _rowmajor(res) if res is not None else 0, M, N, splitk, alpha, beta, dt(out), _stream())
     return out
+
+
+gemm_profile = None  # set to a list to collect (start_event, end_event, flops, shape) per GEMM launch
 
 
 def transpose(x: torch.Tensor, out: Optional[torch.Tensor] = None, pad_to: int = 8) -> torch.Tensor:

@@ -1,0 +1,337 @@
+"""Per-kernel parity on the MI355X: every C-ABI entry point (through midi_model_amd.ops -> libmidihip.so)
+against the CPU restatement of the same op (tests/emu_ops.py) on identical seeded inputs, in fp32
+(verification mode, tight tolerance) and bf16 (production mode, inputs pre-rounded to bf16 so the check
+measures the kernel and not the input rounding).  Shapes cover ragged / non-multiple-of-tile sizes, single
+rows, padding and ignore-index edge cases."""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+import emu_ops as emu
+
+pytestmark = pytest.mark.gpu
+
+DTYPES = [torch.float32, torch.bfloat16]
+
+
+def tol(dtype, k=1.0):
+    return (dict(rtol=2e-4 * k, atol=2e-5 * k) if dtype == torch.float32 else dict(rtol=2e-2 * k, atol=2e-2 * k))
+
+
+@pytest.fixture(scope="module")
+def ops():
+    import midi_model_amd.ops as real
+    return real
+
+
+def rnd(shape, dtype, seed, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return (scale * torch.randn(shape, generator=g)).to(dtype)
+
+
+def cmp(got, want, dtype, k=1.0, what=""):
+    got, want = got.detach().float().cpu(), want.detach().float().cpu()
+    assert got.shape == want.shape, (what, got.shape, want.shape)
+    assert torch.isfinite(got).all(), f"{what}: non-finite output"
+    t = tol(dtype, k)
+    err = (got - want).abs()
+    bad = err > (t["atol"] + t["rtol"] * want.abs())
+    assert not bad.any(), (f"{what}: {int(bad.sum())}/{bad.numel()} off, max abs err {err.max().item():.3e} "
+                           f"(ref max {want.abs().max().item():.3e}), first bad idx {bad.nonzero()[0].tolist()}")
+
+
+# ------------------------------------------------------------------------------------------------ GEMM
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("M,N,K", [(128, 128, 64), (256, 384, 256), (257, 200, 96), (1, 1024, 1024), (1000, 72, 8),
+                                   (64, 3406, 256), (640, 1024, 4096)])
+def test_gemm_nt(ops, dtype, M, N, K):
+    a, b = rnd((M, K), dtype, 1), rnd((N, K), dtype, 2)
+    want = emu.gemm_nt(a, b, torch.empty((M, N), dtype=dtype))
+    out = torch.full((M, N), float("nan"), dtype=dtype, device="cuda")
+    ops.gemm_nt(a.cuda(), b.cuda(), out)
+    cmp(out, want, dtype, k=max(1.0, math.sqrt(K / 256)), what=f"gemm {M}x{N}x{K}")
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_gemm_epilogue_views_splitk(ops, dtype):
+    M, N, K = 300, 520, 2048 + 64
+    a, b, r = rnd((M, K), dtype, 3), rnd((N, K), dtype, 4), rnd((M, N), dtype, 5)
+    # residual epilogue into a separate buffer
+    want = emu.gemm_nt(a, b, torch.empty((M, N), dtype=dtype), beta=1.0, res=r, alpha=0.5)
+    out = torch.empty((M, N), dtype=dtype, device="cuda")
+    ops.gemm_nt(a.cuda(), b.cuda(), out, beta=1.0, res=r.cuda(), alpha=0.5)
+    cmp(out, want, dtype, k=4, what="gemm residual")
+    # accumulate in place + forced split-K
+    acc = r.clone().cuda()
+    ops.gemm_nt(a.cuda(), b.cuda(), acc, beta=1.0, splitk=5)
+    cmp(acc, emu.gemm_nt(a, b, r.clone(), beta=1.0), dtype, k=4, what="gemm split-K accumulate")
+    # output is a narrowed view of a padded buffer (the logits layout), K limited by the argument
+    buf = torch.zeros((M, 576), dtype=dtype, device="cuda")
+    ops.gemm_nt(a.cuda(), b.cuda(), buf[:, :N], K=1024)
+    cmp(buf[:, :N], emu.gemm_nt(a, b, torch.empty((M, N), dtype=dtype), K=1024), dtype, k=3, what="gemm view")
+    assert (buf[:, N:] == 0).all()
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("R,C", [(64, 64), (100, 37), (1000, 1024), (8, 3406)])
+def test_transpose(ops, dtype, R, C):
+    x = rnd((R, C), dtype, 6)
+    out = ops.transpose(x.cuda())
+    assert out.shape == (C, (R + 7) // 8 * 8)
+    assert torch.equal(out[:, :R].cpu(), x.T) and (out[:, R:] == 0).all()
+
+
+# ------------------------------------------------------------------------------------------ embeddings
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_embeddings(ops, dtype):
+    V, D, M, T = 3406, 256, 77, 8
+    g = torch.Generator().manual_seed(7)
+    table = rnd((V, D), dtype, 8)
+    tok = torch.randint(0, V, (M, T), generator=g)
+    tok[3] = 0
+    out = torch.empty((M, D), dtype=dtype, device="cuda")
+    ops.embed_sum_fwd(tok.cuda(), table.cuda(), out)
+    cmp(out, emu.embed_sum_fwd(tok, table, torch.empty((M, D), dtype=dtype)), dtype, what="embed_sum")
+    hid = rnd((M, D), dtype, 9)
+    seq = torch.empty((M, T, D), dtype=dtype, device="cuda")
+    ops.concat_tok_fwd(hid.cuda(), tok.cuda(), table.cuda(), seq, T)
+    assert torch.equal(seq.cpu(), emu.concat_tok_fwd(hid, tok, table, torch.empty((M, T, D), dtype=dtype), T))
+    # scatter backward, both addressing modes, pad rows skipped
+    d1 = rnd((M, D), dtype, 10)
+    acc, ref = torch.zeros((V, D), device="cuda"), torch.zeros((V, D))
+    ops.embed_scatter_bwd(tok.cuda(), T, d1.cuda(), 1, 0, 0, acc, 0)
+    emu.embed_scatter_bwd(tok, T, d1, 1, 0, 0, ref, 0)
+    cmp(acc, ref, torch.float32, k=10, what="scatter (event)")
+    assert acc[0].abs().max() == 0
+    d2 = rnd((M, T, D), dtype, 11)
+    acc.zero_(); ref.zero_()
+    ops.embed_scatter_bwd(tok[:, :7].cuda(), 7, d2.cuda(), T, 1, 1, acc, 0)
+    emu.embed_scatter_bwd(tok[:, :7], 7, d2, T, 1, 1, ref, 0)
+    cmp(acc, ref, torch.float32, k=10, what="scatter (token)")
+    dst = rnd((V, D), dtype, 12)
+    dst_g = dst.clone().cuda()
+    ops.cast_from_f32(acc, dst_g, True)
+    emu.cast_from_f32(ref, dst, True)
+    cmp(dst_g, dst, dtype, what="cast_from_f32")
+    rows = torch.empty((M, D), dtype=dtype, device="cuda")
+    ops.copy_rows(d2.cuda(), T * D, rows, D, M, D)
+    assert torch.equal(rows.cpu(), d2[:, 0])
+
+
+# --------------------------------------------------------------------------------------------- RMSNorm
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("M,D", [(1, 256), (37, 1024), (1000, 1024), (5000, 256)])
+def test_rmsnorm(ops, dtype, M, D):
+    x, w, dy, dres = rnd((M, D), dtype, 13, 2.0), (1 + 0.1 * rnd((D,), torch.float32, 14)).to(dtype), rnd((M, D), dtype, 15), rnd((M, D), dtype, 16)
+    y, rstd = torch.empty((M, D), dtype=dtype), torch.empty(M)
+    emu.rmsnorm_fwd(x, w, y, rstd, 1e-6)
+    yg, rg = torch.empty((M, D), dtype=dtype, device="cuda"), torch.empty(M, device="cuda")
+    ops.rmsnorm_fwd(x.cuda(), w.cuda(), yg, rg, 1e-6)
+    cmp(yg, y, dtype, what="rmsnorm y")
+    cmp(rg, rstd, torch.float32, what="rmsnorm rstd")
+    dx, dw = torch.empty((M, D), dtype=dtype), torch.zeros(D, dtype=dtype)
+    emu.rmsnorm_bwd(x, w, rstd, dy, dres, dx, dw, False)
+    dxg, dwg = torch.empty((M, D), dtype=dtype, device="cuda"), torch.zeros(D, dtype=dtype, device="cuda")
+    ops.rmsnorm_bwd(x.cuda(), w.cuda(), rg, dy.cuda(), dres.cuda(), dxg, dwg, False)
+    cmp(dxg, dx, dtype, k=2, what="rmsnorm dx")
+    cmp(dwg, dw, dtype, k=max(2.0, math.sqrt(M) / 4), what="rmsnorm dw")
+    ops.rmsnorm_bwd(x.cuda(), w.cuda(), rg, dy.cuda(), None, dxg, dwg, True)  # no residual, accumulate dw
+    emu.rmsnorm_bwd(x, w, rstd, dy, None, dx, dw, True)
+    cmp(dxg, dx, dtype, k=2, what="rmsnorm dx (no res)")
+    cmp(dwg, dw, dtype, k=max(3.0, math.sqrt(M) / 3), what="rmsnorm dw (acc)")
+
+
+# ------------------------------------------------------------------------------------------------ RoPE
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("H,hd,S,M", [(4, 64, 10, 30), (1, 256, 8, 64), (16, 64, 33, 33)])
+def test_rope(ops, dtype, H, hd, S, M):
+    from midi_model_amd.engine import RopeTable
+    tab = RopeTable(hd, 10000.0, "cuda", 64)
+    qkv = rnd((M, 3 * H * hd), dtype, 17)
+    for direction, pos0 in ((1, 0), (-1, 0), (1, 5)):
+        want = emu.rope_(qkv.clone(), tab.cos.cpu(), tab.sin.cpu(), S, pos0, H, hd, direction)
+        got = ops.rope_(qkv.clone().cuda(), tab.cos, tab.sin, S, pos0, H, hd, direction)
+        cmp(got, want, dtype, what=f"rope dir={direction} pos0={pos0}")
+        assert torch.equal(got[:, 2 * H * hd:].cpu(), qkv[:, 2 * H * hd:])  # v untouched
+
+
+# ------------------------------------------------------------------------------ event-level attention
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("B,S,H", [(1, 1, 1), (2, 33, 3), (1, 64, 2), (2, 128, 1), (1, 200, 4), (1, 515, 2)])
+def test_attention_fwd_bwd(ops, dtype, B, S, H):
+    D = H * 64
+    scale = 64 ** -0.5
+    qkv = rnd((B * S, 3 * D), dtype, 18)
+    do = rnd((B * S, D), dtype, 19)
+    Sp = (S + 63) // 64 * 64
+    o_ref, lse_ref = torch.empty((B * S, D), dtype=dtype), torch.zeros(B * H * Sp)
+    emu.attn_fwd(qkv, o_ref, lse_ref, B, S, H, scale)
+    o, lse = torch.empty((B * S, D), dtype=dtype, device="cuda"), torch.zeros(B * H * Sp, device="cuda")
+    ops.attn_fwd(qkv.cuda(), o, lse, B, S, H, scale)
+    cmp(o, o_ref, dtype, what="attn o")
+    cmp(lse.view(B, H, Sp)[:, :, :S], lse_ref.view(B, H, Sp)[:, :, :S], torch.float32, k=(1 if dtype == torch.float32 else 50), what="attn lse")
+    dq_ref = torch.empty((B * S, 3 * D), dtype=dtype)
+    emu.attn_bwd(qkv, o_ref, do, lse_ref, dq_ref, B, S, H, scale)
+    dqkv = torch.full((B * S, 3 * D), float("nan"), dtype=dtype, device="cuda")
+    ops.attn_bwd(qkv.cuda(), o, do.cuda(), lse, dqkv, B, S, H, scale)
+    for i, nm in enumerate(("dq", "dk", "dv")):
+        cmp(dqkv[:, i * D:(i + 1) * D], dq_ref[:, i * D:(i + 1) * D], dtype, k=3, what=f"attn {nm}")
+
+
+def test_attention_mfma_vs_plain_on_device(ops):
+    """bf16: the MFMA flash kernels against the thread-per-row kernels running on the same device data."""
+    from midi_model_amd.lib import lib
+    B, S, H = 2, 300, 2
+    D, Sp = H * 64, 320
+    scale = 0.125
+    qkv = rnd((B * S, 3 * D), torch.bfloat16, 20).cuda()
+    do = rnd((B * S, D), torch.bfloat16, 21).cuda()
+    o, lse = torch.empty((B * S, D), dtype=torch.bfloat16, device="cuda"), torch.zeros(B * H * Sp, device="cuda")
+    ops.attn_fwd(qkv, o, lse, B, S, H, scale)
+    o2, lse2 = torch.empty_like(o), torch.zeros_like(lse)
+    st = torch.cuda.current_stream().cuda_stream
+    lib().call("mh_attn_fwd_plain", qkv.data_ptr(), o2.data_ptr(), lse2.data_ptr(), B, S, H, scale, 1, st)
+    cmp(o, o2, torch.bfloat16, what="mfma vs plain o")
+    dq = torch.empty((B * S, 3 * D), dtype=torch.bfloat16, device="cuda")
+    ops.attn_bwd(qkv, o, do, lse, dq, B, S, H, scale)
+    dq2 = torch.empty_like(dq)
+    delta = torch.zeros(B * H * Sp, device="cuda")
+    # delta = rowsum(dO*O) per head, laid out [B,H,Sp]
+    d_ = (do.float() * o2.float()).view(B, S, H, 64).sum(-1).permute(0, 2, 1)
+    delta.view(B, H, Sp)[:, :, :S] = d_
+    lib().call("mh_attn_bwd_plain", qkv.data_ptr(), do.data_ptr(), lse2.data_ptr(), delta.data_ptr(), dq2.data_ptr(), B, S, H, scale, 1, st)
+    cmp(dq, dq2, torch.bfloat16, k=2, what="mfma vs plain dqkv")
+
+
+# ------------------------------------------------------------------------------ token-level attention
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("N,T,H", [(1, 8, 1), (37, 8, 4), (10, 5, 2), (3, 1, 4)])
+def test_tokattn(ops, dtype, N, T, H):
+    D = H * 256
+    scale = 256 ** -0.5
+    qkv, do = rnd((N * T, 3 * D), dtype, 22), rnd((N * T, D), dtype, 23)
+    o_ref, dq_ref = torch.empty((N * T, D), dtype=dtype), torch.empty((N * T, 3 * D), dtype=dtype)
+    emu.tokattn_fwd(qkv, o_ref, N, T, H, scale)
+    emu.tokattn_bwd(qkv, do, dq_ref, N, T, H, scale)
+    o = torch.empty((N * T, D), dtype=dtype, device="cuda")
+    dq = torch.empty((N * T, 3 * D), dtype=dtype, device="cuda")
+    ops.tokattn_fwd(qkv.cuda(), o, N, T, H, scale)
+    ops.tokattn_bwd(qkv.cuda(), do.cuda(), dq, N, T, H, scale)
+    cmp(o, o_ref, dtype, what="tokattn o")
+    cmp(dq, dq_ref, dtype, k=2, what="tokattn dqkv")
+
+
+# ----------------------------------------------------------------------------------------------- SwiGLU
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_swiglu(ops, dtype):
+    M, I = 333, 1024
+    gu, da = rnd((M, 2 * I), dtype, 24, 2.0), rnd((M, I), dtype, 25)
+    a_ref, d_ref = torch.empty((M, I), dtype=dtype), torch.empty((M, 2 * I), dtype=dtype)
+    emu.swiglu_fwd(gu, a_ref)
+    emu.swiglu_bwd(gu, da, d_ref)
+    a, d = torch.empty((M, I), dtype=dtype, device="cuda"), torch.empty((M, 2 * I), dtype=dtype, device="cuda")
+    ops.swiglu_fwd(gu.cuda(), a)
+    ops.swiglu_bwd(gu.cuda(), da.cuda(), d)
+    cmp(a, a_ref, dtype, what="swiglu a")
+    cmp(d, d_ref, dtype, what="swiglu dgu")
+
+
+# ------------------------------------------------------------------------------------- loss, optimiser
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_cross_entropy(ops, dtype):
+    R, V, Vp = 531, 3406, 3456
+    g = torch.Generator().manual_seed(26)
+    logits = torch.zeros((R, Vp), dtype=dtype)
+    logits[:, :V] = rnd((R, V), dtype, 27, 3.0)
+    logits[:, V:] = 77.0  # garbage in the padding columns must be ignored
+    tgt = torch.randint(1, V, (R,), generator=g)
+    tgt[::5] = 0
+    inv = torch.tensor([1.0 / float((tgt != 0).sum())])
+    rl_ref, dl_ref, am_ref = torch.empty(R), torch.empty((R, Vp), dtype=dtype), torch.empty(R, dtype=torch.long)
+    emu.cross_entropy(logits, V, tgt, rl_ref, dl_ref, inv, am_ref, 0)
+    lg = logits.clone().cuda()
+    rl, am = torch.empty(R, device="cuda"), torch.empty(R, dtype=torch.long, device="cuda")
+    ops.cross_entropy(lg, V, tgt.cuda(), rl, lg, inv.cuda(), am, 0)  # gradient written in place
+    cmp(rl, rl_ref, torch.float32, k=(1 if dtype == torch.float32 else 5), what="ce row loss")
+    assert torch.equal(am.cpu(), am_ref)
+    cmp(lg, dl_ref, dtype, k=0.05, what="ce dlogits")
+    assert (lg[:, V:] == 0).all() and (lg[::5] == 0).all()
+    s = torch.empty(1, device="cuda")
+    ops.sum_f32(rl, s)
+    assert abs(s.item() - rl_ref.sum().item()) < 1e-2
+    cnt, iv = torch.empty(1, device="cuda"), torch.empty(1, device="cuda")
+    ops.count_valid(tgt.cuda(), 0, cnt, iv)
+    assert cnt.item() == float((tgt != 0).sum()) and abs(iv.item() - inv.item()) < 1e-9
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_clip_and_adamw(ops, dtype):
+    n = 100003 * 8
+    p, g = rnd((n,), dtype, 28, 0.02), rnd((n,), dtype, 29, 0.01)
+    m, v = rnd((n,), dtype, 30, 0.001), rnd((n,), dtype, 31, 0.001).abs()
+    ss, part, coef, norm = (torch.zeros(1, device="cuda"), torch.empty(1024, device="cuda"),
+                            torch.empty(1, device="cuda"), torch.empty(1, device="cuda"))
+    ops.sumsq(g.cuda(), part, ss, False)
+    want = g.float().pow(2).sum().item()
+    assert abs(ss.item() - want) / want < 1e-5
+    ops.clip_coef(ss, 1.0, coef, norm)
+    assert abs(norm.item() - math.sqrt(want)) / math.sqrt(want) < 1e-5
+    assert abs(coef.item() - min(1.0, 1.0 / (math.sqrt(want) + 1e-6))) < 1e-6
+    args = (3e-3, 0.9, 0.99, 1e-8, 0.01, 1 - 0.9 ** 3, 1 - 0.99 ** 3)
+    pr, mr, vr = p.clone(), m.clone(), v.clone()
+    emu.adamw(pr, g, mr, vr, *args, coef.cpu())
+    pg, mg, vg = p.clone().cuda(), m.clone().cuda(), v.clone().cuda()
+    ops.adamw(pg, g.cuda(), mg, vg, *args, coef)
+    k = 1 if dtype == torch.float32 else 0.5
+    cmp(pg, pr, dtype, k=k, what="adamw p")
+    cmp(mg, mr, dtype, k=k, what="adamw m")
+    cmp(vg, vr, dtype, k=k, what="adamw v")
+
+
+# ----------------------------------------------------------------------------------------------- decode
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("H,hd,Lmax,length", [(16, 64, 128, 1), (16, 64, 128, 100), (4, 256, 8, 1), (4, 256, 8, 7), (2, 64, 1100, 1031)])
+def test_decode_attention_and_cache(ops, dtype, H, hd, Lmax, length):
+    from midi_model_amd.engine import RopeTable
+    B, D = 3, H * hd
+    tab = RopeTable(hd, 10000.0, "cuda", Lmax + 1)
+    kc, vc = rnd((B, H, Lmax, hd), dtype, 32), rnd((B, H, Lmax, hd), dtype, 33)
+    qkv = rnd((B, 3 * D), dtype, 34)
+    pos = length - 1
+    kc_r, vc_r, q_r = kc.clone(), vc.clone(), qkv.clone()
+    emu.kv_append(q_r, tab.cos.cpu(), tab.sin.cpu(), kc_r, vc_r, B, H, hd, Lmax, pos)
+    kc_g, vc_g, q_g = kc.clone().cuda(), vc.clone().cuda(), qkv.clone().cuda()
+    ops.kv_append(q_g, tab.cos, tab.sin, kc_g, vc_g, B, H, hd, Lmax, pos)
+    cmp(q_g, q_r, dtype, what="kv_append q/k rotation")
+    cmp(kc_g, kc_r, dtype, what="kv_append k cache")
+    assert torch.equal(vc_g.cpu(), vc_r)
+    o_r = torch.empty((B, D), dtype=dtype)
+    emu.attn_decode(q_r, kc_r, vc_r, o_r, B, H, hd, Lmax, length, hd ** -0.5)
+    o_g = torch.empty((B, D), dtype=dtype, device="cuda")
+    ops.attn_decode(q_g, kc_g, vc_g, o_g, B, H, hd, Lmax, length, hd ** -0.5)
+    cmp(o_g, o_r, dtype, what="attn_decode")
+    S = min(5, Lmax)
+    pre = rnd((B * S, 3 * D), dtype, 35)
+    ops.kv_store_prefill(pre.cuda(), kc_g, vc_g, B, S, H, hd, Lmax)
+    emu.kv_store_prefill(pre, kc_r, vc_r, B, S, H, hd, Lmax)
+    assert torch.equal(kc_g.cpu()[:, :, :S], kc_r[:, :, :S]) and torch.equal(vc_g.cpu()[:, :, :S], vc_r[:, :, :S])
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_masked_softmax(ops, dtype):
+    import midi_model_amd as mm
+    tok = mm.MIDITokenizerV2()
+    first, lo_t, hi_t, _ = tok.grammar_tables()
+    B, V, Vp = 9, tok.vocab_size, 3456
+    logits = torch.zeros((B, Vp), dtype=dtype)
+    logits[:, :V] = rnd((B, V), dtype, 36, 2.0)
+    lo = torch.tensor([-1, -1, lo_t[3][1], lo_t[3][7], lo_t[6][4], 0, lo_t[4][5], -1, lo_t[8][5]], dtype=torch.int32)
+    hi = torch.tensor([-1, -1, hi_t[3][1], hi_t[3][7], hi_t[6][4], 1, hi_t[4][5], -1, hi_t[8][5]], dtype=torch.int32)
+    fm = torch.tensor(first, dtype=torch.uint8)
+    want = emu.masked_softmax(logits, lo, hi, fm, torch.empty((B, V)), V, 0.8)
+    got = torch.empty((B, V), device="cuda")
+    ops.masked_softmax(logits.cuda(), lo.cuda(), hi.cuda(), fm.cuda(), got, V, 0.8)
+    cmp(got, want, torch.float32, k=(1 if dtype == torch.float32 else 20), what="masked softmax")
+    assert ((got > 0).cpu() == (want > 0)).all()
