@@ -44,7 +44,10 @@ def cpu_baseline(sample_S: int, seed: int = 0):
     orc = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(orc)
     import midi_model_amd as mm
-    cores = os.cpu_count() or 1
+    # With one thread per core of the GPU box's 256-core host the step collapsed to 2.4 events/s (421 s for
+    # 1024 events: oversubscribed GEMMs, profiles/r01_run1_bench.json); the baseline is therefore bounded to
+    # 32 threads and a shorter sample.  `cores` reports the threads actually used.
+    cores = min(os.cpu_count() or 1, 32)
     torch.set_num_threads(cores)
     tok = mm.MIDITokenizerV2()
     shp = orc.Shape(vocab=tok.vocab_size)
@@ -74,7 +77,7 @@ def main():
     ap.add_argument("--seq", type=int, default=2048, help="events per sequence seen by the model")
     ap.add_argument("--config", default="tv2o-medium")
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
-    ap.add_argument("--cpu-sample-seq", type=int, default=1024)
+    ap.add_argument("--cpu-sample-seq", type=int, default=512)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-gemm-events", action="store_true")
     args = ap.parse_args()

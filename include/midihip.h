@@ -62,6 +62,10 @@ int mh_concat_tok_fwd(const void* hidden, const int64_t* tok, int64_t ldtok, con
 int mh_embed_scatter_bwd(const int64_t* tok, int64_t ldtok, int T, const void* dout, int rows_per_m, int jstride,
                          int j0, float* dtable_f32, int64_t M, int64_t V, int D, int64_t pad_id, int dtype,
                          void* stream);
+/* Segment form (production): occurrences pre-sorted by token id.  dtable_f32[v,:] += sum_{i in [seg_start[v],
+ * seg_start[v+1])} dout[src_rows[i]*ld ...]; id `pad_id` is skipped.  `nsplit` blocks share one id's list.   */
+int mh_embed_segment_bwd(const int64_t* src_rows, const int64_t* seg_start, const void* dout, int64_t ld,
+                         float* dtable_f32, int64_t V, int D, int nsplit, int64_t pad_id, int dtype, void* stream);
 /* dst[i] (dtype) = (accumulate ? dst[i] : 0) + src_f32[i] */
 int mh_cast_from_f32(const float* src, void* dst, int64_t n, int accumulate, int dtype, void* stream);
 /* strided row copy: dst[m,:] = src[m*src_ld ...] (+ optional accumulate) — takes d(hidden) out of d(token seq). */
@@ -77,7 +81,7 @@ int mh_rmsnorm_fwd(const void* x, const void* w, void* y, float* rstd, int64_t M
 int mh_rmsnorm_bwd_blocks(int64_t M);
 int mh_rmsnorm_bwd(const void* x, const void* w, const float* rstd, const void* dy, const void* dres, void* dx,
                    float* dw_partial, int64_t M, int D, int dtype, void* stream);
-int mh_colsum(const float* partial, int64_t nblk, void* out, int D, int accumulate, int dtype, void* stream);
+int mh_colsum(float* partial /* clobbered */, int64_t nblk, void* out, int D, int accumulate, int dtype, void* stream);
 
 /* ---- RoPE (TF:models/llama/modeling_llama.py:113-160; half-split rotate_half) --------------------------
  * In place on the q and k thirds of qkv[M, 3*H*hd]; row m sits at position pos0 + (m % S).

@@ -114,6 +114,75 @@ extern "C" int mh_embed_scatter_bwd(const int64_t* tok, int64_t ldtok, int T_, c
   return MH_OK;
 }
 
+// Segment form of the same gradient (the production path): the token occurrences are pre-sorted by token id
+// (src[i] = row of `dout` that occurrence i reads, seg[v]..seg[v+1] = the occurrences of id v), so a block owns
+// one id (and one of `nsplit` slices of its occurrences), sums its rows in registers with coalesced 16-byte
+// loads and touches the fp32 table once — at most nsplit atomics per element instead of one per occurrence
+// (the scatter form serialises ~29k atomics on the row of the ubiquitous "note" id).
+template <typename T>
+__global__ __launch_bounds__(256) void embed_segment_bwd_kernel(const int64_t* __restrict__ src, const int64_t* __restrict__ seg,
+                                                                const T* __restrict__ dout, int64_t ld,
+                                                                float* __restrict__ dtab, int D, int64_t pad_id) {
+  constexpr int N = Pack<T>::N;
+  constexpr int MAXCH = 8;
+  __shared__ float red[4][64 * N];
+  const int64_t v = blockIdx.x;
+  if (v == pad_id) return;
+  const int64_t a0 = seg[v], a1 = seg[v + 1];
+  const int64_t cnt = a1 - a0;
+  if (cnt <= 0) return;
+  const int64_t per = (cnt + gridDim.y - 1) / gridDim.y;
+  const int64_t b0 = a0 + (int64_t)blockIdx.y * per;
+  int64_t b1 = b0 + per;
+  if (b1 > a1) b1 = a1;
+  if (b0 >= b1) return;
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int nch = (D + 64 * N - 1) / (64 * N);
+  float acc[MAXCH][N];
+#pragma unroll
+  for (int ch = 0; ch < MAXCH; ++ch)
+#pragma unroll
+    for (int e = 0; e < N; ++e) acc[ch][e] = 0.f;
+  for (int64_t i = b0 + wv; i < b1; i += 4) {
+    const T* row = dout + src[i] * ld;
+#pragma unroll
+    for (int ch = 0; ch < MAXCH; ++ch) {
+      const int c = (ch * 64 + lane) * N;
+      if (ch < nch && c < D) {
+        Pack<T> p = ld16(row + c);
+#pragma unroll
+        for (int e = 0; e < N; ++e) acc[ch][e] += p.get(e);
+      }
+    }
+  }
+  float* dst = dtab + v * D;
+  for (int ch = 0; ch < nch; ++ch) {
+    __syncthreads();
+#pragma unroll
+    for (int e = 0; e < N; ++e) red[wv][lane * N + e] = acc[ch][e];
+    __syncthreads();
+    for (int t = threadIdx.x; t < 64 * N; t += 256) {
+      const int c = ch * 64 * N + t;
+      if (c < D) {
+        const float s = red[0][t] + red[1][t] + red[2][t] + red[3][t];
+        if (gridDim.y > 1) atomicAdd(dst + c, s); else dst[c] += s;
+      }
+    }
+  }
+}
+
+extern "C" int mh_embed_segment_bwd(const int64_t* src_rows, const int64_t* seg_start, const void* dout, int64_t ld,
+                                    float* dtable_f32, int64_t V, int D, int nsplit, int64_t pad_id, int dtype,
+                                    void* stream) {
+  MH_REQUIRE(V > 0 && V < (1 << 30) && D % 8 == 0 && D <= 4096 && nsplit >= 1 && nsplit <= 65535, "embed_segment_bwd: bad args");
+  MH_REQUIRE(dtype != MH_F32 || D <= 2048, "embed_segment_bwd: fp32 supports D <= 2048");
+  dim3 grid((unsigned)V, (unsigned)nsplit);
+  DISPATCH_T(dtype, (embed_segment_bwd_kernel<T><<<grid, 256, 0, (hipStream_t)stream>>>(src_rows, seg_start, (const T*)dout, ld,
+                                                                                        dtable_f32, D, pad_id)));
+  MH_LAUNCH_CHECK();
+  return MH_OK;
+}
+
 template <typename T>
 __global__ __launch_bounds__(256) void cast_from_f32_kernel(const float* __restrict__ src, T* __restrict__ dst, int64_t n,
                                                             int accumulate) {
@@ -260,21 +329,48 @@ extern "C" int mh_rmsnorm_bwd(const void* x, const void* w, const float* rstd, c
   return MH_OK;
 }
 
+// Column sums of the [nblk, D] fp32 partials, deterministic, in two stages so that more than D/256 blocks
+// work: stage A folds each of NSPLIT row ranges into the range's first row (in place: a block only touches
+// its own rows x 64 columns), stage B adds the NSPLIT surviving rows.
+constexpr int COLSUM_NSPLIT = 32;
+
+__global__ __launch_bounds__(256) void colsum_stage_a_kernel(float* __restrict__ partial, int64_t nblk, int D, int64_t rows_per) {
+  __shared__ float sh[4][64];
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+  const int c = blockIdx.x * 64 + tx;
+  const int64_t r0 = (int64_t)blockIdx.y * rows_per;
+  int64_t r1 = r0 + rows_per;
+  if (r1 > nblk) r1 = nblk;
+  float s = 0.f;
+  if (c < D)
+    for (int64_t r = r0 + ty; r < r1; r += 4) s += partial[r * D + c];
+  sh[ty][tx] = s;
+  __syncthreads();
+  if (ty == 0 && c < D && r0 < nblk) partial[r0 * D + c] = sh[0][tx] + sh[1][tx] + sh[2][tx] + sh[3][tx];
+}
+
 template <typename T>
-__global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ partial, int64_t nblk, T* __restrict__ out,
-                                                     int D, int accumulate) {
+__global__ __launch_bounds__(256) void colsum_stage_b_kernel(const float* __restrict__ partial, int64_t nblk, int64_t rows_per,
+                                                             T* __restrict__ out, int D, int accumulate) {
   const int c = blockIdx.x * 256 + threadIdx.x;
   if (c >= D) return;
   float s = 0.f;
-  for (int64_t b = 0; b < nblk; ++b) s += partial[b * D + c];
+  for (int64_t r = 0; r < nblk; r += rows_per) s += partial[r * D + c];
   if (accumulate) s += to_f(out[c]);
   out[c] = from_f<T>(s);
 }
 
-extern "C" int mh_colsum(const float* partial, int64_t nblk, void* out, int D, int accumulate, int dtype, void* stream) {
+extern "C" int mh_colsum(float* partial, int64_t nblk, void* out, int D, int accumulate, int dtype, void* stream) {
   MH_REQUIRE(nblk > 0 && D > 0, "colsum: bad shape");
-  DISPATCH_T(dtype, (colsum_kernel<T><<<(D + 255) / 256, 256, 0, (hipStream_t)stream>>>(partial, nblk, (T*)out, D,
-                                                                                        accumulate)));
+  hipStream_t st = (hipStream_t)stream;
+  int64_t rows_per = 1;
+  if (nblk > COLSUM_NSPLIT) {
+    rows_per = (nblk + COLSUM_NSPLIT - 1) / COLSUM_NSPLIT;
+    dim3 grid((D + 63) / 64, (unsigned)((nblk + rows_per - 1) / rows_per));
+    colsum_stage_a_kernel<<<grid, 256, 0, st>>>(partial, nblk, D, rows_per);
+    MH_LAUNCH_CHECK();
+  }
+  DISPATCH_T(dtype, (colsum_stage_b_kernel<T><<<(D + 255) / 256, 256, 0, st>>>(partial, nblk, rows_per, (T*)out, D, accumulate)));
   MH_LAUNCH_CHECK();
   return MH_OK;
 }

@@ -417,7 +417,7 @@ class MIDIModel(nn.Module):
         while cur_len < max_len:
             S_new = cur_len - past_len
             e = torch.empty((B * S_new, spec.D), dtype=self.dtype, device=dev)
-            ops.embed_sum_fwd(out[:, past_len:cur_len].reshape(B * S_new, T), Wn.embed, e)
+            ops.embed_sum_fwd(out[:, past_len:cur_len].contiguous().view(B * S_new, T), Wn.embed, e)
             if past_len == 0:
                 hidden = engine.stack_prefill(spec, Wn, e, B, S_new, self.rope("net"), kv1).view(B, S_new, spec.D)[:, -1].contiguous()
             else:

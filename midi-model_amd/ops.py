@@ -120,6 +120,23 @@ def embed_scatter_bwd(tok: torch.Tensor, T: int, dout: torch.Tensor, rows_per_m:
                pad_id, dt(dout), _stream())
 
 
+def token_segments(tok_flat: torch.Tensor, V: int):
+    """Index preparation for embed_segment_bwd: (order, seg_start) with `order` the occurrence indices sorted by
+    token id and seg_start[v] the first sorted position of id v (length V+1)."""
+    sorted_tok, order = torch.sort(tok_flat)
+    seg = torch.searchsorted(sorted_tok, torch.arange(V + 1, device=tok_flat.device, dtype=tok_flat.dtype))
+    return order, seg.contiguous()
+
+
+def embed_segment_bwd(src_rows: torch.Tensor, seg_start: torch.Tensor, dout: torch.Tensor, ld: int,
+                      dtable_f32: torch.Tensor, pad_id: int, nsplit: int = 16) -> None:
+    V, D = dtable_f32.shape
+    assert src_rows.dtype == torch.int64 and seg_start.dtype == torch.int64 and seg_start.numel() == V + 1
+    assert src_rows.is_contiguous() and dtable_f32.dtype == torch.float32
+    lib().call("mh_embed_segment_bwd", _p(src_rows), _p(seg_start), _p(dout), ld, _p(dtable_f32), V, D, nsplit, pad_id,
+               dt(dout), _stream())
+
+
 def cast_from_f32(src: torch.Tensor, dst: torch.Tensor, accumulate: bool) -> None:
     assert src.dtype == torch.float32 and src.numel() == dst.numel() and dst.is_contiguous()
     lib().call("mh_cast_from_f32", _p(src), _p(dst), src.numel(), int(accumulate), dt(dst), _stream())

@@ -61,6 +61,20 @@ def embed_scatter_bwd(tok, T, dout, rows_per_m, jstride, j0, dtable_f32, pad_id)
         dtable_f32.index_add_(0, ids[keep], d[rows[keep]])
 
 
+def token_segments(tok_flat, V):
+    sorted_tok, order = torch.sort(tok_flat, stable=True)
+    seg = torch.searchsorted(sorted_tok, torch.arange(V + 1, dtype=tok_flat.dtype))
+    return order, seg.contiguous()
+
+
+def embed_segment_bwd(src_rows, seg_start, dout, ld, dtable_f32, pad_id, nsplit=16):
+    V, D = dtable_f32.shape
+    rows = torch.as_strided(dout, (int(src_rows.max()) + 1 if src_rows.numel() else 0, D), (ld, 1), dout.storage_offset()).float()
+    ids = torch.repeat_interleave(torch.arange(V), seg_start[1:] - seg_start[:-1])
+    keep = ids != pad_id
+    dtable_f32.index_add_(0, ids[keep], rows[src_rows[keep]])
+
+
 def cast_from_f32(src, dst, accumulate):
     flat = dst.view(-1)
     flat.copy_(((flat.float() if accumulate else 0) + src.view(-1)).to(dst.dtype))
