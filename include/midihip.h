@@ -42,6 +42,15 @@ int mh_version(void);
 int mh_gemm_nt(const void* A, int64_t lda, const void* B, int64_t ldb, void* C, int64_t ldc, const void* R,
                int64_t ldr, int64_t M, int64_t N, int64_t K, float alpha, float beta, int dtype, int splitk,
                void* workspace, void* stream);
+/* General form: transA != 0 means A is stored contraction-major, A[K][M] (lda >= M); likewise transB: B[K][N].
+ * That is how dgrad (dX = dY * W, W[N][K] contracted over its rows) and wgrad (dW = dY^T * X, both contracted
+ * over the row index) present their operands, so neither needs a re-layout pass: the kernel stages such tiles as
+ * they lie and assembles MFMA fragments with LDS transpose reads (ds_read_b64_tr_b16).  bf16 only; K is then
+ * unrestricted.  For non-transposed operands whose K is not a multiple of 8 the row tail up to the next
+ * multiple must be readable and finite (zero).                                                              */
+int mh_gemm(const void* A, int64_t lda, int transA, const void* B, int64_t ldb, int transB, void* C, int64_t ldc,
+            const void* R, int64_t ldr, int64_t M, int64_t N, int64_t K, float alpha, float beta, int dtype, int splitk,
+            void* workspace, void* stream);
 int mh_gemm_splitk_reduce(const void* workspace, void* C, int64_t ldc, const void* R, int64_t ldr, int64_t M,
                           int64_t N, int splitk, float alpha, float beta, int dtype, void* stream);
 /* out[C,R] = in[R,C]^T (operand re-layout for dgrad/wgrad). */

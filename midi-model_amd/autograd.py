@@ -56,9 +56,8 @@ class NetFn(torch.autograd.Function):
         spec = model._specs["net"]
         tmp = torch.empty_like(model._flat)
         G = model._stack_views("net", tmp)
-        views, _ = model.transposed()
         dy2 = dy.contiguous().view(B * S, spec.D).to(model.dtype)
-        dx = engine.stack_backward(spec, model._W["net"], views["net"], G, ctx.saved, dy2, model.rope("net"), False)
+        dx = engine.stack_backward(spec, model._W["net"], G, ctx.saved, dy2, model.rope("net"), False)
         ctx.saved = None
         acc = torch.zeros(G.embed.shape, dtype=torch.float32, device=model.device)
         ops.embed_scatter_bwd(tokens.view(B * S, T), T, dx, 1, 0, 0, acc, model.tokenizer.pad_id)
@@ -108,13 +107,10 @@ class TokFn(torch.autograd.Function):
         G = model._stack_views("net_token", tmp)
         off, n, _ = model._offsets["lm_head.weight"]
         g_lm = tmp[off:off + n].view(V, spec.D)
-        views, lmT = model.transposed()
         dh = torch.empty((R, spec.D), dtype=model.dtype, device=model.device)
-        ops.gemm_nt(dl, lmT, dh)
-        dlT = ops.transpose(dl)
-        hT = ops.transpose(ctx.h)
-        ops.gemm_nt(dlT[:V], hT, g_lm, K=dlT.shape[1])
-        dseq = engine.stack_backward(spec, model._W["net_token"], views["net_token"], G, ctx.saved, dh,
+        ops.gemm_nt(dl, model.lm_head.weight.data, dh, K=V, tb=True)
+        ops.gemm_nt(dl, ctx.h, g_lm, K=R, ta=True, tb=True)
+        dseq = engine.stack_backward(spec, model._W["net_token"], G, ctx.saved, dh,
                                      model.rope("net_token"), False)
         ctx.saved = ctx.h = None
         dhidden = torch.empty((N, spec.D), dtype=model.dtype, device=model.device)

@@ -14,12 +14,19 @@
 // transposed copies [B,H,64,Sp] written by the prep kernels (first structure; to be replaced by
 // ds_read_b64_tr_b16 staging).  All tiles are 64 rows x 128 B in the swizzled LDS format of common.h and
 // arrive by global_load_lds (double buffered, one barrier per tile).
-// Roofline: MFMA (2.5 PFLOP/s bf16 dense); at head_dim 64 the exp/VALU work per MFMA is twice that of
-// head_dim 128, so the VALU pipe is the co-limiter.
+//
+// VALU budget.  At head_dim 64 a 64-key tile is only 16 MFMAs (512 cycles/wave) against 2048 softmax
+// elements per wave, so the per-element VALU cost decides the kernel.  r01 run 1 measured 237 TF/s with ~13
+// VALU instructions per element (always-on 64-bit causal-mask compares, exp2f's denormal path); this
+// version keeps 3-4: the causal mask is compiled only into the diagonal-tile instantiation (MASK), index
+// math is 32-bit and tile-relative, the scale is folded into one fma feeding a raw v_exp_f32, and row maxima
+// are taken on the unscaled scores.
+// Roofline: MFMA (2.5 PFLOP/s bf16 dense), VALU co-limited.
 #include "common.h"
 
 constexpr int HD = 64;
 constexpr int TILE64 = 64 * 128;  // bytes
+constexpr float LOG2E = 1.4426950408889634f;
 
 __device__ inline f32x16 mfma32(const bf16x8& a, const bf16x8& b, f32x16 c) {
   return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
@@ -39,6 +46,9 @@ __device__ inline bf16x8 pack8(const f32x16& v, int base) {
   for (int e = 0; e < 8; ++e) o[e] = (bf16)v[base + e];
   return o;
 }
+__device__ inline float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }  // raw v_exp_f32
+// register r of lane-half hi <-> reduction index (within a 32-block) 16*(r>>3) + 8*hi + (r&7)
+__device__ inline int reg_index(int r, int hi) { return 16 * (r >> 3) + 8 * hi + (r & 7); }
 
 // stage a 64-row x 64-col bf16 tile: rows row0.. (clamped to row_clamp), columns col0..col0+63
 __device__ inline void stage64(const bf16* __restrict__ base, int64_t ld, int64_t row0, int64_t row_clamp, int64_t col0,
@@ -58,9 +68,59 @@ __device__ inline void stage64(const bf16* __restrict__ base, int64_t ld, int64_
 // ---------------------------------------------------------------------------------------------------
 // forward
 // ---------------------------------------------------------------------------------------------------
+// one 64-key tile for one wave (32 query rows).  qrel = query row - first key of the tile.
+template <bool MASK>
+__device__ inline void fwd_tile(const char* tK, const char* tV, const bf16x8 (&qf)[4], f32x16 (&oacc)[2], float& m,
+                                float& l, int pli, int hi, int qrel, float sc) {
+  f32x16 sacc[2] = {zero16(), zero16()};
+#pragma unroll
+  for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+    for (int s = 0; s < 4; ++s) sacc[kb] = mfma32(lds_frag(tK, kb * 32 + pli, 2 * s + hi), qf[s], sacc[kb]);
+  float mx = -INFINITY;
+#pragma unroll
+  for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      if (MASK) {
+        if (kb * 32 + reg_index(r, hi) > qrel) sacc[kb][r] = -INFINITY;
+      }
+      mx = fmaxf(mx, sacc[kb][r]);
+    }
+  mx = fmaxf(mx, __shfl_xor(mx, 32, 64)) * sc;  // running max kept in scaled (log2) units
+  // Rescale O only when some row's maximum actually grew (exact: no threshold).  After the first few tiles of a
+  // row this is rare, and skipping it saves the AGPR<->VGPR round trip of the 32 accumulator registers.
+  float mn = m, alpha = 1.f;
+  if (__any(mx > m)) {
+    mn = fmaxf(m, mx);
+    alpha = fast_exp2(m - mn);
+#pragma unroll
+    for (int db = 0; db < 2; ++db)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) oacc[db][r] *= alpha;
+  }
+  float psum = 0.f;
+#pragma unroll
+  for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const float p = fast_exp2(__builtin_fmaf(sacc[kb][r], sc, -mn));
+      sacc[kb][r] = p;
+      psum += p;
+    }
+  l = l * alpha + psum;
+  m = mn;
+#pragma unroll
+  for (int t = 0; t < 4; ++t) {
+    const bf16x8 pf = pack8(sacc[t >> 1], 8 * (t & 1));
+#pragma unroll
+    for (int db = 0; db < 2; ++db) oacc[db] = mfma32(lds_frag(tV, db * 32 + pli, 2 * t + hi), pf, oacc[db]);
+  }
+}
+
 __global__ __launch_bounds__(256) void attn_fwd_kernel(const bf16* __restrict__ qkv, const bf16* __restrict__ vt,
-                                                       bf16* __restrict__ o, float* __restrict__ lse, int64_t S,
-                                                       int64_t Sp, int H, float sc /* scale*log2(e) */) {
+                                                       bf16* __restrict__ o, float* __restrict__ lse, int S, int Sp, int H,
+                                                       float sc /* scale*log2(e) */) {
   __shared__ __attribute__((aligned(16))) char smem[4 * TILE64];  // [stage][K | V^T]
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -69,11 +129,11 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const bf16* __restrict__ 
   const int h = (int)(bh - b * H);
   const int64_t D = (int64_t)H * HD, D3 = 3 * D;
   const int nqt = gridDim.x;
-  const int64_t q0 = (int64_t)(nqt - 1 - blockIdx.x) * 128;  // heavy (late) query tiles first
-  const int64_t qw0 = q0 + wave * 32;
+  const int q0 = (nqt - 1 - (int)blockIdx.x) * 128;  // heavy (late) query tiles first
+  const int qw0 = q0 + wave * 32;
   const int li = lane & 31, hi = lane >> 5;
-  const int64_t qrow = qw0 + li;
-  const int64_t qld = (qrow < S) ? qrow : S - 1;
+  const int qrow = qw0 + li;
+  const int qld = (qrow < S) ? qrow : S - 1;
 
   const bf16* kbase = qkv + b * S * D3 + D + (int64_t)h * HD;
   const bf16* vtbase = vt + bh * HD * Sp;
@@ -87,9 +147,9 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const bf16* __restrict__ 
   f32x16 oacc[2] = {zero16(), zero16()};
   float m = -INFINITY, l = 0.f;
 
-  int64_t last_q = q0 + 127;
+  int last_q = q0 + 127;
   if (last_q > S - 1) last_q = S - 1;
-  const int kt_last = (int)(last_q / 64);
+  const int kt_last = last_q / 64;
   const int pli = pi32(li);
 
   stage64(kbase, D3, 0, S - 1, 0, smem, wave, lane);
@@ -102,52 +162,12 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const bf16* __restrict__ 
       stage64(kbase, D3, (int64_t)(kt + 1) * 64, S - 1, 0, nxt, wave, lane);
       stage64(vtbase, Sp, 0, HD - 1, (int64_t)(kt + 1) * 64, nxt + TILE64, wave, lane);
     }
-    if ((int64_t)kt * 64 <= qw0 + 31) {  // wave-uniform: this wave still has unmasked keys in the tile
-      const char* tK = cur;
-      const char* tV = cur + TILE64;
-      f32x16 sacc[2] = {zero16(), zero16()};
-#pragma unroll
-      for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-        for (int s = 0; s < 4; ++s) sacc[kb] = mfma32(lds_frag(tK, kb * 32 + pli, 2 * s + hi), qf[s], sacc[kb]);
-      const bool need_mask = ((int64_t)kt * 64 + 63 > qw0);
-      float mx = -INFINITY;
-#pragma unroll
-      for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          float x = sacc[kb][r] * sc;
-          if (need_mask) {
-            const int64_t key = (int64_t)kt * 64 + kb * 32 + 16 * (r >> 3) + 8 * hi + (r & 7);
-            if (key > qrow) x = -INFINITY;
-          }
-          sacc[kb][r] = x;
-          mx = fmaxf(mx, x);
-        }
-      mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-      const float mn = fmaxf(m, mx);
-      const float alpha = exp2f(m - mn);
-      float psum = 0.f;
-#pragma unroll
-      for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const float p = exp2f(sacc[kb][r] - mn);
-          sacc[kb][r] = p;
-          psum += p;
-        }
-      l = l * alpha + psum;
-      m = mn;
-#pragma unroll
-      for (int db = 0; db < 2; ++db)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) oacc[db][r] *= alpha;
-#pragma unroll
-      for (int t = 0; t < 4; ++t) {
-        const bf16x8 pf = pack8(sacc[t >> 1], 8 * (t & 1));
-#pragma unroll
-        for (int db = 0; db < 2; ++db) oacc[db] = mfma32(lds_frag(tV, db * 32 + pli, 2 * t + hi), pf, oacc[db]);
-      }
+    const int k0 = kt * 64;
+    if (k0 <= qw0 + 31) {  // wave-uniform: this wave still has unmasked keys in the tile
+      if (k0 + 63 > qw0)   // wave-uniform: the tile crosses this wave's diagonal
+        fwd_tile<true>(cur, cur + TILE64, qf, oacc, m, l, pli, hi, qrow - k0, sc);
+      else
+        fwd_tile<false>(cur, cur + TILE64, qf, oacc, m, l, pli, hi, 0, sc);
     }
     __syncthreads();
   }
@@ -171,10 +191,40 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const bf16* __restrict__ 
 // ---------------------------------------------------------------------------------------------------
 // backward, dQ: block = 128 query rows, loop over key tiles
 // ---------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const bf16* __restrict__ qkv, const bf16* __restrict__ dout,
-                                                          const float* __restrict__ lse, const float* __restrict__ delta,
-                                                          const bf16* __restrict__ kt_, bf16* __restrict__ dqkv, int64_t S,
-                                                          int64_t Sp, int H, float scale) {
+template <bool MASK>
+__device__ inline void dq_tile(const char* tK, const char* tV, const char* tKT, const bf16x8 (&qf)[4],
+                               const bf16x8 (&dof)[4], f32x16 (&dqacc)[2], int pli, int hi, int qrel, float sc,
+                               float lse2, float dl) {
+#pragma unroll
+  for (int kb = 0; kb < 2; ++kb) {
+    f32x16 sacc = zero16(), pacc = zero16();
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      sacc = mfma32(lds_frag(tK, kb * 32 + pli, 2 * s + hi), qf[s], sacc);
+      pacc = mfma32(lds_frag(tV, kb * 32 + pli, 2 * s + hi), dof[s], pacc);
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      float p = fast_exp2(__builtin_fmaf(sacc[r], sc, -lse2));
+      if (MASK) {
+        if (kb * 32 + reg_index(r, hi) > qrel) p = 0.f;
+      }
+      sacc[r] = p * (pacc[r] - dl);  // dS (unscaled)
+    }
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      const bf16x8 dsf = pack8(sacc, 8 * t);
+#pragma unroll
+      for (int hb = 0; hb < 2; ++hb)
+        dqacc[hb] = mfma32(lds_frag(tKT, hb * 32 + pli, 4 * kb + 2 * t + hi), dsf, dqacc[hb]);
+    }
+  }
+}
+
+__global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const bf16* __restrict__ qkv, const bf16* __restrict__ dout,
+                                                             const float* __restrict__ lse, const float* __restrict__ delta,
+                                                             const bf16* __restrict__ kt_, bf16* __restrict__ dqkv, int S,
+                                                             int Sp, int H, float scale) {
   __shared__ __attribute__((aligned(16))) char smem[6 * TILE64];  // [stage][K | V | K^T]
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -183,12 +233,12 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const bf16* __restrict
   const int h = (int)(bh - b * H);
   const int64_t D = (int64_t)H * HD, D3 = 3 * D;
   const int nqt = gridDim.x;
-  const int64_t q0 = (int64_t)(nqt - 1 - blockIdx.x) * 128;
-  const int64_t qw0 = q0 + wave * 32;
+  const int q0 = (nqt - 1 - (int)blockIdx.x) * 128;
+  const int qw0 = q0 + wave * 32;
   const int li = lane & 31, hi = lane >> 5;
-  const int64_t qrow = qw0 + li;
-  const int64_t qld = (qrow < S) ? qrow : S - 1;
-  const float sc = scale * 1.4426950408889634f;
+  const int qrow = qw0 + li;
+  const int qld = (qrow < S) ? qrow : S - 1;
+  const float sc = scale * LOG2E;
 
   const bf16* kbase = qkv + b * S * D3 + D + (int64_t)h * HD;
   const bf16* vbase = kbase + D;
@@ -204,13 +254,13 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const bf16* __restrict
       dof[s] = *reinterpret_cast<const bf16x8*>(dp + 16 * s);
     }
   }
-  const float lse2 = lse[bh * Sp + qld] * 1.4426950408889634f;
+  const float lse2 = lse[bh * Sp + qld] * LOG2E;
   const float dl = delta[bh * Sp + qld];
   f32x16 dqacc[2] = {zero16(), zero16()};
 
-  int64_t last_q = q0 + 127;
+  int last_q = q0 + 127;
   if (last_q > S - 1) last_q = S - 1;
-  const int kt_last = (int)(last_q / 64);
+  const int kt_last = last_q / 64;
   const int pli = pi32(li);
 
   stage64(kbase, D3, 0, S - 1, 0, smem, wave, lane);
@@ -225,32 +275,12 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const bf16* __restrict
       stage64(vbase, D3, (int64_t)(kt + 1) * 64, S - 1, 0, nxt + TILE64, wave, lane);
       stage64(ktbase, Sp, 0, HD - 1, (int64_t)(kt + 1) * 64, nxt + 2 * TILE64, wave, lane);
     }
-    if ((int64_t)kt * 64 <= qw0 + 31) {
-      const char* tK = cur;
-      const char* tV = cur + TILE64;
-      const char* tKT = cur + 2 * TILE64;
-#pragma unroll
-      for (int kb = 0; kb < 2; ++kb) {
-        f32x16 sacc = zero16(), pacc = zero16();
-#pragma unroll
-        for (int s = 0; s < 4; ++s) {
-          sacc = mfma32(lds_frag(tK, kb * 32 + pli, 2 * s + hi), qf[s], sacc);
-          pacc = mfma32(lds_frag(tV, kb * 32 + pli, 2 * s + hi), dof[s], pacc);
-        }
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int64_t key = (int64_t)kt * 64 + kb * 32 + 16 * (r >> 3) + 8 * hi + (r & 7);
-          const float p = (key <= qrow) ? exp2f(sacc[r] * sc - lse2) : 0.f;
-          sacc[r] = p * (pacc[r] - dl);  // dS (unscaled)
-        }
-#pragma unroll
-        for (int t = 0; t < 2; ++t) {
-          const bf16x8 dsf = pack8(sacc, 8 * t);
-#pragma unroll
-          for (int hb = 0; hb < 2; ++hb)
-            dqacc[hb] = mfma32(lds_frag(tKT, hb * 32 + pli, 4 * kb + 2 * t + hi), dsf, dqacc[hb]);
-        }
-      }
+    const int k0 = kt * 64;
+    if (k0 <= qw0 + 31) {
+      if (k0 + 63 > qw0)
+        dq_tile<true>(cur, cur + TILE64, cur + 2 * TILE64, qf, dof, dqacc, pli, hi, qrow - k0, sc, lse2, dl);
+      else
+        dq_tile<false>(cur, cur + TILE64, cur + 2 * TILE64, qf, dof, dqacc, pli, hi, 0, sc, lse2, dl);
     }
     __syncthreads();
   }
@@ -271,11 +301,61 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const bf16* __restrict
 // ---------------------------------------------------------------------------------------------------
 // backward, dK/dV: block = 128 key rows, loop over the query tiles that see them
 // ---------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const bf16* __restrict__ qkv, const bf16* __restrict__ dout,
-                                                           const float* __restrict__ lse, const float* __restrict__ delta,
-                                                           const bf16* __restrict__ qt_, const bf16* __restrict__ dot_,
-                                                           bf16* __restrict__ dqkv, int64_t S, int64_t Sp, int H,
-                                                           float scale) {
+// one 64-query tile for one wave (32 key rows).  krel = key row - first query of the tile; qlim = number of
+// valid queries in the tile (S - q0, may exceed 64).
+template <bool MASK>
+__device__ inline void dkv_tile(const char* tQ, const char* tDO, const char* tQT, const char* tDOT, const bf16x8 (&kf)[4],
+                                const bf16x8 (&vf)[4], f32x16 (&dkacc)[2], f32x16 (&dvacc)[2], const float* __restrict__ lse_t,
+                                const float* __restrict__ delta_t, int pli, int hi, int krel, int qlim, float sc) {
+#pragma unroll
+  for (int qb = 0; qb < 2; ++qb) {
+    f32x16 sacc = zero16(), pacc = zero16();
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      sacc = mfma32(lds_frag(tQ, qb * 32 + pli, 2 * s + hi), kf[s], sacc);
+      pacc = mfma32(lds_frag(tDO, qb * 32 + pli, 2 * s + hi), vf[s], pacc);
+    }
+    // lse/delta are [B,H,Sp]: the two runs of 8 queries this lane-half owns are aligned 16-byte loads; entries
+    // past S are never-written padding and are discarded by the MASK select (the last tile is always MASK).
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      const int qq = qb * 32 + 16 * t + 8 * hi;
+#pragma unroll
+      for (int v4 = 0; v4 < 2; ++v4) {
+        const f32x4 a = *reinterpret_cast<const f32x4*>(lse_t + qq + 4 * v4);
+        const f32x4 d4 = *reinterpret_cast<const f32x4*>(delta_t + qq + 4 * v4);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const int r = 8 * t + 4 * v4 + e;
+          float p = fast_exp2(__builtin_fmaf(sacc[r], sc, -a[e] * LOG2E));
+          float ds = p * (pacc[r] - d4[e]);
+          if (MASK) {
+            const int q = qq + 4 * v4 + e;
+            const bool ok = (q >= krel) && (q < qlim);
+            p = ok ? p : 0.f;
+            ds = ok ? ds : 0.f;
+          }
+          sacc[r] = p;
+          pacc[r] = ds;
+        }
+      }
+    }
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      const bf16x8 pf = pack8(sacc, 8 * t), dsf = pack8(pacc, 8 * t);
+#pragma unroll
+      for (int xb = 0; xb < 2; ++xb) {
+        dvacc[xb] = mfma32(lds_frag(tDOT, xb * 32 + pli, 4 * qb + 2 * t + hi), pf, dvacc[xb]);
+        dkacc[xb] = mfma32(lds_frag(tQT, xb * 32 + pli, 4 * qb + 2 * t + hi), dsf, dkacc[xb]);
+      }
+    }
+  }
+}
+
+__global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const bf16* __restrict__ qkv, const bf16* __restrict__ dout,
+                                                              const float* __restrict__ lse, const float* __restrict__ delta,
+                                                              const bf16* __restrict__ qt_, const bf16* __restrict__ dot_,
+                                                              bf16* __restrict__ dqkv, int S, int Sp, int H, float scale) {
   __shared__ __attribute__((aligned(16))) char smem[8 * TILE64];  // [stage][Q | dO | Q^T | dO^T]
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -283,17 +363,19 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const bf16* __restric
   const int64_t b = bh / H;
   const int h = (int)(bh - b * H);
   const int64_t D = (int64_t)H * HD, D3 = 3 * D;
-  const int64_t k0 = (int64_t)blockIdx.x * 128;
-  const int64_t kw0 = k0 + wave * 32;
+  const int k0 = (int)blockIdx.x * 128;
+  const int kw0 = k0 + wave * 32;
   const int li = lane & 31, hi = lane >> 5;
-  const int64_t krow = kw0 + li;
-  const int64_t kld = (krow < S) ? krow : S - 1;
-  const float sc = scale * 1.4426950408889634f;
+  const int krow = kw0 + li;
+  const int kld = (krow < S) ? krow : S - 1;
+  const float sc = scale * LOG2E;
 
   const bf16* qbase = qkv + b * S * D3 + (int64_t)h * HD;
   const bf16* dobase = dout + b * S * D + (int64_t)h * HD;
   const bf16* qtbase = qt_ + bh * HD * Sp;
   const bf16* dotbase = dot_ + bh * HD * Sp;
+  const float* lse_b = lse + bh * Sp;
+  const float* delta_b = delta + bh * Sp;
 
   bf16x8 kf[4], vf[4];
   {
@@ -306,7 +388,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const bf16* __restric
   }
   f32x16 dkacc[2] = {zero16(), zero16()}, dvacc[2] = {zero16(), zero16()};
   const int pli = pi32(li);
-  const int qt_first = (int)(k0 / 64), qt_last = (int)((S - 1) / 64);
+  const int qt_first = k0 / 64, qt_last = (S - 1) / 64;
 
   auto stage_all = [&](int qt, char* dst) {
     stage64(qbase, D3, (int64_t)qt * 64, S - 1, 0, dst, wave, lane);
@@ -321,56 +403,16 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const bf16* __restric
     const char* cur = smem + st * 4 * TILE64;
     char* nxt = smem + (st ^ 1) * 4 * TILE64;
     if (qt + 1 <= qt_last) stage_all(qt + 1, nxt);
-    if ((int64_t)qt * 64 + 63 >= kw0) {  // wave-uniform: some query of this tile sees this wave's keys
-      const char* tQ = cur;
-      const char* tDO = cur + TILE64;
-      const char* tQT = cur + 2 * TILE64;
-      const char* tDOT = cur + 3 * TILE64;
-#pragma unroll
-      for (int qb = 0; qb < 2; ++qb) {
-        f32x16 sacc = zero16(), pacc = zero16();
-#pragma unroll
-        for (int s = 0; s < 4; ++s) {
-          sacc = mfma32(lds_frag(tQ, qb * 32 + pli, 2 * s + hi), kf[s], sacc);
-          pacc = mfma32(lds_frag(tDO, qb * 32 + pli, 2 * s + hi), vf[s], pacc);
-        }
-        // register r <-> query qbase_r + (r&7), in two runs of 8
-        // lse/delta are [B,H,Sp] (Sp = S rounded up to 64): the two runs of 8 are aligned 16-byte loads;
-        // entries past S are never-written padding and are discarded by the select below.
-        float lsev[16], dlv[16];
-#pragma unroll
-        for (int t = 0; t < 2; ++t) {
-          const int64_t qq = bh * Sp + (int64_t)qt * 64 + qb * 32 + 16 * t + 8 * hi;
-#pragma unroll
-          for (int v4 = 0; v4 < 2; ++v4) {
-            const f32x4 a = *reinterpret_cast<const f32x4*>(lse + qq + 4 * v4);
-            const f32x4 d4 = *reinterpret_cast<const f32x4*>(delta + qq + 4 * v4);
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-              lsev[8 * t + 4 * v4 + e] = a[e] * 1.4426950408889634f;
-              dlv[8 * t + 4 * v4 + e] = d4[e];
-            }
-          }
-        }
-        f32x16 pv, dsv;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int64_t q = (int64_t)qt * 64 + qb * 32 + 16 * (r >> 3) + 8 * hi + (r & 7);
-          const bool ok = (q >= krow && q < S);
-          const float p = ok ? exp2f(sacc[r] * sc - lsev[r]) : 0.f;
-          pv[r] = p;
-          dsv[r] = ok ? p * (pacc[r] - dlv[r]) : 0.f;
-        }
-#pragma unroll
-        for (int t = 0; t < 2; ++t) {
-          const bf16x8 pf = pack8(pv, 8 * t), dsf = pack8(dsv, 8 * t);
-#pragma unroll
-          for (int xb = 0; xb < 2; ++xb) {
-            dvacc[xb] = mfma32(lds_frag(tDOT, xb * 32 + pli, 4 * qb + 2 * t + hi), pf, dvacc[xb]);
-            dkacc[xb] = mfma32(lds_frag(tQT, xb * 32 + pli, 4 * qb + 2 * t + hi), dsf, dkacc[xb]);
-          }
-        }
-      }
+    const int qs = qt * 64;
+    if (qs + 63 >= kw0) {  // wave-uniform: some query of this tile sees this wave's keys
+      // the causal mask matters when the tile's first query is below the wave's last key; the ragged tail
+      // (queries past S) only exists in the last tile
+      if (qs < kw0 + 31 || qs + 64 > S)
+        dkv_tile<true>(cur, cur + TILE64, cur + 2 * TILE64, cur + 3 * TILE64, kf, vf, dkacc, dvacc, lse_b + qs,
+                       delta_b + qs, pli, hi, krow - qs, S - qs, sc);
+      else
+        dkv_tile<false>(cur, cur + TILE64, cur + 2 * TILE64, cur + 3 * TILE64, kf, vf, dkacc, dvacc, lse_b + qs,
+                        delta_b + qs, pli, hi, 0, 64, sc);
     }
     __syncthreads();
   }
@@ -396,10 +438,11 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const bf16* __restric
 int mh_attn_fwd_mfma(const void* qkv, const void* vt, void* o, float* lse, int64_t B, int64_t S, int H, float scale,
                      hipStream_t st) {
   MH_REQUIRE(vt != nullptr, "attn_fwd(bf16): needs the transposed V copy (mh_attn_prep_fwd)");
+  MH_REQUIRE(S < (1 << 24), "attn_fwd: sequence too long");
   const int64_t Sp = (S + 63) / 64 * 64;
   dim3 grid((unsigned)((S + 127) / 128), (unsigned)(B * H));
-  attn_fwd_kernel<<<grid, 256, 0, st>>>((const bf16*)qkv, (const bf16*)vt, (bf16*)o, lse, S, Sp, H,
-                                        scale * 1.4426950408889634f);
+  attn_fwd_kernel<<<grid, 256, 0, st>>>((const bf16*)qkv, (const bf16*)vt, (bf16*)o, lse, (int)S, (int)Sp, H,
+                                        scale * LOG2E);
   MH_LAUNCH_CHECK();
   return MH_OK;
 }
@@ -408,13 +451,14 @@ int mh_attn_bwd_mfma(const void* qkv, const void* dout, const float* lse, const 
                      const void* kt, const void* dot, void* dqkv, int64_t B, int64_t S, int H, float scale,
                      hipStream_t st) {
   MH_REQUIRE(qt != nullptr && kt != nullptr && dot != nullptr, "attn_bwd(bf16): needs the transposed copies (mh_attn_prep_bwd)");
+  MH_REQUIRE(S < (1 << 24), "attn_bwd: sequence too long");
   const int64_t Sp = (S + 63) / 64 * 64;
   dim3 grid((unsigned)((S + 127) / 128), (unsigned)(B * H));
   attn_bwd_dq_kernel<<<grid, 256, 0, st>>>((const bf16*)qkv, (const bf16*)dout, lse, delta, (const bf16*)kt,
-                                           (bf16*)dqkv, S, Sp, H, scale);
+                                           (bf16*)dqkv, (int)S, (int)Sp, H, scale);
   MH_LAUNCH_CHECK();
   attn_bwd_dkv_kernel<<<grid, 256, 0, st>>>((const bf16*)qkv, (const bf16*)dout, lse, delta, (const bf16*)qt,
-                                            (const bf16*)dot, (bf16*)dqkv, S, Sp, H, scale);
+                                            (const bf16*)dot, (bf16*)dqkv, (int)S, (int)Sp, H, scale);
   MH_LAUNCH_CHECK();
   return MH_OK;
 }

@@ -53,7 +53,66 @@ __device__ inline void stage_tile(const T* __restrict__ base, int64_t ld, int64_
   }
 }
 
-template <typename T>
+// ---- "T-mode" operands: stored contraction-major, X[k][r] (r contiguous) --------------------------------
+// This is what dgrad (W[N][K] read as K rows x N contraction) and wgrad (dY[M][N], X[M][K] contracted over M)
+// present; instead of re-laying them out in HBM the tile is staged as it lies — 64 k-rows x 256 B — and the MFMA
+// fragment (8 consecutive k for one row r) is assembled by two ds_read_b64_tr_b16 transpose reads (semantics
+// pinned by tools/probe.hip: within a 16-lane group, lane p supplies 4 contiguous bf16 of row p>>2; output lane
+// i receives element i of each of the 4 rows).  The 32-byte granules (= one fragment's 16 rows) of k-row k are
+// XOR-swizzled with (k&3)|((k>>1)&4) so the 8 k-rows a 32-lane half touches land on 8 different granules.
+__device__ inline int tswz(int krow) { return (krow & 3) | ((krow >> 1) & 4); }
+
+__device__ inline void stage_tile_t(const bf16* __restrict__ base, int64_t ld, int64_t r0, int64_t nrows, int64_t k0,
+                                    int64_t kend, char* lds_tile, int wave, int lane) {
+  const int ksub = lane >> 4, pc = lane & 15;
+#pragma unroll
+  for (int it = 0; it < 4; ++it) {
+    const int q = wave + 4 * it;          // group of 4 k-rows (1 KiB)
+    const int krow = q * 4 + ksub;
+    const int lg = (pc >> 1) ^ tswz(krow);  // logical granule held by this physical slot
+    const int64_t r = r0 + lg * 16 + (pc & 1) * 8;
+    const int64_t k = k0 + krow;
+    const void* src = (k < kend && r < nrows) ? (const void*)(base + k * ld + r) : (const void*)g_zero16;
+    glds16(src, lds_tile + q * 1024);
+  }
+}
+
+typedef __attribute__((ext_vector_type(4))) short s16x4_t;
+__device__ inline Pack<bf16> frag_t(const char* tile, int rl /* fragment's first row in the tile, multiple of 16 */, int kk,
+                                    int fi, int fg) {
+  union {
+    Pack<bf16> p;
+    s16x4_t h[2];
+  } u;
+#pragma unroll
+  for (int t = 0; t < 2; ++t) {
+    const int krow = kk * 32 + fg * 8 + t * 4 + (fi >> 2);
+    const int off = krow * 256 + (((rl >> 4) ^ tswz(krow)) << 5) + ((fi & 3) << 3);
+    u.h[t] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t*)(tile + off));
+  }
+  return u.p;
+}
+
+template <typename T, bool TR>
+__device__ inline void stage_any(const T* __restrict__ base, int64_t ld, int64_t r0, int64_t nrows, int64_t k0, int64_t kend,
+                                 char* tile, int wave, int lane) {
+  if constexpr (TR) {
+    static_assert(sizeof(T) == 2, "T-mode operands are bf16 only");
+    stage_tile_t((const bf16*)base, ld, r0, nrows, k0, kend, tile, wave, lane);
+  } else {
+    stage_tile<T>(base, ld, r0, nrows, k0, kend, tile, wave, lane);
+  }
+}
+template <typename T, bool TR>
+__device__ inline Pack<T> frag_any(const char* tile, int row0, int kk, int fi, int fg) {
+  if constexpr (TR) {
+    return frag_t(tile, row0, kk, fi, fg);
+  } else {
+    return *reinterpret_cast<const Pack<T>*>(tile + lds_tile_off(row0 + fi, kk * 4 + fg));
+  }
+}
+
+template <typename T, bool TA, bool TB>
 __global__ __launch_bounds__(256) void gemm_nt_kernel(const T* __restrict__ A, int64_t lda, const T* __restrict__ B,
                                                       int64_t ldb, T* C, int64_t ldc, const T* R, int64_t ldr, int64_t M, int64_t N,
                                                       int64_t K, float alpha, float beta, int tiles_n, int nwg,
@@ -84,8 +143,8 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const T* __restrict__ A, i
   const int fi = lane & 15, fg = lane >> 4;
 
   if (nt > 0) {
-    stage_tile<T>(A, lda, m0, M, kbeg, kend, smem, wave, lane);
-    stage_tile<T>(B, ldb, n0, N, kbeg, kend, smem + TILE_BYTES, wave, lane);
+    stage_any<T, TA>(A, lda, m0, M, kbeg, kend, smem, wave, lane);
+    stage_any<T, TB>(B, ldb, n0, N, kbeg, kend, smem + TILE_BYTES, wave, lane);
   }
   __syncthreads();
   for (int t = 0; t < nt; ++t) {
@@ -93,8 +152,8 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const T* __restrict__ A, i
     char* nxt = smem + ((t + 1) & 1) * 2 * TILE_BYTES;
     if (t + 1 < nt) {
       const int64_t k0 = kbeg + (int64_t)(t + 1) * BK;
-      stage_tile<T>(A, lda, m0, M, k0, kend, nxt, wave, lane);
-      stage_tile<T>(B, ldb, n0, N, k0, kend, nxt + TILE_BYTES, wave, lane);
+      stage_any<T, TA>(A, lda, m0, M, k0, kend, nxt, wave, lane);
+      stage_any<T, TB>(B, ldb, n0, N, k0, kend, nxt + TILE_BYTES, wave, lane);
     }
     const char* tA = cur;
     const char* tB = cur + TILE_BYTES;
@@ -103,8 +162,8 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const T* __restrict__ A, i
       Pack<T> fx[4], fw[4];
 #pragma unroll
       for (int f = 0; f < 4; ++f) {
-        fw[f] = *reinterpret_cast<const Pack<T>*>(tB + lds_tile_off(wn * 64 + f * 16 + fi, kk * 4 + fg));
-        fx[f] = *reinterpret_cast<const Pack<T>*>(tA + lds_tile_off(wm * 64 + f * 16 + fi, kk * 4 + fg));
+        fw[f] = frag_any<T, TB>(tB, wn * 64 + f * 16, kk, fi, fg);
+        fx[f] = frag_any<T, TA>(tA, wm * 64 + f * 16, kk, fi, fg);
       }
 #pragma unroll
       for (int fn = 0; fn < 4; ++fn)
@@ -189,14 +248,16 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
 }
 
 template <typename T>
-static int gemm_launch(const void* A, int64_t lda, const void* B, int64_t ldb, void* C, int64_t ldc, const void* R,
-                       int64_t ldr, int64_t M, int64_t N, int64_t K, float alpha, float beta, int splitk,
+static int gemm_launch(const void* A, int64_t lda, int ta, const void* B, int64_t ldb, int tb, void* C, int64_t ldc,
+                       const void* R, int64_t ldr, int64_t M, int64_t N, int64_t K, float alpha, float beta, int splitk,
                        void* workspace, hipStream_t st) {
   constexpr int EPC = 16 / sizeof(T);
   constexpr int BK = 128 / sizeof(T);
   MH_REQUIRE(M > 0 && N > 0 && K > 0, "gemm: empty problem M=%ld N=%ld K=%ld", (long)M, (long)N, (long)K);
-  MH_REQUIRE(K % EPC == 0 && lda % EPC == 0 && ldb % EPC == 0, "gemm: K/lda/ldb must be multiples of %d elements (K=%ld lda=%ld ldb=%ld)",
-             EPC, (long)K, (long)lda, (long)ldb);
+  MH_REQUIRE(lda % EPC == 0 && ldb % EPC == 0, "gemm: lda/ldb must be multiples of %d elements (lda=%ld ldb=%ld)", EPC,
+             (long)lda, (long)ldb);
+  MH_REQUIRE(sizeof(T) == 2 || (!ta && !tb), "gemm: contraction-major (transposed) operands are bf16 only");
+  MH_REQUIRE((ta ? lda >= M : lda >= K) && (tb ? ldb >= N : ldb >= K), "gemm: leading dimension smaller than the row length");
   MH_REQUIRE(((uintptr_t)A & 15) == 0 && ((uintptr_t)B & 15) == 0, "gemm: A/B must be 16-byte aligned");
   MH_REQUIRE(beta == 0.f || R != nullptr, "gemm: beta != 0 needs R");
   const int64_t tiles_m = (M + BM - 1) / BM, tiles_n = (N + BN - 1) / BN;
@@ -207,8 +268,18 @@ static int gemm_launch(const void* A, int64_t lda, const void* B, int64_t ldb, v
   MH_REQUIRE(splitk == 1 || workspace != nullptr, "gemm: split-K needs a workspace");
   const int nwg = (int)(tiles_m * tiles_n);
   dim3 grid(nwg, 1, splitk);
-  gemm_nt_kernel<T><<<grid, 256, 0, st>>>((const T*)A, lda, (const T*)B, ldb, (T*)C, ldc, (const T*)R, ldr, M, N, K,
-                                            alpha, beta, (int)tiles_n, nwg, kps, (float*)workspace);
+#define MH_GEMM_LAUNCH(TA_, TB_)                                                                                      \
+  gemm_nt_kernel<T, TA_, TB_><<<grid, 256, 0, st>>>((const T*)A, lda, (const T*)B, ldb, (T*)C, ldc, (const T*)R, ldr, M, N, \
+                                                     K, alpha, beta, (int)tiles_n, nwg, kps, (float*)workspace)
+  if constexpr (sizeof(T) == 2) {
+    if (ta && tb) MH_GEMM_LAUNCH(true, true);
+    else if (ta) MH_GEMM_LAUNCH(true, false);
+    else if (tb) MH_GEMM_LAUNCH(false, true);
+    else MH_GEMM_LAUNCH(false, false);
+  } else {
+    MH_GEMM_LAUNCH(false, false);
+  }
+#undef MH_GEMM_LAUNCH
   MH_LAUNCH_CHECK();
   return MH_OK;
 }
@@ -234,16 +305,22 @@ extern "C" int mh_gemm_splitk_reduce(const void* workspace, void* C, int64_t ldc
   return MH_ERR_ARG;
 }
 
+extern "C" int mh_gemm(const void* A, int64_t lda, int transA, const void* B, int64_t ldb, int transB, void* C,
+                       int64_t ldc, const void* R, int64_t ldr, int64_t M, int64_t N, int64_t K, float alpha, float beta,
+                       int dtype, int splitk, void* workspace, void* stream) {
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == MH_BF16)
+    return gemm_launch<bf16>(A, lda, transA, B, ldb, transB, C, ldc, R, ldr, M, N, K, alpha, beta, splitk, workspace, st);
+  if (dtype == MH_F32)
+    return gemm_launch<float>(A, lda, transA, B, ldb, transB, C, ldc, R, ldr, M, N, K, alpha, beta, splitk, workspace, st);
+  mh_set_error("gemm: bad dtype %d", dtype);
+  return MH_ERR_ARG;
+}
+
 extern "C" int mh_gemm_nt(const void* A, int64_t lda, const void* B, int64_t ldb, void* C, int64_t ldc,
                           const void* R, int64_t ldr, int64_t M, int64_t N, int64_t K, float alpha, float beta,
                           int dtype, int splitk, void* workspace, void* stream) {
-  hipStream_t st = (hipStream_t)stream;
-  if (dtype == MH_BF16)
-    return gemm_launch<bf16>(A, lda, B, ldb, C, ldc, R, ldr, M, N, K, alpha, beta, splitk, workspace, st);
-  if (dtype == MH_F32)
-    return gemm_launch<float>(A, lda, B, ldb, C, ldc, R, ldr, M, N, K, alpha, beta, splitk, workspace, st);
-  mh_set_error("gemm: bad dtype %d", dtype);
-  return MH_ERR_ARG;
+  return mh_gemm(A, lda, 0, B, ldb, 0, C, ldc, R, ldr, M, N, K, alpha, beta, dtype, splitk, workspace, stream);
 }
 
 // ---- transpose: out[c][r] = in[r][c]; 64x64 tiles through LDS, 16-byte global accesses both ways ----

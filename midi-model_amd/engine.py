@@ -88,12 +88,9 @@ def _check_heads(spec: StackSpec):
 
 
 def linear_wgrad(dy: torch.Tensor, x: torch.Tensor, dw: torch.Tensor, accumulate: bool):
-    """dw[N,K] (+)= dy[M,N]^T @ x[M,K]: the contraction runs over the M rows, so both operands are re-laid
-    out contraction-major first (mh_transpose), then the same NT kernel runs with split-K."""
-    M = dy.shape[0]
-    dyT = ops.transpose(dy)            # [N, Mp]
-    xT = ops.transpose(x)              # [K, Mp]
-    ops.gemm_nt(dyT, xT, dw, K=dyT.shape[1], beta=1.0 if accumulate else 0.0)
+    """dw[N,K] (+)= dy[M,N]^T @ x[M,K]: the contraction runs over the M rows, i.e. both operands are
+    contraction-major as they lie in HBM; the GEMM reads them in that form (split-K over M)."""
+    ops.gemm_nt(dy, x, dw, K=dy.shape[0], ta=True, tb=True, beta=1.0 if accumulate else 0.0)
 
 
 # --------------------------------------------------------------------------------------------------
@@ -145,7 +142,7 @@ def stack_forward(spec: StackSpec, W: StackTensors, x: torch.Tensor, nseq: int, 
     return y, ((saved, x, rstdf, nseq, slen) if save else None)
 
 
-def stack_backward(spec: StackSpec, W: StackTensors, WT: StackTensors, G: StackTensors, ctx, dy: torch.Tensor,
+def stack_backward(spec: StackSpec, W: StackTensors, G: StackTensors, ctx, dy: torch.Tensor,
                    rope: RopeTable, accumulate: bool, on_layer_done: Optional[Callable[[int], None]] = None):
     """dy = d loss / d last_hidden_state  ->  d loss / d inputs_embeds; parameter gradients go to G
     (overwritten, or added to when `accumulate`).  `on_layer_done(i)` fires when layer i's gradients are
@@ -156,24 +153,24 @@ def stack_backward(spec: StackSpec, W: StackTensors, WT: StackTensors, G: StackT
     dx = _empty((M, D), dy)
     ops.rmsnorm_bwd(x_last, W.norm, rstdf, dy, None, dx, G.norm, accumulate)
     for li in range(len(W.layers) - 1, -1, -1):
-        lw, lt, lg = W.layers[li], WT.layers[li], G.layers[li]
+        lw, lg = W.layers[li], G.layers[li]
         x, rstd1, h1, qkv, o, lse, x2, rstd2, h2, gu, a = saved[li]
         # ---- MLP ----
         da = _empty((M, I), dy)
-        ops.gemm_nt(dx, lt.wd, da)                      # lt.wd = wd^T [I, D]
+        ops.gemm_nt(dx, lw.wd, da, tb=True)             # d a = dx @ wd      (wd [D, I] read contraction-major)
         linear_wgrad(dx, a, lg.wd, accumulate)
         dgu = _empty((M, 2 * I), dy)
         ops.swiglu_bwd(gu, da, dgu)
         del da
         dh2 = _empty((M, D), dy)
-        ops.gemm_nt(dgu, lt.wgu, dh2)                   # lt.wgu = wgu^T [D, 2I]
+        ops.gemm_nt(dgu, lw.wgu, dh2, tb=True)          # d h2 = dgu @ wgu
         linear_wgrad(dgu, h2, lg.wgu, accumulate)
         del dgu
         dx2 = _empty((M, D), dy)
         ops.rmsnorm_bwd(x2, lw.n2, rstd2, dh2, dx, dx2, lg.n2, accumulate)
         # ---- attention ----
         do = dh2                                        # reuse
-        ops.gemm_nt(dx2, lt.wo, do)                     # lt.wo = wo^T [D, D]
+        ops.gemm_nt(dx2, lw.wo, do, tb=True)            # d o = dx2 @ wo
         linear_wgrad(dx2, o, lg.wo, accumulate)
         dqkv = _empty((M, 3 * D), dy)
         if spec.kind == "event":
@@ -182,7 +179,7 @@ def stack_backward(spec: StackSpec, W: StackTensors, WT: StackTensors, G: StackT
             ops.tokattn_bwd(qkv, do, dqkv, nseq, slen, H, spec.scale)
         ops.rope_(dqkv, rope.cos, rope.sin, slen, 0, H, spec.hd, -1)
         dh1 = do
-        ops.gemm_nt(dqkv, lt.wqkv, dh1)                 # lt.wqkv = wqkv^T [D, 3D]
+        ops.gemm_nt(dqkv, lw.wqkv, dh1, tb=True)        # d h1 = dqkv @ wqkv
         linear_wgrad(dqkv, h1, lg.wqkv, accumulate)
         del dqkv
         ops.rmsnorm_bwd(x, lw.n1, rstd1, dh1, dx2, dx, lg.n1, accumulate)

@@ -219,46 +219,6 @@ class MIDIModel(nn.Module):
             self._g_lm = self._flat_grad[off:off + n].view(self.lm_head.weight.shape)
         return self._flat_grad
 
-    def _version(self) -> int:
-        return sum(p._version for p in self.parameters())
-
-    def transposed(self):
-        """[in, out] copies of every projection matrix (the dgrad operands), refreshed when parameters changed."""
-        ver = self._version()
-        if self._wt is not None and self._wt_version == ver:
-            return self._wt
-        if self._wt is None:
-            buf = torch.empty(self._n_mat, dtype=self.dtype, device=self.device)
-            views = {k: self._stack_views_T(k, buf) for k in ("net", "net_token")}
-            lmT = torch.zeros((self.config.n_embd, self.vocab_padded), dtype=self.dtype, device=self.device)
-            self._wt = (views, lmT)
-        views, lmT = self._wt
-        for k in ("net", "net_token"):
-            for lw, lt in zip(self._W[k].layers, views[k].layers):
-                ops.transpose(lw.wqkv, lt.wqkv)
-                ops.transpose(lw.wo, lt.wo)
-                ops.transpose(lw.wgu, lt.wgu)
-                ops.transpose(lw.wd, lt.wd)
-        ops.transpose(self.lm_head.weight.data, lmT)
-        self._wt_version = ver
-        return self._wt
-
-    def _stack_views_T(self, pre: str, buf: torch.Tensor) -> StackTensors:
-        spec = self._specs[pre]
-        D, I = spec.D, spec.I
-
-        def view(name, rows, cols):
-            off, _, _ = self._offsets[name]
-            return buf[off:off + rows * cols].view(rows, cols)
-
-        st = StackTensors()
-        for i in range(spec.L):
-            b = f"{pre}.layers.{i}."
-            st.layers.append(LayerTensors(
-                wqkv=view(b + "self_attn.q_proj.weight", D, 3 * D), wo=view(b + "self_attn.o_proj.weight", D, D),
-                wgu=view(b + "mlp.gate_proj.weight", D, 2 * I), wd=view(b + "mlp.down_proj.weight", I, D)))
-        return st
-
     # ------------------------------------------------------------------------------ reference methods
     def load_merge_lora(self, model_id):
         raise NotImplementedError("LoRA merge (midi_model.py:109-114) needs `peft`; out of scope of the HIP path")

@@ -51,11 +51,26 @@ def _pick_splitk(M: int, N: int, K: int) -> int:
 
 
 def gemm_nt(a: torch.Tensor, b: torch.Tensor, out: torch.Tensor, *, K: Optional[int] = None, alpha: float = 1.0,
-            beta: float = 0.0, res: Optional[torch.Tensor] = None, splitk: int = 0) -> torch.Tensor:
-    """out[M,N] = alpha * a[M,K] @ b[N,K]^T + beta * res   (res defaults to `out` when beta != 0)."""
+            beta: float = 0.0, res: Optional[torch.Tensor] = None, splitk: int = 0, ta: bool = False,
+            tb: bool = False) -> torch.Tensor:
+    """out[M,N] = alpha * A @ B^T + beta * res   (res defaults to `out` when beta != 0).
+
+    A is a[M,K] (or, with ``ta``, stored contraction-major as a[K,M]); B is b[N,K] (with ``tb``: b[K,N]).
+    The contraction-major forms are what dgrad / wgrad present; bf16 feeds them to the kernel as they lie
+    (LDS transpose reads), the fp32 verification mode re-lays them out with mh_transpose first."""
     M, N = out.shape
-    K = a.shape[1] if K is None else K
-    assert a.shape[0] == M and b.shape[0] == N and a.shape[1] >= K and b.shape[1] >= K, (a.shape, b.shape, out.shape, K)
+    if (ta or tb) and out.dtype != torch.bfloat16:
+        K = K if K is not None else (a.shape[0] if ta else a.shape[1])
+        if ta:
+            a = transpose(a[:K])  # [M, K rounded up to 8], zero padded
+        if tb:
+            b = transpose(b[:K])
+        ta = tb = False
+    if K is None:
+        K = a.shape[0] if ta else a.shape[1]
+    ka, ma = (a.shape[0], a.shape[1]) if ta else (a.shape[1], a.shape[0])
+    kb, nb = (b.shape[0], b.shape[1]) if tb else (b.shape[1], b.shape[0])
+    assert ma >= M and nb >= N and ka >= K and kb >= K, (a.shape, b.shape, out.shape, K, ta, tb)
     assert a.dtype == b.dtype == out.dtype
     if beta != 0.0 and res is None:
         res = out
@@ -68,11 +83,11 @@ def gemm_nt(a: torch.Tensor, b: torch.Tensor, out: torch.Tensor, *, K: Optional[
     if prof is not None:  # bench.py: HIP events on the launch stream around every projection GEMM
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-    lib().call("mh_gemm_nt", _p(a), _rowmajor(a), _p(b), _rowmajor(b), _p(out), _rowmajor(out), _p(res),
+    lib().call("mh_gemm", _p(a), _rowmajor(a), int(ta), _p(b), _rowmajor(b), int(tb), _p(out), _rowmajor(out), _p(res),
                _rowmajor(res) if res is not None else 0, M, N, K, alpha, beta, dt(out), splitk, _p(ws), _stream())
     if prof is not None:
         e1.record()
-        prof.append((e0, e1, 2.0 * M * N * K, (M, N, K, splitk)))
+        prof.append((e0, e1, 2.0 * M * N * K, (M, N, K, splitk, int(ta), int(tb))))
     if splitk > 1:
         lib().call("mh_gemm_splitk_reduce", _p(ws), _p(out), _rowmajor(out), _p(res),
                    _rowmajor(res) if res is not None else 0, M, N, splitk, alpha, beta, dt(out), _stream())

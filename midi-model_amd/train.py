@@ -163,7 +163,6 @@ class TrainMIDIModel(MIDIModel):
                   self.weight_decay, bc1, bc2, coef)
         ops.adamw(flat[nm:], g[nm:], o["m"][nm:], o["v"][nm:], lr, self.betas[0], self.betas[1], self.eps, 0.0,
                   bc1, bc2, coef)
-        self._wt_version = -1  # the kernels wrote through raw pointers: transposed weight copies are stale
         self.global_step += 1
         self._micro = 0
 
@@ -222,7 +221,6 @@ class TrainMIDIModel(MIDIModel):
         accumulate = backward and self._micro > 0
         if backward:
             self.grad_buffer()
-            views, lmT = self.transposed()
             dh = torch.empty((R, D), dtype=dty, device=dev)
         chunk = max(T, (self.ce_chunk_rows // T) * T)
         logits = torch.empty((min(chunk, R), Vp), dtype=dty, device=dev)
@@ -234,10 +232,11 @@ class TrainMIDIModel(MIDIModel):
             ops.cross_entropy(lg, V, targets[r0:r1], row_loss[r0:r1], lg if backward else None, inv,
                               argmax[r0:r1] if want_acc else None, tok.pad_id)
             if backward:
-                ops.gemm_nt(lg, lmT, dh[r0:r1])                       # d h = dlogits @ W_lm
-                dlT = ops.transpose(lg)                               # [Vp, rows]
-                hT = ops.transpose(h[r0:r1])                          # [D, rows]
-                ops.gemm_nt(dlT[:V], hT, self._g_lm, K=dlT.shape[1], beta=0.0 if (first and not accumulate) else 1.0)
+                # d h = dlogits @ W_lm and d W_lm += dlogits^T @ h, operands read as they lie (padding columns of
+                # dlogits are zero, so the contraction may run to the 8-aligned V)
+                ops.gemm_nt(lg, lm_w, dh[r0:r1], K=V, tb=True)
+                ops.gemm_nt(lg, h[r0:r1], self._g_lm, K=r1 - r0, ta=True, tb=True,
+                            beta=0.0 if (first and not accumulate) else 1.0)
                 first = False
         loss_sum = torch.empty(1, dtype=torch.float32, device=dev)
         ops.sum_f32(row_loss, loss_sum)
@@ -257,7 +256,7 @@ class TrainMIDIModel(MIDIModel):
         def tok_done(li: int):
             self._announce(red, *self._layer_range("net_token", li))
 
-        dseq = engine.stack_backward(tspec, Wt, views["net_token"], self._G["net_token"], ctx_tok, dh,
+        dseq = engine.stack_backward(tspec, Wt, self._G["net_token"], ctx_tok, dh,
                                      self.rope("net_token"), accumulate, tok_done)
         del dh, ctx_tok
         acc32 = torch.zeros((V, D), dtype=torch.float32, device=dev)
@@ -280,7 +279,7 @@ class TrainMIDIModel(MIDIModel):
         def net_done(li: int):
             self._announce(red, *self._layer_range("net", li))
 
-        dx = engine.stack_backward(spec, Wn, views["net"], self._G["net"], ctx_net, dhidden, self.rope("net"),
+        dx = engine.stack_backward(spec, Wn, self._G["net"], ctx_net, dhidden, self.rope("net"),
                                    accumulate, net_done)
         acc32.zero_()
         order, seg = ops.token_segments(x.view(-1), V)
@@ -350,4 +349,3 @@ class TrainMIDIModel(MIDIModel):
         import torch.distributed as dist
         if dist.is_available() and dist.is_initialized() and dist.get_world_size(self.process_group) > 1:
             dist.broadcast(self._flat, src=src, group=self.process_group)
-            self._wt_version = -1

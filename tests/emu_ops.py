@@ -19,10 +19,13 @@ def round_up(x, m):
     return (x + m - 1) // m * m
 
 
-def gemm_nt(a, b, out, *, K=None, alpha=1.0, beta=0.0, res=None, splitk=0):
-    K = a.shape[1] if K is None else K
+def gemm_nt(a, b, out, *, K=None, alpha=1.0, beta=0.0, res=None, splitk=0, ta=False, tb=False):
+    if K is None:
+        K = a.shape[0] if ta else a.shape[1]
     M, N = out.shape
-    acc = a[:M, :K].float() @ b[:N, :K].float().T
+    af = a[:K, :M].float().T if ta else a[:M, :K].float()
+    bf = b[:K, :N].float().T if tb else b[:N, :K].float()
+    acc = af @ bf.T
     r = alpha * acc
     if beta != 0.0:
         r = r + beta * (out if res is None else res).float()

@@ -56,6 +56,22 @@ def test_gemm_nt(ops, dtype, M, N, K):
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("ta,tb", [(False, True), (True, False), (True, True)])
+@pytest.mark.parametrize("M,N,K", [(128, 128, 64), (200, 136, 100), (1024, 256, 2051), (72, 1000, 333)])
+def test_gemm_contraction_major_operands(ops, dtype, ta, tb, M, N, K):
+    """dgrad / wgrad operand forms: A stored [K,M] and/or B stored [K,N] (bf16: LDS transpose reads, any K;
+    fp32: re-layout fallback).  Row lengths M, N are multiples of 8 as every model dimension is."""
+    Kn = (K + 7) // 8 * 8  # a non-transposed operand must be readable/zero up to the next multiple of 8
+    a = rnd((K, M), dtype, 41) if ta else torch.cat([rnd((M, K), dtype, 41), torch.zeros((M, Kn - K), dtype=dtype)], 1)
+    b = rnd((K, N), dtype, 42) if tb else torch.cat([rnd((N, K), dtype, 42), torch.zeros((N, Kn - K), dtype=dtype)], 1)
+    want = emu.gemm_nt(a, b, torch.empty((M, N), dtype=dtype), K=K, ta=ta, tb=tb)
+    for sk in (1, 3):
+        out = torch.full((M, N), float("nan"), dtype=dtype, device="cuda")
+        ops.gemm_nt(a.cuda(), b.cuda(), out, K=K, ta=ta, tb=tb, splitk=sk)
+        cmp(out, want, dtype, k=max(1.0, K / 256), what=f"gemm ta={ta} tb={tb} {M}x{N}x{K} splitk={sk}")
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
 def test_gemm_epilogue_views_splitk(ops, dtype):
     M, N, K = 300, 520, 2048 + 64
     a, b, r = rnd((M, K), dtype, 3), rnd((N, K), dtype, 4), rnd((M, N), dtype, 5)

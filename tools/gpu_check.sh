@@ -20,7 +20,8 @@ if [ "$MODE" != "quick" ]; then
 fi
 if [ "$MODE" = "prof" ]; then
   cd /tmp
-  timeout 1200 rocprofv3 --kernel-trace --stats -d "$GRAFT_REPO_ROOT/gpurun_out/prof" -o bench -- python "$GRAFT_REPO_ROOT/bench.py" --steps 2 --warmup 1 --no-cpu-baseline > "$GRAFT_REPO_ROOT/gpurun_out/prof_bench.log" 2>&1
+  rm -rf "$GRAFT_REPO_ROOT/gpurun_out/prof"
+  timeout 1200 rocprofv3 --kernel-trace --stats --output-format csv -d "$GRAFT_REPO_ROOT/gpurun_out/prof" -o bench -- python "$GRAFT_REPO_ROOT/bench.py" --steps 2 --warmup 1 --no-cpu-baseline > "$GRAFT_REPO_ROOT/gpurun_out/prof_bench.log" 2>&1
   echo "prof rc=$?" >> "$GRAFT_REPO_ROOT/gpurun_out/prof_bench.log"
 fi
 tail -5 gpurun_out/kernels.log gpurun_out/model.log gpurun_out/smoke.log
