@@ -31,6 +31,9 @@ extern "C" {
 
 const char* mh_last_error(void);
 int mh_version(void);
+/* runtime options: "gemm" = 0 (128x128 two-stage kernel) | 1 (256x128 three-stage pipelined kernel, bf16). */
+int mh_set_option(const char* name, int value);
+int mh_get_option(const char* name);
 
 /* ---- dense projections (MFMA) ------------------------------------------------------------------
  * C[M,N] = alpha * A[M,K] * B[N,K]^T + beta * R[M,N]      (R may be NULL when beta == 0; R may alias C)

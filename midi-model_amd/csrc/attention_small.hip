@@ -64,7 +64,7 @@ __global__ __launch_bounds__(256) void tokattn_fwd_kernel(const T* __restrict__ 
 #pragma unroll
       for (int j = 0; j <= i; ++j) {
         float p = q[i][0] * k[j][0] + q[i][1] * k[j][1] + q[i][2] * k[j][2] + q[i][3] * k[j][3];
-        s[j] = wave_sum(p) * scale;
+        s[j] = wave_sum_fast(p) * scale;
         mx = fmaxf(mx, s[j]);
       }
       float den = 0.f;
@@ -118,8 +118,8 @@ __global__ __launch_bounds__(256) void tokattn_bwd_kernel(const T* __restrict__ 
       for (int j = 0; j <= i; ++j) {
         float a = q[i][0] * k[j][0] + q[i][1] * k[j][1] + q[i][2] * k[j][2] + q[i][3] * k[j][3];
         float b = dO[i][0] * v[j][0] + dO[i][1] * v[j][1] + dO[i][2] * v[j][2] + dO[i][3] * v[j][3];
-        p[j] = wave_sum(a) * scale;
-        dp[j] = wave_sum(b);
+        p[j] = wave_sum_fast(a) * scale;
+        dp[j] = wave_sum_fast(b);
         mx = fmaxf(mx, p[j]);
       }
       float den = 0.f;

@@ -68,6 +68,26 @@ __device__ inline float wave_max(float v) {
   return v;
 }
 
+// All-lanes sum without touching the LDS pipe: 4 DPP steps inside each 16-lane row (quad swaps, half-row and
+// row mirrors), then v_permlane16_swap / v_permlane32_swap fold the rows (gfx950; semantics pinned by
+// tools/probe.hip: swap(x,x) returns {even rows|low half, odd rows|high half} replicated, so r[0]+r[1] is the
+// xor-16 / xor-32 sum in every lane).  ~10 VALU ops instead of 6 dependent ds_bpermute round trips.
+template <int CTRL> __device__ inline float dpp_move(float v) {
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, true));
+}
+__device__ inline float wave_sum_fast(float v) {
+  v += dpp_move<0xB1>(v);   // quad_perm(1,0,3,2)
+  v += dpp_move<0x4E>(v);   // quad_perm(2,3,0,1)
+  v += dpp_move<0x141>(v);  // row_half_mirror
+  v += dpp_move<0x140>(v);  // row_mirror
+  const int iv = __float_as_int(v);
+  auto a = __builtin_amdgcn_permlane16_swap(iv, iv, false, false);
+  v = __int_as_float(a[0]) + __int_as_float(a[1]);
+  const int iw = __float_as_int(v);
+  auto b = __builtin_amdgcn_permlane32_swap(iw, iw, false, false);
+  return __int_as_float(b[0]) + __int_as_float(b[1]);
+}
+
 // ---- LDS tile format shared by the MFMA kernels -----------------------------------------------
 // A tile is ROWS x 128 bytes (64 bf16 or 32 fp32 along the contraction).  The eight 16-byte chunks of
 // a row are XOR-swizzled with ((row>>1)&7) so that the ds_read_b128 fragment reads of both MFMA

@@ -247,6 +247,11 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
   }
 }
 
+extern int g_mh_gemm_variant;  // api.cpp
+int mh_gemm_pipe_bf16(const void* A, int64_t lda, int ta, const void* B, int64_t ldb, int tb, void* C, int64_t ldc,
+                      const void* R, int64_t ldr, int64_t M, int64_t N, int64_t K, float alpha, float beta, int splitk,
+                      void* workspace, hipStream_t st);  // gemm_pipe.hip
+
 template <typename T>
 static int gemm_launch(const void* A, int64_t lda, int ta, const void* B, int64_t ldb, int tb, void* C, int64_t ldc,
                        const void* R, int64_t ldr, int64_t M, int64_t N, int64_t K, float alpha, float beta, int splitk,
@@ -266,6 +271,10 @@ static int gemm_launch(const void* A, int64_t lda, int ta, const void* B, int64_
   // every z-slice gets a BK-aligned k range; slices past K (possible after the rounding) store zero partials
   const int64_t kps = ((K + splitk - 1) / splitk + BK - 1) / BK * BK;
   MH_REQUIRE(splitk == 1 || workspace != nullptr, "gemm: split-K needs a workspace");
+  if constexpr (sizeof(T) == 2) {
+    if (g_mh_gemm_variant == 1)
+      return mh_gemm_pipe_bf16(A, lda, ta, B, ldb, tb, C, ldc, R, ldr, M, N, K, alpha, beta, splitk, workspace, st);
+  }
   const int nwg = (int)(tiles_m * tiles_n);
   dim3 grid(nwg, 1, splitk);
 #define MH_GEMM_LAUNCH(TA_, TB_)                                                                                      \

@@ -1,0 +1,236 @@
+// Pipelined bf16 projection GEMM (second structure): C = alpha * opA(A) * opB(B)^T + beta * R.
+//
+// r01 run 2 measured the first structure (gemm.hip: 128x128 tile, 2 LDS stages, vmcnt(0)+barrier per K-step) at
+// 450-900 TFLOP/s over the model's shapes: every K-step exposes the full HBM/L2 latency of the tile it just
+// requested, hidden only by the second resident block.  This kernel keeps TWO K-tiles of LDS-DMA in flight:
+//   * 256x128 block tile, 8 waves (4 along M x 2 along N, each 64x64 = 4x4 v_mfma_f32_16x16x32_bf16 fragments),
+//     K-step 64, three LDS stages of 48 KiB (144 KiB, one block per CU, two waves per SIMD);
+//   * per K-step: s_waitcnt vmcnt(6) (all of this wave's loads except the newest tile have landed) -> raw
+//     s_barrier (everyone's tile t landed, everyone finished tile t-1) -> issue tile t+2 into the stage tile t-1
+//     vacated -> ds_read + MFMA on tile t.  No vmcnt(0) in the loop, loads span barriers
+//     (cdna_hip_programming.md "Pipelining across barriers": LDS-DMA data is ordered for a ds_read by the issuing
+//     waves' counted vmcnt followed by a barrier the reader has passed);
+//   * operands in either layout (row-major K-contiguous, or contraction-major via ds_read_b64_tr_b16), same LDS
+//     swizzles and zero-block tail handling as gemm.hip; same epilogue (swapped MFMA -> 8-byte stores, split-K).
+// Roofline: MFMA, 2.5 PFLOP/s dense bf16.
+#include "common.h"
+
+
+namespace {
+
+__device__ __attribute__((aligned(16))) char g_zero16[16];  // source of out-of-range chunks
+
+constexpr int PBM = 256, PBN = 128, PBK = 64;
+constexpr int A_BYTES = PBM * 128, B_BYTES = PBN * 128, STAGE_BYTES = A_BYTES + B_BYTES;  // 32 KiB + 16 KiB
+constexpr int NSTAGE = 3;
+constexpr int LDS_BYTES = NSTAGE * STAGE_BYTES;  // 147456
+constexpr int NWAVE = 8;
+
+typedef __attribute__((ext_vector_type(4))) short s16x4_t;
+
+__device__ inline int tswz(int krow) { return (krow & 3) | ((krow >> 1) & 4); }
+
+// row-major operand X[r][k]: tile ROWS x 128 B, 16-byte chunks swizzled by ((r>>1)&7)
+template <int ROWS>
+__device__ inline void stage_n(const bf16* __restrict__ base, int64_t ld, int64_t row0, int64_t nrows, int64_t k0, int64_t kend,
+                               char* tile, int wave, int lane) {
+  const int rsub = lane >> 3, pc = lane & 7;
+#pragma unroll
+  for (int it = 0; it < ROWS / 8 / NWAVE; ++it) {
+    const int g8 = wave + NWAVE * it;
+    const int r = g8 * 8 + rsub;
+    const int c = pc ^ ((r >> 1) & 7);
+    const int64_t grow = row0 + r;
+    const int64_t k = k0 + c * 8;
+    const void* src = (grow < nrows && k < kend) ? (const void*)(base + grow * ld + k) : (const void*)g_zero16;
+    glds16(src, tile + g8 * 1024);
+  }
+}
+
+// contraction-major operand X[k][r]: tile 64 k-rows x (2*ROWS) bytes, 32-byte granules swizzled by tswz(k)
+template <int ROWS>
+__device__ inline void stage_t(const bf16* __restrict__ base, int64_t ld, int64_t r0, int64_t nrows, int64_t k0, int64_t kend,
+                               char* tile, int wave, int lane) {
+  constexpr int CPR = ROWS / 8;        // 16-byte chunks per k-row
+  constexpr int KPI = 64 / CPR;        // k-rows per 1 KiB instruction
+  const int ksub = lane / CPR, pc = lane % CPR;
+#pragma unroll
+  for (int it = 0; it < ROWS / 8 / NWAVE; ++it) {
+    const int q = wave + NWAVE * it;
+    const int krow = q * KPI + ksub;
+    const int lg = (pc >> 1) ^ tswz(krow);
+    const int64_t r = r0 + lg * 16 + (pc & 1) * 8;
+    const int64_t k = k0 + krow;
+    const void* src = (k < kend && r < nrows) ? (const void*)(base + k * ld + r) : (const void*)g_zero16;
+    glds16(src, tile + q * 1024);
+  }
+}
+
+template <bool TR, int ROWS>
+__device__ inline bf16x8 frag(const char* tile, int row0, int kk, int fi, int fg) {
+  if constexpr (!TR) {
+    return *reinterpret_cast<const bf16x8*>(tile + lds_tile_off(row0 + fi, kk * 4 + fg));
+  } else {
+    union {
+      bf16x8 v;
+      s16x4_t h[2];
+    } u;
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      const int krow = kk * 32 + fg * 8 + t * 4 + (fi >> 2);
+      const int off = krow * (2 * ROWS) + (((row0 >> 4) ^ tswz(krow)) << 5) + ((fi & 3) << 3);
+      u.h[t] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t*)(tile + off));
+    }
+    return u.v;
+  }
+}
+
+template <bool TA, bool TB>
+__global__ __launch_bounds__(512) void gemm_pipe_kernel(const bf16* __restrict__ A, int64_t lda, const bf16* __restrict__ B,
+                                                        int64_t ldb, bf16* C, int64_t ldc, const bf16* R, int64_t ldr,
+                                                        int64_t M, int64_t N, int64_t K, float alpha, float beta, int tiles_n,
+                                                        int nwg, int64_t k_per_split, float* __restrict__ ws) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 1, wn = wave & 1;
+
+  const int bid = blockIdx.x;
+  const int q = nwg >> 3, r8 = nwg & 7, xcd = bid & 7;
+  const int swz = (xcd < r8 ? xcd * (q + 1) : r8 * (q + 1) + (xcd - r8) * q) + (bid >> 3);
+  const int tm = swz / tiles_n, tn = swz - tm * tiles_n;
+  const int64_t m0 = (int64_t)tm * PBM, n0 = (int64_t)tn * PBN;
+
+  const int64_t kbeg = (int64_t)blockIdx.z * k_per_split;
+  const int64_t kend = (kbeg + k_per_split < K) ? kbeg + k_per_split : K;
+  const int nt = (kend > kbeg) ? (int)((kend - kbeg + PBK - 1) / PBK) : 0;
+
+  f32x4 acc[4][4];
+#pragma unroll
+  for (int a = 0; a < 4; ++a)
+#pragma unroll
+    for (int b = 0; b < 4; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const int fi = lane & 15, fg = lane >> 4;
+
+  auto issue = [&](int t, int stage) {
+    char* buf = smem + stage * STAGE_BYTES;
+    const int64_t k0 = kbeg + (int64_t)t * PBK;
+    if constexpr (TA) stage_t<PBM>(A, lda, m0, M, k0, kend, buf, wave, lane);
+    else stage_n<PBM>(A, lda, m0, M, k0, kend, buf, wave, lane);
+    if constexpr (TB) stage_t<PBN>(B, ldb, n0, N, k0, kend, buf + A_BYTES, wave, lane);
+    else stage_n<PBN>(B, ldb, n0, N, k0, kend, buf + A_BYTES, wave, lane);
+  };
+  // every wave issues exactly 6 LDS-DMA instructions per K-tile (4 for A, 2 for B) in both layouts
+  if (nt > 0) issue(0, 0);
+  if (nt > 1) issue(1, 1);
+  int cur = 0;       // stage holding tile t
+  int fill = 2;      // stage tile t+2 goes to (= the one tile t-1 vacated)
+  for (int t = 0; t < nt; ++t) {
+    if (t + 1 < nt) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    if (t + 2 < nt) issue(t + 2, fill);
+    const char* tA = smem + cur * STAGE_BYTES;
+    const char* tB = tA + A_BYTES;
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+      bf16x8 fx[4], fw[4];
+#pragma unroll
+      for (int f = 0; f < 4; ++f) {
+        fw[f] = frag<TB, PBN>(tB, wn * 64 + f * 16, kk, fi, fg);
+        fx[f] = frag<TA, PBM>(tA, wm * 64 + f * 16, kk, fi, fg);
+      }
+      __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+      for (int fn = 0; fn < 4; ++fn)
+#pragma unroll
+        for (int fm = 0; fm < 4; ++fm)
+          acc[fn][fm] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw[fn], fx[fm], acc[fn][fm], 0, 0, 0);
+      __builtin_amdgcn_s_setprio(0);
+    }
+    cur = (cur == NSTAGE - 1) ? 0 : cur + 1;
+    fill = (fill == NSTAGE - 1) ? 0 : fill + 1;
+  }
+
+  // epilogue (identical to gemm.hip): lane (fi, fg) of fragment (fn, fm) holds C[m][n..n+3]
+  const bool partial = (gridDim.z > 1);
+  float* wsz = partial ? ws + (int64_t)blockIdx.z * M * N : nullptr;
+  const bool vec_ok = partial ? ((N & 3) == 0)
+                              : ((ldc & 3) == 0 && ((uintptr_t)C & 15) == 0 &&
+                                 (R == nullptr || ((ldr & 3) == 0 && ((uintptr_t)R & 15) == 0)));
+#pragma unroll
+  for (int fm = 0; fm < 4; ++fm) {
+    const int64_t m = m0 + wm * 64 + fm * 16 + fi;
+    if (m >= M) continue;
+#pragma unroll
+    for (int fn = 0; fn < 4; ++fn) {
+      const int64_t n = n0 + wn * 64 + fn * 16 + fg * 4;
+      if (n >= N) continue;
+      f32x4 v = acc[fn][fm];
+      if (partial) {
+        float* dst = wsz + m * N + n;
+        if (vec_ok && n + 3 < N) {
+          *reinterpret_cast<f32x4*>(dst) = v;
+        } else {
+          for (int e = 0; e < 4 && n + e < N; ++e) dst[e] = v[e];
+        }
+        continue;
+      }
+      if (vec_ok && n + 3 < N) {
+        if (R != nullptr && beta != 0.f) {
+          bf16x4 rv = *reinterpret_cast<const bf16x4*>(R + m * ldr + n);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] = alpha * v[e] + beta * (float)rv[e];
+        } else {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] = alpha * v[e];
+        }
+        bf16x4 o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[e] = (bf16)v[e];
+        *reinterpret_cast<bf16x4*>(C + m * ldc + n) = o;
+      } else {
+        for (int e = 0; e < 4 && n + e < N; ++e) {
+          float x = alpha * v[e];
+          if (R != nullptr && beta != 0.f) x += beta * (float)R[m * ldr + n + e];
+          C[m * ldc + n + e] = (bf16)x;
+        }
+      }
+    }
+  }
+}
+
+template <bool TA, bool TB>
+int launch_one(const void* A, int64_t lda, const void* B, int64_t ldb, void* C, int64_t ldc, const void* R, int64_t ldr,
+               int64_t M, int64_t N, int64_t K, float alpha, float beta, int splitk, void* workspace, hipStream_t st) {
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_pipe_kernel<TA, TB>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+    if (e != hipSuccess) {
+      mh_set_error("gemm_pipe: cannot raise dynamic LDS to %d bytes: %s", LDS_BYTES, hipGetErrorString(e));
+      return MH_ERR_LAUNCH;
+    }
+    attr_set = true;
+  }
+  const int64_t tiles_m = (M + PBM - 1) / PBM, tiles_n = (N + PBN - 1) / PBN;
+  const int nwg = (int)(tiles_m * tiles_n);
+  const int64_t kps = ((K + splitk - 1) / splitk + PBK - 1) / PBK * PBK;
+  dim3 grid(nwg, 1, splitk);
+  gemm_pipe_kernel<TA, TB><<<grid, 512, LDS_BYTES, st>>>((const bf16*)A, lda, (const bf16*)B, ldb, (bf16*)C, ldc, (const bf16*)R,
+                                                         ldr, M, N, K, alpha, beta, (int)tiles_n, nwg, kps, (float*)workspace);
+  MH_LAUNCH_CHECK();
+  return MH_OK;
+}
+
+}  // namespace
+
+// called by gemm.hip after argument validation (bf16 only)
+int mh_gemm_pipe_bf16(const void* A, int64_t lda, int ta, const void* B, int64_t ldb, int tb, void* C, int64_t ldc,
+                      const void* R, int64_t ldr, int64_t M, int64_t N, int64_t K, float alpha, float beta, int splitk,
+                      void* workspace, hipStream_t st) {
+  if (ta && tb) return launch_one<true, true>(A, lda, B, ldb, C, ldc, R, ldr, M, N, K, alpha, beta, splitk, workspace, st);
+  if (ta) return launch_one<true, false>(A, lda, B, ldb, C, ldc, R, ldr, M, N, K, alpha, beta, splitk, workspace, st);
+  if (tb) return launch_one<false, true>(A, lda, B, ldb, C, ldc, R, ldr, M, N, K, alpha, beta, splitk, workspace, st);
+  return launch_one<false, false>(A, lda, B, ldb, C, ldc, R, ldr, M, N, K, alpha, beta, splitk, workspace, st);
+}

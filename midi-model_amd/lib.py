@@ -39,7 +39,7 @@ def parse_header(path: str = HEADER) -> Dict[str, Tuple[str, List[Tuple[str, str
 
 def _to_ctype(t: str):
     if "*" in t:
-        return ctypes.c_void_p
+        return ctypes.c_char_p if "char" in t else ctypes.c_void_p
     t = t.replace("const", "").strip()
     return _CTYPES[t]
 

@@ -43,11 +43,28 @@ def round_up(x: int, m: int) -> int:
 
 
 # ---------------------------------------------------------------------------------------------- GEMM
+_gemm_variant = None
+
+
+def set_option(name: str, value: int) -> None:
+    """runtime kernel selection (see mh_set_option in include/midihip.h)"""
+    global _gemm_variant
+    lib().call("mh_set_option", name.encode(), int(value))
+    if name == "gemm":
+        _gemm_variant = int(value)
+
+
 def _pick_splitk(M: int, N: int, K: int) -> int:
-    tiles = ((M + 127) // 128) * ((N + 127) // 128)
-    if tiles >= 256 or K < 2048:
+    """Split the contraction when the output has too few tiles to fill 256 CUs (the weight-gradient shapes):
+    aim at >= 512 workgroups, keep >= 512 contraction elements per slice."""
+    global _gemm_variant
+    if _gemm_variant is None:
+        _gemm_variant = lib().cdll.mh_get_option(b"gemm")
+    bm = 256 if _gemm_variant == 1 else 128
+    tiles = ((M + bm - 1) // bm) * ((N + 127) // 128)
+    if tiles >= 384 or K < 1024:
         return 1
-    return int(max(1, min(64, 768 // tiles, K // 1024)))
+    return int(max(1, min(64, -(-512 // tiles), K // 512)))
 
 
 def gemm_nt(a: torch.Tensor, b: torch.Tensor, out: torch.Tensor, *, K: Optional[int] = None, alpha: float = 1.0,

@@ -26,6 +26,14 @@ def ops():
     return real
 
 
+@pytest.fixture(params=[0, 1], ids=["gemm128", "gemmpipe"])
+def gemm_variant(request, ops):
+    """run the GEMM tests against both projection kernels (gemm.hip / gemm_pipe.hip)"""
+    ops.set_option("gemm", request.param)
+    yield request.param
+    ops.set_option("gemm", 1)
+
+
 def rnd(shape, dtype, seed, scale=1.0):
     g = torch.Generator().manual_seed(seed)
     return (scale * torch.randn(shape, generator=g)).to(dtype)
@@ -46,7 +54,7 @@ def cmp(got, want, dtype, k=1.0, what=""):
 @pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("M,N,K", [(128, 128, 64), (256, 384, 256), (257, 200, 96), (1, 1024, 1024), (1000, 72, 8),
                                    (64, 3406, 256), (640, 1024, 4096)])
-def test_gemm_nt(ops, dtype, M, N, K):
+def test_gemm_nt(ops, gemm_variant, dtype, M, N, K):
     a, b = rnd((M, K), dtype, 1), rnd((N, K), dtype, 2)
     want = emu.gemm_nt(a, b, torch.empty((M, N), dtype=dtype))
     out = torch.full((M, N), float("nan"), dtype=dtype, device="cuda")
@@ -58,7 +66,7 @@ def test_gemm_nt(ops, dtype, M, N, K):
 @pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("ta,tb", [(False, True), (True, False), (True, True)])
 @pytest.mark.parametrize("M,N,K", [(128, 128, 64), (200, 136, 100), (1024, 256, 2051), (72, 1000, 333)])
-def test_gemm_contraction_major_operands(ops, dtype, ta, tb, M, N, K):
+def test_gemm_contraction_major_operands(ops, gemm_variant, dtype, ta, tb, M, N, K):
     """dgrad / wgrad operand forms: A stored [K,M] and/or B stored [K,N] (bf16: LDS transpose reads, any K;
     fp32: re-layout fallback).  Row lengths M, N are multiples of 8 as every model dimension is."""
     Kn = (K + 7) // 8 * 8  # a non-transposed operand must be readable/zero up to the next multiple of 8
@@ -72,7 +80,7 @@ def test_gemm_contraction_major_operands(ops, dtype, ta, tb, M, N, K):
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
-def test_gemm_epilogue_views_splitk(ops, dtype):
+def test_gemm_epilogue_views_splitk(ops, gemm_variant, dtype):
     M, N, K = 300, 520, 2048 + 64
     a, b, r = rnd((M, K), dtype, 3), rnd((N, K), dtype, 4), rnd((M, N), dtype, 5)
     # residual epilogue into a separate buffer
