@@ -15,14 +15,14 @@ void mh_set_error(const char* fmt, ...) {
 
 // ---- runtime options -------------------------------------------------------------------------------------
 // "gemm": 0 = first structure (128x128, 2 LDS stages), 1 = pipelined structure (256x128, 3 stages, counted
-// vmcnt; bf16 only).  Initial value from the environment variable MH_GEMM (default 1).
+// vmcnt; bf16 only).  Initial value from the environment variable MH_GEMM (default 0: the pipelined kernel is correct but measured slower, profiles/r01_run3).
 #include <stdlib.h>
 #include <string.h>
 static int env_int(const char* name, int dflt) {
   const char* v = getenv(name);
   return (v && *v) ? atoi(v) : dflt;
 }
-int g_mh_gemm_variant = env_int("MH_GEMM", 1);
+int g_mh_gemm_variant = env_int("MH_GEMM", 0);
 
 extern "C" int mh_set_option(const char* name, int value) {
   if (strcmp(name, "gemm") == 0) {

@@ -102,6 +102,21 @@ __device__ inline void glds16(const void* src, void* lds_rows8) {
   __builtin_amdgcn_global_load_lds((glb_void_t*)src, (lds_void_t*)lds_rows8, 16, 0, 0);
 }
 
+// Tile rasterisation for the GEMMs.  An XCD (private 4 MiB L2) runs a contiguous range of tile indices, and the
+// 32-64 tiles resident on it at one time are consecutive indices; walking GM tile-rows column by column makes
+// those tiles share GM A-panels and a few B-panels instead of one A-panel and EVERY B-panel (r01 PMC: the
+// row-major order re-streamed the whole 16 MiB weight for every 128-row panel of a [32768x8192x1024] GEMM,
+// 4.2 GB of L2 misses, L2 hit rate 49 %).
+__device__ inline void gemm_tile_of(int idx, int tiles_m, int tiles_n, int GM, int& tm, int& tn) {
+  const int width = GM * tiles_n;
+  const int gid = idx / width;
+  const int first = gid * GM;
+  const int gsize = (tiles_m - first < GM) ? tiles_m - first : GM;
+  const int rem = idx - gid * width;
+  tn = rem / gsize;
+  tm = first + (rem - tn * gsize);
+}
+
 // 32x32 MFMA row permutation: swap bits 2 and 3 of the row index.  Feeding operand row i from
 // tile row pi(i) makes accumulator registers 8t..8t+7 of lane half `hi` correspond to tile rows
 // 16t+8hi..16t+8hi+7, i.e. a contiguous 8-element run that is directly the next MFMA's operand.

@@ -127,7 +127,8 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const T* __restrict__ A, i
   const int bid = blockIdx.x;
   const int q = nwg >> 3, r8 = nwg & 7, xcd = bid & 7;
   const int swz = (xcd < r8 ? xcd * (q + 1) : r8 * (q + 1) + (xcd - r8) * q) + (bid >> 3);
-  const int tm = swz / tiles_n, tn = swz - tm * tiles_n;
+  int tm, tn;
+  gemm_tile_of(swz, nwg / tiles_n, tiles_n, 8, tm, tn);
   const int64_t m0 = (int64_t)tm * BM, n0 = (int64_t)tn * BN;
 
   const int64_t kbeg = (int64_t)blockIdx.z * k_per_split;

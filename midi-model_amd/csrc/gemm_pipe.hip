@@ -13,8 +13,9 @@
 //   * operands in either layout (row-major K-contiguous, or contraction-major via ds_read_b64_tr_b16), same LDS
 //     swizzles and zero-block tail handling as gemm.hip; same epilogue (swapped MFMA -> 8-byte stores, split-K).
 // Roofline: MFMA, 2.5 PFLOP/s dense bf16.
-#include "common.h"
+#include <limits.h>
 
+#include "common.h"
 
 namespace {
 
@@ -30,39 +31,63 @@ typedef __attribute__((ext_vector_type(4))) short s16x4_t;
 
 __device__ inline int tswz(int krow) { return (krow & 3) | ((krow >> 1) & 4); }
 
+// Per-lane staging context, computed once per block: for each of this wave's LDS-DMA instructions of a tile the
+// lane's source pointer at contraction offset 0 and the contraction limit below which its 16-byte chunk is in
+// range (INT_MIN for an out-of-range row).  Per K-tile a chunk then costs one compare, one 64-bit add and one
+// select instead of re-deriving rows, swizzles and bounds (r01 PMC: 3.7 VALU instructions per MFMA before).
+template <int ROWS>
+struct StageCtx {
+  static constexpr int NI = ROWS / 8 / NWAVE;
+  const bf16* p[NI];
+  int klim[NI];
+};
+
 // row-major operand X[r][k]: tile ROWS x 128 B, 16-byte chunks swizzled by ((r>>1)&7)
 template <int ROWS>
-__device__ inline void stage_n(const bf16* __restrict__ base, int64_t ld, int64_t row0, int64_t nrows, int64_t k0, int64_t kend,
-                               char* tile, int wave, int lane) {
+__device__ inline void stage_init_n(StageCtx<ROWS>& c, const bf16* __restrict__ base, int64_t ld, int64_t row0, int64_t nrows,
+                                    int64_t kend, int wave, int lane) {
   const int rsub = lane >> 3, pc = lane & 7;
 #pragma unroll
-  for (int it = 0; it < ROWS / 8 / NWAVE; ++it) {
-    const int g8 = wave + NWAVE * it;
-    const int r = g8 * 8 + rsub;
-    const int c = pc ^ ((r >> 1) & 7);
+  for (int it = 0; it < StageCtx<ROWS>::NI; ++it) {
+    const int r = (wave + NWAVE * it) * 8 + rsub;
+    const int ch = pc ^ ((r >> 1) & 7);
     const int64_t grow = row0 + r;
-    const int64_t k = k0 + c * 8;
-    const void* src = (grow < nrows && k < kend) ? (const void*)(base + grow * ld + k) : (const void*)g_zero16;
-    glds16(src, tile + g8 * 1024);
+    c.p[it] = base + (grow < nrows ? grow : 0) * ld + ch * 8;
+    c.klim[it] = (grow < nrows) ? (int)kend - ch * 8 : INT_MIN;
+  }
+}
+template <int ROWS>
+__device__ inline void stage_n(const StageCtx<ROWS>& c, int k0, char* tile, int wave) {
+#pragma unroll
+  for (int it = 0; it < StageCtx<ROWS>::NI; ++it) {
+    const void* src = (k0 < c.klim[it]) ? (const void*)(c.p[it] + k0) : (const void*)g_zero16;
+    glds16(src, tile + (wave + NWAVE * it) * 1024);
   }
 }
 
 // contraction-major operand X[k][r]: tile 64 k-rows x (2*ROWS) bytes, 32-byte granules swizzled by tswz(k)
 template <int ROWS>
-__device__ inline void stage_t(const bf16* __restrict__ base, int64_t ld, int64_t r0, int64_t nrows, int64_t k0, int64_t kend,
-                               char* tile, int wave, int lane) {
+__device__ inline void stage_init_t(StageCtx<ROWS>& c, const bf16* __restrict__ base, int64_t ld, int64_t r0, int64_t nrows,
+                                    int64_t kend, int wave, int lane) {
   constexpr int CPR = ROWS / 8;        // 16-byte chunks per k-row
   constexpr int KPI = 64 / CPR;        // k-rows per 1 KiB instruction
   const int ksub = lane / CPR, pc = lane % CPR;
 #pragma unroll
-  for (int it = 0; it < ROWS / 8 / NWAVE; ++it) {
-    const int q = wave + NWAVE * it;
-    const int krow = q * KPI + ksub;
+  for (int it = 0; it < StageCtx<ROWS>::NI; ++it) {
+    const int krow = (wave + NWAVE * it) * KPI + ksub;
     const int lg = (pc >> 1) ^ tswz(krow);
     const int64_t r = r0 + lg * 16 + (pc & 1) * 8;
-    const int64_t k = k0 + krow;
-    const void* src = (k < kend && r < nrows) ? (const void*)(base + k * ld + r) : (const void*)g_zero16;
-    glds16(src, tile + q * 1024);
+    c.p[it] = base + (int64_t)krow * ld + (r < nrows ? r : 0);
+    c.klim[it] = (r < nrows) ? (int)kend - krow : INT_MIN;
+  }
+}
+template <int ROWS>
+__device__ inline void stage_t(const StageCtx<ROWS>& c, int k0, int64_t ld, char* tile, int wave) {
+  const int64_t koff = (int64_t)k0 * ld;
+#pragma unroll
+  for (int it = 0; it < StageCtx<ROWS>::NI; ++it) {
+    const void* src = (k0 < c.klim[it]) ? (const void*)(c.p[it] + koff) : (const void*)g_zero16;
+    glds16(src, tile + (wave + NWAVE * it) * 1024);
   }
 }
 
@@ -98,7 +123,8 @@ __global__ __launch_bounds__(512) void gemm_pipe_kernel(const bf16* __restrict__
   const int bid = blockIdx.x;
   const int q = nwg >> 3, r8 = nwg & 7, xcd = bid & 7;
   const int swz = (xcd < r8 ? xcd * (q + 1) : r8 * (q + 1) + (xcd - r8) * q) + (bid >> 3);
-  const int tm = swz / tiles_n, tn = swz - tm * tiles_n;
+  int tm, tn;
+  gemm_tile_of(swz, nwg / tiles_n, tiles_n, 4, tm, tn);
   const int64_t m0 = (int64_t)tm * PBM, n0 = (int64_t)tn * PBN;
 
   const int64_t kbeg = (int64_t)blockIdx.z * k_per_split;
@@ -112,13 +138,19 @@ __global__ __launch_bounds__(512) void gemm_pipe_kernel(const bf16* __restrict__
     for (int b = 0; b < 4; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
   const int fi = lane & 15, fg = lane >> 4;
 
+  StageCtx<PBM> ca;
+  StageCtx<PBN> cb;
+  if constexpr (TA) stage_init_t<PBM>(ca, A, lda, m0, M, kend, wave, lane);
+  else stage_init_n<PBM>(ca, A, lda, m0, M, kend, wave, lane);
+  if constexpr (TB) stage_init_t<PBN>(cb, B, ldb, n0, N, kend, wave, lane);
+  else stage_init_n<PBN>(cb, B, ldb, n0, N, kend, wave, lane);
   auto issue = [&](int t, int stage) {
     char* buf = smem + stage * STAGE_BYTES;
-    const int64_t k0 = kbeg + (int64_t)t * PBK;
-    if constexpr (TA) stage_t<PBM>(A, lda, m0, M, k0, kend, buf, wave, lane);
-    else stage_n<PBM>(A, lda, m0, M, k0, kend, buf, wave, lane);
-    if constexpr (TB) stage_t<PBN>(B, ldb, n0, N, k0, kend, buf + A_BYTES, wave, lane);
-    else stage_n<PBN>(B, ldb, n0, N, k0, kend, buf + A_BYTES, wave, lane);
+    const int k0 = (int)kbeg + t * PBK;
+    if constexpr (TA) stage_t<PBM>(ca, k0, lda, buf, wave);
+    else stage_n<PBM>(ca, k0, buf, wave);
+    if constexpr (TB) stage_t<PBN>(cb, k0, ldb, buf + A_BYTES, wave);
+    else stage_n<PBN>(cb, k0, buf + A_BYTES, wave);
   };
   // every wave issues exactly 6 LDS-DMA instructions per K-tile (4 for A, 2 for B) in both layouts
   if (nt > 0) issue(0, 0);
