@@ -22,11 +22,16 @@ static int env_int(const char* name, int dflt) {
   const char* v = getenv(name);
   return (v && *v) ? atoi(v) : dflt;
 }
-int g_mh_gemm_variant = env_int("MH_GEMM", 0);
+int g_mh_gemm_variant = env_int("MH_GEMM", 3);
+int g_mh_gemm_ablate = 0;  // micro-benchmark only: bit0 = no tile loads after the first, bit1 = no LDS reads / MFMA
 
 extern "C" int mh_set_option(const char* name, int value) {
   if (strcmp(name, "gemm") == 0) {
     g_mh_gemm_variant = value;
+    return 0;
+  }
+  if (strcmp(name, "gemm_ablate") == 0) {
+    g_mh_gemm_ablate = value;
     return 0;
   }
   mh_set_error("unknown option %s", name);

@@ -110,7 +110,7 @@ __device__ inline bf16x8 frag(const char* tile, int row0, int kk, int fi, int fg
   }
 }
 
-template <bool TA, bool TB>
+template <bool TA, bool TB, bool PP>
 __global__ __launch_bounds__(512) void gemm_pipe_kernel(const bf16* __restrict__ A, int64_t lda, const bf16* __restrict__ B,
                                                         int64_t ldb, bf16* C, int64_t ldc, const bf16* R, int64_t ldr,
                                                         int64_t M, int64_t N, int64_t K, float alpha, float beta, int tiles_n,
@@ -157,6 +157,78 @@ __global__ __launch_bounds__(512) void gemm_pipe_kernel(const bf16* __restrict__
   if (nt > 1) issue(1, 1);
   int cur = 0;       // stage holding tile t
   int fill = 2;      // stage tile t+2 goes to (= the one tile t-1 vacated)
+  if constexpr (PP) {
+    // Ping-pong schedule.  Waves w and w+4 share a SIMD; group 0 (waves 0-3, rows 0-127) and group 1 (waves
+    // 4-7, rows 128-255) run the same two segments per K-tile — LOAD (fragments of tile t: LDS -> registers,
+    // then issue the LDS-DMA of tile t+2) and MFMA (32 matrix instructions on those registers) — but one segment
+    // apart, with one workgroup barrier between segments.  So on every SIMD one wave is in its MFMA segment
+    // while the other reads LDS / issues loads: the matrix pipe never waits for the LDS pipe of its own wave.
+    //   group 0:  [LOAD 0][MFMA 0][LOAD 1][MFMA 1] ...                 barrier b separates segments b-1 | b
+    //   group 1:  [ idle ][LOAD 0][MFMA 0][LOAD 1][MFMA 1] ...
+    // Ordering: tile t is read by LOAD(t) in segments 2t (group 0) and 2t+1 (group 1); every wave waits for its
+    // own LDS-DMA of tile t (vmcnt) before barrier 2t, and drains its ds_reads (lgkmcnt) at the end of a LOAD
+    // segment, so the stage of tile t-1 is free when tile t+2 is issued into it after barrier 2t.
+    const int grp = wave >> 2;
+    bf16x8 fx[2][4], fw[2][4];
+    auto load_frags = [&](int stage) {
+      const char* tA = smem + stage * STAGE_BYTES;
+      const char* tB = tA + A_BYTES;
+#pragma unroll
+      for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+        for (int f = 0; f < 4; ++f) {
+          fw[kk][f] = frag<TB, PBN>(tB, wn * 64 + f * 16, kk, fi, fg);
+          fx[kk][f] = frag<TA, PBM>(tA, wm * 64 + f * 16, kk, fi, fg);
+        }
+    };
+    auto mfma_all = [&]() {
+      __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+      for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+        for (int fn = 0; fn < 4; ++fn)
+#pragma unroll
+          for (int fm = 0; fm < 4; ++fm)
+            acc[fn][fm] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw[kk][fn], fx[kk][fm], acc[fn][fm], 0, 0, 0);
+      __builtin_amdgcn_s_setprio(0);
+    };
+    auto bar = [&]() {
+      __builtin_amdgcn_sched_barrier(0);
+      __builtin_amdgcn_s_barrier();
+      __builtin_amdgcn_sched_barrier(0);
+    };
+    auto wait_tile = [&](int t) {
+      if (t + 1 < nt) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    };
+    auto load_segment = [&](int t) {
+      load_frags(cur);
+      if (t + 2 < nt) issue(t + 2, fill);
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      cur = (cur == NSTAGE - 1) ? 0 : cur + 1;
+      fill = (fill == NSTAGE - 1) ? 0 : fill + 1;
+    };
+    if (grp == 0) {
+      for (int t = 0; t < nt; ++t) {
+        wait_tile(t);
+        bar();  // barrier 2t
+        load_segment(t);
+        bar();  // barrier 2t+1
+        mfma_all();
+      }
+      bar();    // barrier 2nt
+    } else {
+      for (int t = 0; t < nt; ++t) {
+        wait_tile(t);
+        bar();  // barrier 2t
+        if (t > 0) mfma_all();
+        bar();  // barrier 2t+1
+        load_segment(t);
+      }
+      bar();    // barrier 2nt
+      if (nt > 0) mfma_all();
+    }
+  } else
   for (int t = 0; t < nt; ++t) {
     if (t + 1 < nt) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -232,12 +304,12 @@ __global__ __launch_bounds__(512) void gemm_pipe_kernel(const bf16* __restrict__
   }
 }
 
-template <bool TA, bool TB>
+template <bool TA, bool TB, bool PP>
 int launch_one(const void* A, int64_t lda, const void* B, int64_t ldb, void* C, int64_t ldc, const void* R, int64_t ldr,
                int64_t M, int64_t N, int64_t K, float alpha, float beta, int splitk, void* workspace, hipStream_t st) {
   static bool attr_set = false;
   if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_pipe_kernel<TA, TB>),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_pipe_kernel<TA, TB, PP>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
     if (e != hipSuccess) {
       mh_set_error("gemm_pipe: cannot raise dynamic LDS to %d bytes: %s", LDS_BYTES, hipGetErrorString(e));
@@ -249,7 +321,7 @@ int launch_one(const void* A, int64_t lda, const void* B, int64_t ldb, void* C, 
   const int nwg = (int)(tiles_m * tiles_n);
   const int64_t kps = ((K + splitk - 1) / splitk + PBK - 1) / PBK * PBK;
   dim3 grid(nwg, 1, splitk);
-  gemm_pipe_kernel<TA, TB><<<grid, 512, LDS_BYTES, st>>>((const bf16*)A, lda, (const bf16*)B, ldb, (bf16*)C, ldc, (const bf16*)R,
+  gemm_pipe_kernel<TA, TB, PP><<<grid, 512, LDS_BYTES, st>>>((const bf16*)A, lda, (const bf16*)B, ldb, (bf16*)C, ldc, (const bf16*)R,
                                                          ldr, M, N, K, alpha, beta, (int)tiles_n, nwg, kps, (float*)workspace);
   MH_LAUNCH_CHECK();
   return MH_OK;
@@ -257,12 +329,16 @@ int launch_one(const void* A, int64_t lda, const void* B, int64_t ldb, void* C, 
 
 }  // namespace
 
-// called by gemm.hip after argument validation (bf16 only)
+// called by gemm.hip after argument validation (bf16 only); pingpong = 0: lockstep waves, 1: ping-pong wave groups
 int mh_gemm_pipe_bf16(const void* A, int64_t lda, int ta, const void* B, int64_t ldb, int tb, void* C, int64_t ldc,
                       const void* R, int64_t ldr, int64_t M, int64_t N, int64_t K, float alpha, float beta, int splitk,
-                      void* workspace, hipStream_t st) {
-  if (ta && tb) return launch_one<true, true>(A, lda, B, ldb, C, ldc, R, ldr, M, N, K, alpha, beta, splitk, workspace, st);
-  if (ta) return launch_one<true, false>(A, lda, B, ldb, C, ldc, R, ldr, M, N, K, alpha, beta, splitk, workspace, st);
-  if (tb) return launch_one<false, true>(A, lda, B, ldb, C, ldc, R, ldr, M, N, K, alpha, beta, splitk, workspace, st);
-  return launch_one<false, false>(A, lda, B, ldb, C, ldc, R, ldr, M, N, K, alpha, beta, splitk, workspace, st);
+                      void* workspace, int pingpong, hipStream_t st) {
+#define MH_PIPE(TA_, TB_)                                                                                                    \
+  return pingpong ? launch_one<TA_, TB_, true>(A, lda, B, ldb, C, ldc, R, ldr, M, N, K, alpha, beta, splitk, workspace, st)  \
+                  : launch_one<TA_, TB_, false>(A, lda, B, ldb, C, ldc, R, ldr, M, N, K, alpha, beta, splitk, workspace, st)
+  if (ta && tb) MH_PIPE(true, true);
+  if (ta) MH_PIPE(true, false);
+  if (tb) MH_PIPE(false, true);
+  MH_PIPE(false, false);
+#undef MH_PIPE
 }

@@ -1,0 +1,297 @@
+// Ping-pong bf16 projection GEMM, 256x256 block tile (third structure): C = alpha * opA(A) * opB(B)^T + beta * R.
+//
+// What the measurements of the first two structures said (profiles/r01_run3_*):
+//   * 128x128 tiles move 64 FLOP per byte staged L2 -> LDS: at 780 TFLOP/s the kernel already pulls 12 TB/s out of
+//     L2, and ablating either the loads or the MFMAs only removes 30 % of the time -> both sides matter;
+//   * every global_load_lds instruction costs its wave ~100+ issue cycles, so the loads per MFMA must drop;
+//   * a workgroup whose two waves per SIMD run in lockstep never overlaps LDS reads with MFMAs (256x128 pipelined
+//     kernel: slower than two independent 128x128 blocks), while the ping-pong schedule of gemm_pipe.hip does.
+// This kernel therefore uses
+//   * a 256x256 tile (128 FLOP per staged byte), 8 waves = 2 groups (M halves) x 4 (N quarters), wave tile 128x64:
+//     per 32-deep K-step a wave issues 4 LDS-DMA + 12 ds_read_b128 for 32 MFMAs (16x16x32);
+//   * K-step 32 (64-byte LDS rows) so a step's fragments are 48 VGPRs and four 32 KiB stages fit (128 KiB):
+//     three K-steps of LDS-DMA stay in flight, waited with counted vmcnt only;
+//   * the ping-pong schedule: waves w and w+4 share a SIMD and alternate LOAD(t) / MFMA(t) segments one segment
+//     apart, one workgroup barrier per segment (see gemm_pipe.hip for the ordering argument);
+//   * 64-byte-row LDS layout: chunk c of row r sits at r*64 + ((c ^ X[(r>>2)&3]) << 4), X = {0,3,2,1}: the four
+//     16-lane groups of a ds_read_b128 fragment read (rows i, chunk g) each hit 16 distinct 16-byte slots of the
+//     256-byte bank row; contraction-major operands keep the 32-byte-granule swizzle and ds_read_b64_tr_b16.
+// Roofline: MFMA, 2.5 PFLOP/s dense bf16.
+#include <limits.h>
+
+#include "common.h"
+
+namespace {
+
+__device__ __attribute__((aligned(16))) char g_zero16[16];  // source of out-of-range chunks
+
+constexpr int QBM = 256, QBN = 256, QBK = 32;
+constexpr int OP_BYTES = 256 * 64;             // one operand's K-step: 256 rows x 64 B (or 32 k-rows x 512 B)
+constexpr int STAGE_BYTES = 2 * OP_BYTES;      // 32 KiB
+constexpr int NSTAGE = 4;
+constexpr int LDS_BYTES = NSTAGE * STAGE_BYTES;  // 131072
+constexpr int NWAVE = 8;
+constexpr int NI = 2;                          // LDS-DMA instructions per wave per operand per K-step
+
+typedef __attribute__((ext_vector_type(4))) short s16x4_t;
+
+__device__ inline int tswz(int krow) { return (krow & 3) | ((krow >> 1) & 4); }
+__device__ inline int xswz(int row) { return (0x1230 >> (((row >> 2) & 3) * 4)) & 3; }  // {0,3,2,1}[(row>>2)&3]
+
+struct StageCtx {
+  const bf16* p[NI];
+  int klim[NI];
+};
+
+// row-major operand X[r][k]: K-step tile 256 rows x 64 B; one LDS-DMA instruction = 16 rows
+__device__ inline void stage_init_n(StageCtx& c, const bf16* __restrict__ base, int64_t ld, int64_t row0, int64_t nrows,
+                                    int64_t kend, int wave, int lane) {
+  const int rsub = lane >> 2, pc = lane & 3;
+#pragma unroll
+  for (int it = 0; it < NI; ++it) {
+    const int r = (wave + NWAVE * it) * 16 + rsub;
+    const int ch = pc ^ xswz(r);
+    const int64_t grow = row0 + r;
+    c.p[it] = base + (grow < nrows ? grow : 0) * ld + ch * 8;
+    c.klim[it] = (grow < nrows) ? (int)kend - ch * 8 : INT_MIN;
+  }
+}
+__device__ inline void stage_n(const StageCtx& c, int k0, char* tile, int wave) {
+#pragma unroll
+  for (int it = 0; it < NI; ++it) {
+    const void* src = (k0 < c.klim[it]) ? (const void*)(c.p[it] + k0) : (const void*)g_zero16;
+    glds16(src, tile + (wave + NWAVE * it) * 1024);
+  }
+}
+
+// contraction-major operand X[k][r]: K-step tile 32 k-rows x 512 B; one LDS-DMA instruction = 2 k-rows
+__device__ inline void stage_init_t(StageCtx& c, const bf16* __restrict__ base, int64_t ld, int64_t r0, int64_t nrows,
+                                    int64_t kend, int wave, int lane) {
+  const int ksub = lane >> 5, pc = lane & 31;
+#pragma unroll
+  for (int it = 0; it < NI; ++it) {
+    const int krow = (wave + NWAVE * it) * 2 + ksub;
+    const int lg = (pc >> 1) ^ tswz(krow);
+    const int64_t r = r0 + lg * 16 + (pc & 1) * 8;
+    c.p[it] = base + (int64_t)krow * ld + (r < nrows ? r : 0);
+    c.klim[it] = (r < nrows) ? (int)kend - krow : INT_MIN;
+  }
+}
+__device__ inline void stage_t(const StageCtx& c, int k0, int64_t ld, char* tile, int wave) {
+  const int64_t koff = (int64_t)k0 * ld;
+#pragma unroll
+  for (int it = 0; it < NI; ++it) {
+    const void* src = (k0 < c.klim[it]) ? (const void*)(c.p[it] + koff) : (const void*)g_zero16;
+    glds16(src, tile + (wave + NWAVE * it) * 1024);
+  }
+}
+
+template <bool TR>
+__device__ inline bf16x8 frag(const char* tile, int row0, int fi, int fg) {
+  if constexpr (!TR) {
+    const int row = row0 + fi;
+    return *reinterpret_cast<const bf16x8*>(tile + row * 64 + ((fg ^ xswz(row)) << 4));
+  } else {
+    union {
+      bf16x8 v;
+      s16x4_t h[2];
+    } u;
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      const int krow = fg * 8 + t * 4 + (fi >> 2);
+      const int off = krow * 512 + (((row0 >> 4) ^ tswz(krow)) << 5) + ((fi & 3) << 3);
+      u.h[t] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t*)(tile + off));
+    }
+    return u.v;
+  }
+}
+
+template <bool TA, bool TB>
+__global__ __launch_bounds__(512, 2) void gemm_pp256_kernel(const bf16* __restrict__ A, int64_t lda,
+                                                            const bf16* __restrict__ B, int64_t ldb, bf16* C, int64_t ldc,
+                                                            const bf16* R, int64_t ldr, int64_t M, int64_t N, int64_t K,
+                                                            float alpha, float beta, int tiles_n, int nwg,
+                                                            int64_t k_per_split, float* __restrict__ ws) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int grp = wave >> 2;      // M half (and ping-pong group: waves w, w+4 share a SIMD)
+  const int wn = wave & 3;        // N quarter
+
+  const int bid = blockIdx.x;
+  const int q = nwg >> 3, r8 = nwg & 7, xcd = bid & 7;
+  const int swz = (xcd < r8 ? xcd * (q + 1) : r8 * (q + 1) + (xcd - r8) * q) + (bid >> 3);
+  int tm, tn;
+  gemm_tile_of(swz, nwg / tiles_n, tiles_n, 4, tm, tn);
+  const int64_t m0 = (int64_t)tm * QBM, n0 = (int64_t)tn * QBN;
+
+  const int64_t kbeg = (int64_t)blockIdx.z * k_per_split;
+  const int64_t kend = (kbeg + k_per_split < K) ? kbeg + k_per_split : K;
+  const int nt = (kend > kbeg) ? (int)((kend - kbeg + QBK - 1) / QBK) : 0;
+
+  f32x4 acc[4][8];  // [fn][fm]: 64 columns x 128 rows of this wave
+#pragma unroll
+  for (int a = 0; a < 4; ++a)
+#pragma unroll
+    for (int b = 0; b < 8; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const int fi = lane & 15, fg = lane >> 4;
+
+  StageCtx ca, cb;
+  if constexpr (TA) stage_init_t(ca, A, lda, m0, M, kend, wave, lane);
+  else stage_init_n(ca, A, lda, m0, M, kend, wave, lane);
+  if constexpr (TB) stage_init_t(cb, B, ldb, n0, N, kend, wave, lane);
+  else stage_init_n(cb, B, ldb, n0, N, kend, wave, lane);
+  auto issue = [&](int t, int stage) {
+    char* buf = smem + stage * STAGE_BYTES;
+    const int k0 = (int)kbeg + t * QBK;
+    if constexpr (TA) stage_t(ca, k0, lda, buf, wave);
+    else stage_n(ca, k0, buf, wave);
+    if constexpr (TB) stage_t(cb, k0, ldb, buf + OP_BYTES, wave);
+    else stage_n(cb, k0, buf + OP_BYTES, wave);
+  };
+  // every wave issues exactly 4 LDS-DMA instructions per K-step; three steps stay in flight
+  if (nt > 0) issue(0, 0);
+  if (nt > 1) issue(1, 1);
+  if (nt > 2) issue(2, 2);
+  int cur = 0;   // stage of K-step t
+  int fill = 3;  // stage K-step t+3 goes to (the one step t-1 vacated)
+
+  bf16x8 fx[8], fw[4];
+  auto load_frags = [&](int stage) {
+    const char* tA = smem + stage * STAGE_BYTES;
+    const char* tB = tA + OP_BYTES;
+#pragma unroll
+    for (int f = 0; f < 4; ++f) fw[f] = frag<TB>(tB, wn * 64 + f * 16, fi, fg);
+#pragma unroll
+    for (int f = 0; f < 8; ++f) fx[f] = frag<TA>(tA, grp * 128 + f * 16, fi, fg);
+  };
+  auto mfma_all = [&]() {
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int fn = 0; fn < 4; ++fn)
+#pragma unroll
+      for (int fm = 0; fm < 8; ++fm)
+        acc[fn][fm] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw[fn], fx[fm], acc[fn][fm], 0, 0, 0);
+    __builtin_amdgcn_s_setprio(0);
+  };
+  auto bar = [&]() {
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+  };
+  auto wait_step = [&](int t) {  // this wave's LDS-DMA of step t has landed (newer steps may still be in flight)
+    if (t + 2 < nt) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    else if (t + 1 < nt) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  };
+  auto load_segment = [&](int t) {
+    load_frags(cur);
+    if (t + 3 < nt) issue(t + 3, fill);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    cur = (cur + 1) & (NSTAGE - 1);
+    fill = (fill + 1) & (NSTAGE - 1);
+  };
+  if (grp == 0) {
+    for (int t = 0; t < nt; ++t) {
+      wait_step(t);
+      bar();  // barrier 2t
+      load_segment(t);
+      bar();  // barrier 2t+1
+      mfma_all();
+    }
+    bar();    // barrier 2nt
+  } else {
+    for (int t = 0; t < nt; ++t) {
+      wait_step(t);
+      bar();  // barrier 2t
+      if (t > 0) mfma_all();
+      bar();  // barrier 2t+1
+      load_segment(t);
+    }
+    bar();    // barrier 2nt
+    if (nt > 0) mfma_all();
+  }
+
+  // epilogue: lane (fi, fg) of fragment (fn, fm) holds C[m][n..n+3], m = m0 + grp*128 + fm*16 + fi
+  const bool partial = (gridDim.z > 1);
+  float* wsz = partial ? ws + (int64_t)blockIdx.z * M * N : nullptr;
+  const bool vec_ok = partial ? ((N & 3) == 0)
+                              : ((ldc & 3) == 0 && ((uintptr_t)C & 15) == 0 &&
+                                 (R == nullptr || ((ldr & 3) == 0 && ((uintptr_t)R & 15) == 0)));
+#pragma unroll
+  for (int fm = 0; fm < 8; ++fm) {
+    const int64_t m = m0 + grp * 128 + fm * 16 + fi;
+    if (m >= M) continue;
+#pragma unroll
+    for (int fn = 0; fn < 4; ++fn) {
+      const int64_t n = n0 + wn * 64 + fn * 16 + fg * 4;
+      if (n >= N) continue;
+      f32x4 v = acc[fn][fm];
+      if (partial) {
+        float* dst = wsz + m * N + n;
+        if (vec_ok && n + 3 < N) {
+          *reinterpret_cast<f32x4*>(dst) = v;
+        } else {
+          for (int e = 0; e < 4 && n + e < N; ++e) dst[e] = v[e];
+        }
+        continue;
+      }
+      if (vec_ok && n + 3 < N) {
+        if (R != nullptr && beta != 0.f) {
+          bf16x4 rv = *reinterpret_cast<const bf16x4*>(R + m * ldr + n);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] = alpha * v[e] + beta * (float)rv[e];
+        } else {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] = alpha * v[e];
+        }
+        bf16x4 o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[e] = (bf16)v[e];
+        *reinterpret_cast<bf16x4*>(C + m * ldc + n) = o;
+      } else {
+        for (int e = 0; e < 4 && n + e < N; ++e) {
+          float x = alpha * v[e];
+          if (R != nullptr && beta != 0.f) x += beta * (float)R[m * ldr + n + e];
+          C[m * ldc + n + e] = (bf16)x;
+        }
+      }
+    }
+  }
+}
+
+template <bool TA, bool TB>
+int launch_one(const void* A, int64_t lda, const void* B, int64_t ldb, void* C, int64_t ldc, const void* R, int64_t ldr,
+               int64_t M, int64_t N, int64_t K, float alpha, float beta, int splitk, void* workspace, hipStream_t st) {
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_pp256_kernel<TA, TB>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+    if (e != hipSuccess) {
+      mh_set_error("gemm_pp256: cannot raise dynamic LDS to %d bytes: %s", LDS_BYTES, hipGetErrorString(e));
+      return MH_ERR_LAUNCH;
+    }
+    attr_set = true;
+  }
+  const int64_t tiles_m = (M + QBM - 1) / QBM, tiles_n = (N + QBN - 1) / QBN;
+  const int nwg = (int)(tiles_m * tiles_n);
+  const int64_t kps = ((K + splitk - 1) / splitk + QBK - 1) / QBK * QBK;
+  dim3 grid(nwg, 1, splitk);
+  gemm_pp256_kernel<TA, TB><<<grid, 512, LDS_BYTES, st>>>((const bf16*)A, lda, (const bf16*)B, ldb, (bf16*)C, ldc,
+                                                          (const bf16*)R, ldr, M, N, K, alpha, beta, (int)tiles_n, nwg, kps,
+                                                          (float*)workspace);
+  MH_LAUNCH_CHECK();
+  return MH_OK;
+}
+
+}  // namespace
+
+// called by gemm.hip after argument validation (bf16 only)
+int mh_gemm_pp256_bf16(const void* A, int64_t lda, int ta, const void* B, int64_t ldb, int tb, void* C, int64_t ldc,
+                       const void* R, int64_t ldr, int64_t M, int64_t N, int64_t K, float alpha, float beta, int splitk,
+                       void* workspace, hipStream_t st) {
+  if (ta && tb) return launch_one<true, true>(A, lda, B, ldb, C, ldc, R, ldr, M, N, K, alpha, beta, splitk, workspace, st);
+  if (ta) return launch_one<true, false>(A, lda, B, ldb, C, ldc, R, ldr, M, N, K, alpha, beta, splitk, workspace, st);
+  if (tb) return launch_one<false, true>(A, lda, B, ldb, C, ldc, R, ldr, M, N, K, alpha, beta, splitk, workspace, st);
+  return launch_one<false, false>(A, lda, B, ldb, C, ldc, R, ldr, M, N, K, alpha, beta, splitk, workspace, st);
+}

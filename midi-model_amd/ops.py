@@ -60,11 +60,13 @@ def _pick_splitk(M: int, N: int, K: int) -> int:
     global _gemm_variant
     if _gemm_variant is None:
         _gemm_variant = lib().cdll.mh_get_option(b"gemm")
-    bm = 256 if _gemm_variant == 1 else 128
-    tiles = ((M + bm - 1) // bm) * ((N + 127) // 128)
-    if tiles >= 384 or K < 1024:
+    bm = 256 if _gemm_variant in (1, 2, 3) else 128
+    bn = 256 if _gemm_variant == 3 else 128
+    tiles = ((M + bm - 1) // bm) * ((N + bn - 1) // bn)
+    per_cu = 1 if _gemm_variant in (1, 2, 3) else 2   # resident workgroups per CU of the active kernel
+    if tiles >= 192 * per_cu or K < 1024:
         return 1
-    return int(max(1, min(64, -(-512 // tiles), K // 512)))
+    return int(max(1, min(64, -(-256 * per_cu // tiles), K // 512)))
 
 
 def gemm_nt(a: torch.Tensor, b: torch.Tensor, out: torch.Tensor, *, K: Optional[int] = None, alpha: float = 1.0,

@@ -42,7 +42,8 @@ def main():
             b[:, K:] = 0
         ref = None
         for v in variants:
-            ops.set_option("gemm", v)
+            ops.set_option("gemm", v % 10)
+            ops.set_option("gemm_ablate", v // 10)  # 10 = no loads, 20 = no compute (variant 0 only; wrong results)
             for sk in splitks:
                 out = torch.empty((M, N), device=dev, dtype=torch.bfloat16)
                 ops.gemm_nt(a, b, out, K=K, ta=bool(ta), tb=bool(tb), splitk=sk)
