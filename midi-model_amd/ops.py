@@ -66,7 +66,9 @@ def _pick_splitk(M: int, N: int, K: int) -> int:
     per_cu = 1 if _gemm_variant in (1, 2, 3) else 2   # resident workgroups per CU of the active kernel
     if tiles >= 192 * per_cu or K < 1024:
         return 1
-    return int(max(1, min(64, -(-256 * per_cu // tiles), K // 512)))
+    # fill the 256 CUs once (or twice for the two-per-CU kernel) but never spill a few workgroups into an extra
+    # round: 48 tiles x 6 slices = 288 workgroups ran at 590 TFLOP/s where 48 x 5 = 240 fits one round
+    return int(max(1, min(64, (256 * per_cu) // tiles, K // 512)))
 
 
 def gemm_nt(a: torch.Tensor, b: torch.Tensor, out: torch.Tensor, *, K: Optional[int] = None, alpha: float = 1.0,

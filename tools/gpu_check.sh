@@ -24,5 +24,5 @@ if [ "$MODE" = "prof" ]; then
   timeout 1200 rocprofv3 --kernel-trace --stats --output-format csv -d "$GRAFT_REPO_ROOT/gpurun_out/prof" -o bench -- python "$GRAFT_REPO_ROOT/bench.py" --steps 2 --warmup 1 --no-cpu-baseline > "$GRAFT_REPO_ROOT/gpurun_out/prof_bench.log" 2>&1
   echo "prof rc=$?" >> "$GRAFT_REPO_ROOT/gpurun_out/prof_bench.log"
 fi
-tail -5 gpurun_out/kernels.log gpurun_out/model.log gpurun_out/smoke.log
+for f in kernels model smoke; do tail -n 3 gpurun_out/$f.log; done
 cat gpurun_out/bench.log 2>/dev/null | tail -2
