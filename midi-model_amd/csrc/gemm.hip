@@ -256,7 +256,13 @@ int mh_gemm_pipe_bf16(const void* A, int64_t lda, int ta, const void* B, int64_t
 
 int mh_gemm_pp256_bf16(const void* A, int64_t lda, int ta, const void* B, int64_t ldb, int tb, void* C, int64_t ldc,
                        const void* R, int64_t ldr, int64_t M, int64_t N, int64_t K, float alpha, float beta, int splitk,
-                       void* workspace, hipStream_t st);  // gemm_pp256.hip
+                       void* workspace, int gl, hipStream_t st);  // gemm_pp256.hip
+int mh_gemm_pp256p_bf16(const void* A, int64_t lda, int ta, const void* B, int64_t ldb, int tb, void* C, int64_t ldc,
+                        const void* R, int64_t ldr, int64_t M, int64_t N, int64_t K, float alpha, float beta, int splitk,
+                        void* workspace, hipStream_t st);  // gemm_pp256p.hip (persistent)
+int mh_gemm_w4_bf16(const void* A, int64_t lda, int ta, const void* B, int64_t ldb, int tb, void* C, int64_t ldc,
+                    const void* R, int64_t ldr, int64_t M, int64_t N, int64_t K, float alpha, float beta, int splitk,
+                    void* workspace, hipStream_t st);  // gemm_w4.hip (one wave per SIMD)
 
 template <typename T>
 static int gemm_launch(const void* A, int64_t lda, int ta, const void* B, int64_t ldb, int tb, void* C, int64_t ldc,
@@ -278,8 +284,13 @@ static int gemm_launch(const void* A, int64_t lda, int ta, const void* B, int64_
   const int64_t kps = ((K + splitk - 1) / splitk + BK - 1) / BK * BK;
   MH_REQUIRE(splitk == 1 || workspace != nullptr, "gemm: split-K needs a workspace");
   if constexpr (sizeof(T) == 2) {
-    if (g_mh_gemm_variant == 3)
-      return mh_gemm_pp256_bf16(A, lda, ta, B, ldb, tb, C, ldc, R, ldr, M, N, K, alpha, beta, splitk, workspace, st);
+    if (g_mh_gemm_variant == 7)
+      return mh_gemm_w4_bf16(A, lda, ta, B, ldb, tb, C, ldc, R, ldr, M, N, K, alpha, beta, splitk, workspace, st);
+    if (g_mh_gemm_variant == 6)
+      return mh_gemm_pp256p_bf16(A, lda, ta, B, ldb, tb, C, ldc, R, ldr, M, N, K, alpha, beta, splitk, workspace, st);
+    if (g_mh_gemm_variant >= 3 && g_mh_gemm_variant <= 5)  // 3: all 4 LDS-DMA in the LOAD segment, 4: 2+2, 5: all in MFMA
+      return mh_gemm_pp256_bf16(A, lda, ta, B, ldb, tb, C, ldc, R, ldr, M, N, K, alpha, beta, splitk, workspace,
+                                g_mh_gemm_variant == 3 ? 4 : (g_mh_gemm_variant == 4 ? 2 : 0), st);
     if (g_mh_gemm_variant == 1 || g_mh_gemm_variant == 2)
       return mh_gemm_pipe_bf16(A, lda, ta, B, ldb, tb, C, ldc, R, ldr, M, N, K, alpha, beta, splitk, workspace,
                                g_mh_gemm_variant == 2, st);

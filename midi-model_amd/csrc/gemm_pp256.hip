@@ -106,26 +106,34 @@ __device__ inline bf16x8 frag(const char* tile, int row0, int fi, int fg) {
   }
 }
 
-template <bool TA, bool TB>
+template <bool TA, bool TB, int GLX>
 __global__ __launch_bounds__(512, 2) void gemm_pp256_kernel(const bf16* __restrict__ A, int64_t lda,
                                                             const bf16* __restrict__ B, int64_t ldb, bf16* C, int64_t ldc,
                                                             const bf16* R, int64_t ldr, int64_t M, int64_t N, int64_t K,
                                                             float alpha, float beta, int tiles_n, int nwg,
                                                             int64_t k_per_split, float* __restrict__ ws) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int GL = GLX & 7, ABL = GLX >> 3;  // ABL (micro-benchmark only): 1 no LDS-DMA in the loop, 2 no reads, 4 no MFMA
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int grp = wave >> 2;      // M half (and ping-pong group: waves w, w+4 share a SIMD)
   const int wn = wave & 3;        // N quarter
 
-  const int bid = blockIdx.x;
-  const int q = nwg >> 3, r8 = nwg & 7, xcd = bid & 7;
-  const int swz = (xcd < r8 ? xcd * (q + 1) : r8 * (q + 1) + (xcd - r8) * q) + (bid >> 3);
+  // Work item order.  The hardware deals workgroups to the 8 XCDs round robin by linear id (x fastest, then z); an
+  // XCD has its own L2.  Give XCD x a CONTIGUOUS range of items, items numbered slice-major with the tiles of one
+  // K-slice in grouped raster order (gemm_tile_of): the ~32 workgroups resident on an XCD then share A/B panels.
+  // Without the slice-major part the 16 slices of a [1024 x 1024 x 262144] weight gradient put every tile of a slice
+  // on a different XCD and the kernel ran at the HBM/fabric rate (r01: LDS-DMA alone 529 us of 608 us).
+  const int nitems = nwg * (int)gridDim.z;
+  const int lin = blockIdx.x + nwg * (int)blockIdx.z;
+  const int q = nitems >> 3, r8 = nitems & 7, xcd = lin & 7;
+  const int item = (xcd < r8 ? xcd * (q + 1) : r8 * (q + 1) + (xcd - r8) * q) + (lin >> 3);
+  const int zslice = item / nwg;
   int tm, tn;
-  gemm_tile_of(swz, nwg / tiles_n, tiles_n, 4, tm, tn);
+  gemm_tile_of(item - zslice * nwg, nwg / tiles_n, tiles_n, 4, tm, tn);
   const int64_t m0 = (int64_t)tm * QBM, n0 = (int64_t)tn * QBN;
 
-  const int64_t kbeg = (int64_t)blockIdx.z * k_per_split;
+  const int64_t kbeg = (int64_t)zslice * k_per_split;
   const int64_t kend = (kbeg + k_per_split < K) ? kbeg + k_per_split : K;
   const int nt = (kend > kbeg) ? (int)((kend - kbeg + QBK - 1) / QBK) : 0;
 
@@ -141,37 +149,47 @@ __global__ __launch_bounds__(512, 2) void gemm_pp256_kernel(const bf16* __restri
   else stage_init_n(ca, A, lda, m0, M, kend, wave, lane);
   if constexpr (TB) stage_init_t(cb, B, ldb, n0, N, kend, wave, lane);
   else stage_init_n(cb, B, ldb, n0, N, kend, wave, lane);
-  auto issue = [&](int t, int stage) {
-    char* buf = smem + stage * STAGE_BYTES;
+  // LDS-DMA instruction j (0,1: A; 2,3: B) of K-step t; step t lives in stage t & 3
+  auto issue_one = [&](int t, int j) {
+    char* buf = smem + (t & (NSTAGE - 1)) * STAGE_BYTES + (j >> 1) * OP_BYTES + (wave + NWAVE * (j & 1)) * 1024;
     const int k0 = (int)kbeg + t * QBK;
-    if constexpr (TA) stage_t(ca, k0, lda, buf, wave);
-    else stage_n(ca, k0, buf, wave);
-    if constexpr (TB) stage_t(cb, k0, ldb, buf + OP_BYTES, wave);
-    else stage_n(cb, k0, buf + OP_BYTES, wave);
+    const StageCtx& c = (j >> 1) ? cb : ca;
+    const bool tr = (j >> 1) ? TB : TA;
+    const int64_t ld = (j >> 1) ? ldb : lda;
+    const bf16* p = c.p[j & 1] + (tr ? (int64_t)k0 * ld : (int64_t)k0);
+    const void* src = (k0 < c.klim[j & 1]) ? (const void*)p : (const void*)g_zero16;
+    glds16(src, buf);
   };
   // every wave issues exactly 4 LDS-DMA instructions per K-step; three steps stay in flight
-  if (nt > 0) issue(0, 0);
-  if (nt > 1) issue(1, 1);
-  if (nt > 2) issue(2, 2);
-  int cur = 0;   // stage of K-step t
-  int fill = 3;  // stage K-step t+3 goes to (the one step t-1 vacated)
+#pragma unroll
+  for (int s0 = 0; s0 < 3; ++s0)
+    if (s0 < nt) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) issue_one(s0, j);
+    }
 
   bf16x8 fx[8], fw[4];
-  auto load_frags = [&](int stage) {
-    const char* tA = smem + stage * STAGE_BYTES;
+  auto load_frags = [&](int t) {
+    const char* tA = smem + (t & (NSTAGE - 1)) * STAGE_BYTES;
     const char* tB = tA + OP_BYTES;
+    if ((ABL & 2) && t > 0) return;
 #pragma unroll
     for (int f = 0; f < 4; ++f) fw[f] = frag<TB>(tB, wn * 64 + f * 16, fi, fg);
 #pragma unroll
     for (int f = 0; f < 8; ++f) fx[f] = frag<TA>(tA, grp * 128 + f * 16, fi, fg);
   };
-  auto mfma_all = [&]() {
+  // MFMA segment of step t: 32 matrix instructions; the LDS-DMA instructions GL..3 of step t+3 are issued between
+  // groups of 8 of them (an LDS-DMA issue costs ~60 cycles among MFMAs but 100-185 among ds_reads: r01 PMC showed
+  // the LOAD segment, not the 512-cycle MFMA segment, setting the barrier-to-barrier interval).
+  auto mfma_all = [&](int t) {
     __builtin_amdgcn_s_setprio(1);
 #pragma unroll
-    for (int fn = 0; fn < 4; ++fn)
+    for (int fn = 0; fn < 4; ++fn) {
 #pragma unroll
       for (int fm = 0; fm < 8; ++fm)
-        acc[fn][fm] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw[fn], fx[fm], acc[fn][fm], 0, 0, 0);
+        if (!(ABL & 4)) acc[fn][fm] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw[fn], fx[fm], acc[fn][fm], 0, 0, 0);
+      if (fn >= GL && t + 3 < nt) issue_one(t + 3, fn);
+    }
     __builtin_amdgcn_s_setprio(0);
   };
   auto bar = [&]() {
@@ -179,17 +197,27 @@ __global__ __launch_bounds__(512, 2) void gemm_pp256_kernel(const bf16* __restri
     __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_sched_barrier(0);
   };
-  auto wait_step = [&](int t) {  // this wave's LDS-DMA of step t has landed (newer steps may still be in flight)
-    if (t + 2 < nt) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-    else if (t + 1 < nt) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  // Before barrier 2t every wave makes sure its own LDS-DMA of step t has landed; newer instructions may stay in
+  // flight.  Group 0 arrives having issued steps t+1 and t+2 completely; group 1 arrives one segment earlier in its
+  // own sequence: all of t+1 but only the first GL instructions of t+2.
+  auto wait_step = [&](int t) {
+    const int newer = (t + 1 < nt ? 4 : 0) + (t + 2 < nt ? (grp == 0 ? 4 : GL) : 0);
+    switch (newer) {
+      case 8: asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); break;
+      case 7: asm volatile("s_waitcnt vmcnt(7)" ::: "memory"); break;
+      case 6: asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); break;
+      case 5: asm volatile("s_waitcnt vmcnt(5)" ::: "memory"); break;
+      case 4: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
+      default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+    }
   };
   auto load_segment = [&](int t) {
-    load_frags(cur);
-    if (t + 3 < nt) issue(t + 3, fill);
+    load_frags(t);
+    if (t + 3 < nt && !(ABL & 1)) {
+#pragma unroll
+      for (int j = 0; j < GL; ++j) issue_one(t + 3, j);
+    }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    cur = (cur + 1) & (NSTAGE - 1);
-    fill = (fill + 1) & (NSTAGE - 1);
   };
   if (grp == 0) {
     for (int t = 0; t < nt; ++t) {
@@ -197,24 +225,24 @@ __global__ __launch_bounds__(512, 2) void gemm_pp256_kernel(const bf16* __restri
       bar();  // barrier 2t
       load_segment(t);
       bar();  // barrier 2t+1
-      mfma_all();
+      mfma_all(t);
     }
     bar();    // barrier 2nt
   } else {
     for (int t = 0; t < nt; ++t) {
       wait_step(t);
       bar();  // barrier 2t
-      if (t > 0) mfma_all();
+      if (t > 0) mfma_all(t - 1);
       bar();  // barrier 2t+1
       load_segment(t);
     }
     bar();    // barrier 2nt
-    if (nt > 0) mfma_all();
+    if (nt > 0) mfma_all(nt - 1);
   }
 
   // epilogue: lane (fi, fg) of fragment (fn, fm) holds C[m][n..n+3], m = m0 + grp*128 + fm*16 + fi
   const bool partial = (gridDim.z > 1);
-  float* wsz = partial ? ws + (int64_t)blockIdx.z * M * N : nullptr;
+  float* wsz = partial ? ws + (int64_t)zslice * M * N : nullptr;
   const bool vec_ok = partial ? ((N & 3) == 0)
                               : ((ldc & 3) == 0 && ((uintptr_t)C & 15) == 0 &&
                                  (R == nullptr || ((ldr & 3) == 0 && ((uintptr_t)R & 15) == 0)));
@@ -260,12 +288,12 @@ __global__ __launch_bounds__(512, 2) void gemm_pp256_kernel(const bf16* __restri
   }
 }
 
-template <bool TA, bool TB>
+template <bool TA, bool TB, int GL>
 int launch_one(const void* A, int64_t lda, const void* B, int64_t ldb, void* C, int64_t ldc, const void* R, int64_t ldr,
                int64_t M, int64_t N, int64_t K, float alpha, float beta, int splitk, void* workspace, hipStream_t st) {
   static bool attr_set = false;
   if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_pp256_kernel<TA, TB>),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_pp256_kernel<TA, TB, GL>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
     if (e != hipSuccess) {
       mh_set_error("gemm_pp256: cannot raise dynamic LDS to %d bytes: %s", LDS_BYTES, hipGetErrorString(e));
@@ -277,7 +305,7 @@ int launch_one(const void* A, int64_t lda, const void* B, int64_t ldb, void* C, 
   const int nwg = (int)(tiles_m * tiles_n);
   const int64_t kps = ((K + splitk - 1) / splitk + QBK - 1) / QBK * QBK;
   dim3 grid(nwg, 1, splitk);
-  gemm_pp256_kernel<TA, TB><<<grid, 512, LDS_BYTES, st>>>((const bf16*)A, lda, (const bf16*)B, ldb, (bf16*)C, ldc,
+  gemm_pp256_kernel<TA, TB, GL><<<grid, 512, LDS_BYTES, st>>>((const bf16*)A, lda, (const bf16*)B, ldb, (bf16*)C, ldc,
                                                           (const bf16*)R, ldr, M, N, K, alpha, beta, (int)tiles_n, nwg, kps,
                                                           (float*)workspace);
   MH_LAUNCH_CHECK();
@@ -286,12 +314,28 @@ int launch_one(const void* A, int64_t lda, const void* B, int64_t ldb, void* C, 
 
 }  // namespace
 
-// called by gemm.hip after argument validation (bf16 only)
+extern int g_mh_gemm_ablate;  // api.cpp
+
+// called by gemm.hip after argument validation (bf16 only).  gl = LDS-DMA instructions (of 4 per K-step) issued in the
+// LOAD segment; the rest go between the MFMAs.
 int mh_gemm_pp256_bf16(const void* A, int64_t lda, int ta, const void* B, int64_t ldb, int tb, void* C, int64_t ldc,
                        const void* R, int64_t ldr, int64_t M, int64_t N, int64_t K, float alpha, float beta, int splitk,
-                       void* workspace, hipStream_t st) {
-  if (ta && tb) return launch_one<true, true>(A, lda, B, ldb, C, ldc, R, ldr, M, N, K, alpha, beta, splitk, workspace, st);
-  if (ta) return launch_one<true, false>(A, lda, B, ldb, C, ldc, R, ldr, M, N, K, alpha, beta, splitk, workspace, st);
-  if (tb) return launch_one<false, true>(A, lda, B, ldb, C, ldc, R, ldr, M, N, K, alpha, beta, splitk, workspace, st);
-  return launch_one<false, false>(A, lda, B, ldb, C, ldc, R, ldr, M, N, K, alpha, beta, splitk, workspace, st);
+                       void* workspace, int gl, hipStream_t st) {
+  if (ta == tb && g_mh_gemm_ablate) {
+#define MH_AB(X_) case X_: if (ta) return launch_one<true, true, 4 + 8 * X_>(A, lda, B, ldb, C, ldc, R, ldr, M, N, K, alpha, beta, splitk, workspace, st); \
+    return launch_one<false, false, 4 + 8 * X_>(A, lda, B, ldb, C, ldc, R, ldr, M, N, K, alpha, beta, splitk, workspace, st);
+    switch (g_mh_gemm_ablate) { MH_AB(1) MH_AB(3) MH_AB(4) MH_AB(5) default: break; }
+#undef MH_AB
+  }
+#define MH_PP(TA_, TB_)                                                                                                   \
+  switch (gl) {                                                                                                           \
+    case 0: return launch_one<TA_, TB_, 0>(A, lda, B, ldb, C, ldc, R, ldr, M, N, K, alpha, beta, splitk, workspace, st);  \
+    case 2: return launch_one<TA_, TB_, 2>(A, lda, B, ldb, C, ldc, R, ldr, M, N, K, alpha, beta, splitk, workspace, st);  \
+    default: return launch_one<TA_, TB_, 4>(A, lda, B, ldb, C, ldc, R, ldr, M, N, K, alpha, beta, splitk, workspace, st); \
+  }
+  if (ta && tb) { MH_PP(true, true) }
+  if (ta) { MH_PP(true, false) }
+  if (tb) { MH_PP(false, true) }
+  MH_PP(false, false)
+#undef MH_PP
 }

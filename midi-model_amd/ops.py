@@ -60,15 +60,21 @@ def _pick_splitk(M: int, N: int, K: int) -> int:
     global _gemm_variant
     if _gemm_variant is None:
         _gemm_variant = lib().cdll.mh_get_option(b"gemm")
-    bm = 256 if _gemm_variant in (1, 2, 3) else 128
-    bn = 256 if _gemm_variant == 3 else 128
+    bm = 256 if _gemm_variant in (1, 2, 3, 4, 5, 6, 7) else 128
+    bn = 256 if _gemm_variant in (3, 4, 5, 6, 7) else 128
     tiles = ((M + bm - 1) // bm) * ((N + bn - 1) // bn)
-    per_cu = 1 if _gemm_variant in (1, 2, 3) else 2   # resident workgroups per CU of the active kernel
+    per_cu = 1 if _gemm_variant in (1, 2, 3, 4, 5, 6, 7) else 2   # resident workgroups per CU of the active kernel
     if tiles >= 192 * per_cu or K < 1024:
         return 1
     # fill the 256 CUs once (or twice for the two-per-CU kernel) but never spill a few workgroups into an extra
     # round: 48 tiles x 6 slices = 288 workgroups ran at 590 TFLOP/s where 48 x 5 = 240 fits one round
-    return int(max(1, min(64, (256 * per_cu) // tiles, K // 512)))
+    s = int(max(1, min(64, (256 * per_cu) // tiles, K // 512)))
+    while True:  # slices are whole 32-deep K-steps: shrink the count until none is left empty
+        kps = -(-(-(-K // s)) // 32) * 32
+        s2 = -(-K // kps)
+        if s2 == s:
+            return s
+        s = s2
 
 
 def gemm_nt(a: torch.Tensor, b: torch.Tensor, out: torch.Tensor, *, K: Optional[int] = None, alpha: float = 1.0,

@@ -26,7 +26,7 @@ def ops():
     return real
 
 
-@pytest.fixture(params=[0, 1, 2, 3], ids=["gemm128", "gemmpipe", "gemmpingpong", "gemmpp256"])
+@pytest.fixture(params=[0, 1, 2, 3, 4, 5, 6, 7], ids=["gemm128", "gemmpipe", "gemmpingpong", "gemmpp256", "gemmpp256_22", "gemmpp256_04", "gemmpersist", "gemmw4"])
 def gemm_variant(request, ops):
     """run the GEMM tests against both projection kernels (gemm.hip / gemm_pipe.hip)"""
     ops.set_option("gemm", request.param)

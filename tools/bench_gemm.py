@@ -31,6 +31,10 @@ def main():
     if os.environ.get("MH_BENCH_SHAPES") == "quick":  # PMC passes: three representative shapes, one timed launch
         shapes = [(32768, 8192, 1024, 0, 0, 12), (32768, 1024, 8192, 0, 1, 12), (8192, 1024, 32768, 1, 1, 12)]
         iters = 1
+    if os.environ.get("MH_BENCH_SHAPES") == "nn":  # ablation runs (row-major operands only)
+        shapes = [(32768, 1024, 16384, 0, 0, 0), (8192, 1024, 32768, 1, 1, 12), (1024, 1024, 262144, 1, 1, 6)]
+    if os.environ.get("MH_BENCH_SHAPES") == "few":
+        shapes = [(32768, 8192, 1024, 0, 0, 12), (32768, 1024, 8192, 0, 1, 12), (8192, 1024, 32768, 1, 1, 12)]
     for (M, N, K, ta, tb, calls) in shapes:
         Kp = (K + 7) // 8 * 8
         Mp, Np = (M + 63) // 64 * 64, (N + 63) // 64 * 64   # contraction-major operands keep an aligned row stride
@@ -42,8 +46,8 @@ def main():
             b[:, K:] = 0
         ref = None
         for v in variants:
-            ops.set_option("gemm", v % 10)
-            ops.set_option("gemm_ablate", v // 10)  # 10 = no loads, 20 = no compute (variant 0 only; wrong results)
+            ops.set_option("gemm", v % 10 if v < 1000 else 6)
+            ops.set_option("gemm_ablate", v // 10 if v < 1000 else v - 1000)  # 10 = no loads, 20 = no compute (variant 0 only; wrong results)
             for sk in splitks:
                 out = torch.empty((M, N), device=dev, dtype=torch.bfloat16)
                 ops.gemm_nt(a, b, out, K=K, ta=bool(ta), tb=bool(tb), splitk=sk)
