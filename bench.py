@@ -167,7 +167,7 @@ def main():
             print("[bench] GEMM launches by shape (M,N,K,splitk,transA,transB): calls, total ms, TFLOP/s", file=sys.stderr)
             for shp, (t_, f_, n_) in sorted(by_shape.items(), key=lambda kv: -kv[1][0]):
                 print(f"[bench]   {shp}: {n_:4d} {t_:9.3f} {f_ / (t_ * 1e-3) / 1e12:8.1f}", file=sys.stderr)
-            out["roofline"] = {"bound": "mfma", "kernel": "gemm_nt_kernel<bf16> (all projection GEMMs: fwd, dgrad, wgrad, lm_head)",
+            out["roofline"] = {"bound": "mfma", "kernel": "gemm_pp256_kernel (all projection GEMMs: fwd, dgrad, wgrad, lm_head)",
                                "achieved": ach, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": ach / PEAK_BF16_TFLOPS,
                                "traffic": None, "launches": n, "avg_launch_us": 1e3 * ms / n,
                                "avg_flops_per_launch": fl / n, "gemm_share_of_step_time": ms * 1e-3 / dt}

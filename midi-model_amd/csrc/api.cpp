@@ -14,16 +14,18 @@ void mh_set_error(const char* fmt, ...) {
 }
 
 // ---- runtime options -------------------------------------------------------------------------------------
-// "gemm": 0 = first structure (128x128, 2 LDS stages), 1 = pipelined structure (256x128, 3 stages, counted
-// vmcnt; bf16 only).  Initial value from the environment variable MH_GEMM (default 0: the pipelined kernel is correct but measured slower, profiles/r01_run3).
+// "gemm": 1 = the production bf16 kernel (gemm_pp256.hip: 256x256 tile, 4-stage LDS-DMA ring, ping-pong wave groups),
+// 0 = the first structure (gemm.hip: 128x128, 2 stages), which also serves fp32; kept as an independent check of the
+// production kernel in the GPU tests.  Initial value from the environment variable MH_GEMM (default 1).
+// "gemm_ablate": selects the micro-benchmark builds of the production kernel (wrong results; tools/bench_gemm.py).
 #include <stdlib.h>
 #include <string.h>
 static int env_int(const char* name, int dflt) {
   const char* v = getenv(name);
   return (v && *v) ? atoi(v) : dflt;
 }
-int g_mh_gemm_variant = env_int("MH_GEMM", 3);
-int g_mh_gemm_ablate = 0;  // micro-benchmark only: bit0 = no tile loads after the first, bit1 = no LDS reads / MFMA
+int g_mh_gemm_variant = env_int("MH_GEMM", 1);
+int g_mh_gemm_ablate = 0;
 
 extern "C" int mh_set_option(const char* name, int value) {
   if (strcmp(name, "gemm") == 0) {

@@ -116,7 +116,7 @@ template <typename T, bool TA, bool TB>
 __global__ __launch_bounds__(256) void gemm_nt_kernel(const T* __restrict__ A, int64_t lda, const T* __restrict__ B,
                                                       int64_t ldb, T* C, int64_t ldc, const T* R, int64_t ldr, int64_t M, int64_t N,
                                                       int64_t K, float alpha, float beta, int tiles_n, int nwg,
-                                                      int64_t k_per_split, float* __restrict__ ws, int ablate) {
+                                                      int64_t k_per_split, float* __restrict__ ws) {
   __shared__ __attribute__((aligned(16))) char smem[4 * TILE_BYTES];  // [stage][A|B]
   constexpr int BK = 128 / sizeof(T);
   const int tid = threadIdx.x, lane = tid & 63;
@@ -151,14 +151,13 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const T* __restrict__ A, i
   for (int t = 0; t < nt; ++t) {
     char* cur = smem + (t & 1) * 2 * TILE_BYTES;
     char* nxt = smem + ((t + 1) & 1) * 2 * TILE_BYTES;
-    if (t + 1 < nt && !(ablate & 1)) {
+    if (t + 1 < nt) {
       const int64_t k0 = kbeg + (int64_t)(t + 1) * BK;
       stage_any<T, TA>(A, lda, m0, M, k0, kend, nxt, wave, lane);
       stage_any<T, TB>(B, ldb, n0, N, k0, kend, nxt + TILE_BYTES, wave, lane);
     }
     const char* tA = cur;
     const char* tB = cur + TILE_BYTES;
-    if (!(ablate & 2))  // ablation switch (micro-benchmark only): skip LDS reads + MFMA
 #pragma unroll
     for (int kk = 0; kk < 2; ++kk) {
       Pack<T> fx[4], fw[4];
@@ -249,20 +248,10 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
   }
 }
 
-extern int g_mh_gemm_variant, g_mh_gemm_ablate;  // api.cpp
-int mh_gemm_pipe_bf16(const void* A, int64_t lda, int ta, const void* B, int64_t ldb, int tb, void* C, int64_t ldc,
-                      const void* R, int64_t ldr, int64_t M, int64_t N, int64_t K, float alpha, float beta, int splitk,
-                      void* workspace, int pingpong, hipStream_t st);  // gemm_pipe.hip
-
+extern int g_mh_gemm_variant;  // api.cpp
 int mh_gemm_pp256_bf16(const void* A, int64_t lda, int ta, const void* B, int64_t ldb, int tb, void* C, int64_t ldc,
                        const void* R, int64_t ldr, int64_t M, int64_t N, int64_t K, float alpha, float beta, int splitk,
-                       void* workspace, int gl, hipStream_t st);  // gemm_pp256.hip
-int mh_gemm_pp256p_bf16(const void* A, int64_t lda, int ta, const void* B, int64_t ldb, int tb, void* C, int64_t ldc,
-                        const void* R, int64_t ldr, int64_t M, int64_t N, int64_t K, float alpha, float beta, int splitk,
-                        void* workspace, hipStream_t st);  // gemm_pp256p.hip (persistent)
-int mh_gemm_w4_bf16(const void* A, int64_t lda, int ta, const void* B, int64_t ldb, int tb, void* C, int64_t ldc,
-                    const void* R, int64_t ldr, int64_t M, int64_t N, int64_t K, float alpha, float beta, int splitk,
-                    void* workspace, hipStream_t st);  // gemm_w4.hip (one wave per SIMD)
+                       void* workspace, hipStream_t st);  // gemm_pp256.hip
 
 template <typename T>
 static int gemm_launch(const void* A, int64_t lda, int ta, const void* B, int64_t ldb, int tb, void* C, int64_t ldc,
@@ -284,22 +273,14 @@ static int gemm_launch(const void* A, int64_t lda, int ta, const void* B, int64_
   const int64_t kps = ((K + splitk - 1) / splitk + BK - 1) / BK * BK;
   MH_REQUIRE(splitk == 1 || workspace != nullptr, "gemm: split-K needs a workspace");
   if constexpr (sizeof(T) == 2) {
-    if (g_mh_gemm_variant == 7)
-      return mh_gemm_w4_bf16(A, lda, ta, B, ldb, tb, C, ldc, R, ldr, M, N, K, alpha, beta, splitk, workspace, st);
-    if (g_mh_gemm_variant == 6)
-      return mh_gemm_pp256p_bf16(A, lda, ta, B, ldb, tb, C, ldc, R, ldr, M, N, K, alpha, beta, splitk, workspace, st);
-    if (g_mh_gemm_variant >= 3 && g_mh_gemm_variant <= 5)  // 3: all 4 LDS-DMA in the LOAD segment, 4: 2+2, 5: all in MFMA
-      return mh_gemm_pp256_bf16(A, lda, ta, B, ldb, tb, C, ldc, R, ldr, M, N, K, alpha, beta, splitk, workspace,
-                                g_mh_gemm_variant == 3 ? 4 : (g_mh_gemm_variant == 4 ? 2 : 0), st);
-    if (g_mh_gemm_variant == 1 || g_mh_gemm_variant == 2)
-      return mh_gemm_pipe_bf16(A, lda, ta, B, ldb, tb, C, ldc, R, ldr, M, N, K, alpha, beta, splitk, workspace,
-                               g_mh_gemm_variant == 2, st);
+    if (g_mh_gemm_variant != 0)  // production kernel; 0 = the first structure below (kept as an independent check)
+      return mh_gemm_pp256_bf16(A, lda, ta, B, ldb, tb, C, ldc, R, ldr, M, N, K, alpha, beta, splitk, workspace, st);
   }
   const int nwg = (int)(tiles_m * tiles_n);
   dim3 grid(nwg, 1, splitk);
 #define MH_GEMM_LAUNCH(TA_, TB_)                                                                                      \
   gemm_nt_kernel<T, TA_, TB_><<<grid, 256, 0, st>>>((const T*)A, lda, (const T*)B, ldb, (T*)C, ldc, (const T*)R, ldr, M, N, \
-                                                     K, alpha, beta, (int)tiles_n, nwg, kps, (float*)workspace, g_mh_gemm_ablate)
+                                                     K, alpha, beta, (int)tiles_n, nwg, kps, (float*)workspace)
   if constexpr (sizeof(T) == 2) {
     if (ta && tb) MH_GEMM_LAUNCH(true, true);
     else if (ta) MH_GEMM_LAUNCH(true, false);

@@ -45,12 +45,12 @@ struct StageCtx {
 
 // row-major operand X[r][k]: K-step tile 256 rows x 64 B; one LDS-DMA instruction = 16 rows
 __device__ inline void stage_init_n(StageCtx& c, const bf16* __restrict__ base, int64_t ld, int64_t row0, int64_t nrows,
-                                    int64_t kend, int wave, int lane) {
-  const int rsub = lane >> 2, pc = lane & 3;
+                                    int64_t kend, int wave, int lane, bool fullline = false) {
+  const int rsub = fullline ? (lane >> 3) : (lane >> 2), pc = fullline ? (lane & 7) : (lane & 3);
 #pragma unroll
   for (int it = 0; it < NI; ++it) {
     const int r = (wave + NWAVE * it) * 16 + rsub;
-    const int ch = pc ^ xswz(r);
+    const int ch = fullline ? pc : (pc ^ xswz(r));
     const int64_t grow = row0 + r;
     c.p[it] = base + (grow < nrows ? grow : 0) * ld + ch * 8;
     c.klim[it] = (grow < nrows) ? (int)kend - ch * 8 : INT_MIN;
@@ -106,14 +106,15 @@ __device__ inline bf16x8 frag(const char* tile, int row0, int fi, int fg) {
   }
 }
 
-template <bool TA, bool TB, int GLX>
+template <bool TA, bool TB, int ABL>
 __global__ __launch_bounds__(512, 2) void gemm_pp256_kernel(const bf16* __restrict__ A, int64_t lda,
                                                             const bf16* __restrict__ B, int64_t ldb, bf16* C, int64_t ldc,
                                                             const bf16* R, int64_t ldr, int64_t M, int64_t N, int64_t K,
                                                             float alpha, float beta, int tiles_n, int nwg,
                                                             int64_t k_per_split, float* __restrict__ ws) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  constexpr int GL = GLX & 7, ABL = GLX >> 3;  // ABL (micro-benchmark only): 1 no LDS-DMA in the loop, 2 no reads, 4 no MFMA
+  // ABL != 0 builds are micro-benchmarks with wrong results (tools/bench_gemm.py): 1 = no LDS-DMA after the pipeline
+  // fill, 2 = no fragment reads, 4 = no MFMA, 8 = row-major pieces fetch whole 128-byte lines (8 rows x 128 B)
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int grp = wave >> 2;      // M half (and ping-pong group: waves w, w+4 share a SIMD)
@@ -146,9 +147,9 @@ __global__ __launch_bounds__(512, 2) void gemm_pp256_kernel(const bf16* __restri
 
   StageCtx ca, cb;
   if constexpr (TA) stage_init_t(ca, A, lda, m0, M, kend, wave, lane);
-  else stage_init_n(ca, A, lda, m0, M, kend, wave, lane);
+  else stage_init_n(ca, A, lda, m0, M, kend, wave, lane, (ABL & 8) != 0);
   if constexpr (TB) stage_init_t(cb, B, ldb, n0, N, kend, wave, lane);
-  else stage_init_n(cb, B, ldb, n0, N, kend, wave, lane);
+  else stage_init_n(cb, B, ldb, n0, N, kend, wave, lane, (ABL & 8) != 0);
   // LDS-DMA instruction j (0,1: A; 2,3: B) of K-step t; step t lives in stage t & 3
   auto issue_one = [&](int t, int j) {
     char* buf = smem + (t & (NSTAGE - 1)) * STAGE_BYTES + (j >> 1) * OP_BYTES + (wave + NWAVE * (j & 1)) * 1024;
@@ -178,9 +179,8 @@ __global__ __launch_bounds__(512, 2) void gemm_pp256_kernel(const bf16* __restri
 #pragma unroll
     for (int f = 0; f < 8; ++f) fx[f] = frag<TA>(tA, grp * 128 + f * 16, fi, fg);
   };
-  // MFMA segment of step t: 32 matrix instructions; the LDS-DMA instructions GL..3 of step t+3 are issued between
-  // groups of 8 of them (an LDS-DMA issue costs ~60 cycles among MFMAs but 100-185 among ds_reads: r01 PMC showed
-  // the LOAD segment, not the 512-cycle MFMA segment, setting the barrier-to-barrier interval).
+  // MFMA segment of step t: 32 matrix instructions and nothing else (issuing part of the LDS-DMA here, between the
+  // MFMAs, measured 10% slower: an LDS-DMA issue blocks the wave for 60-180 cycles and the matrix pipe starves)
   auto mfma_all = [&](int t) {
     __builtin_amdgcn_s_setprio(1);
 #pragma unroll
@@ -188,7 +188,6 @@ __global__ __launch_bounds__(512, 2) void gemm_pp256_kernel(const bf16* __restri
 #pragma unroll
       for (int fm = 0; fm < 8; ++fm)
         if (!(ABL & 4)) acc[fn][fm] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw[fn], fx[fm], acc[fn][fm], 0, 0, 0);
-      if (fn >= GL && t + 3 < nt) issue_one(t + 3, fn);
     }
     __builtin_amdgcn_s_setprio(0);
   };
@@ -197,25 +196,18 @@ __global__ __launch_bounds__(512, 2) void gemm_pp256_kernel(const bf16* __restri
     __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_sched_barrier(0);
   };
-  // Before barrier 2t every wave makes sure its own LDS-DMA of step t has landed; newer instructions may stay in
-  // flight.  Group 0 arrives having issued steps t+1 and t+2 completely; group 1 arrives one segment earlier in its
-  // own sequence: all of t+1 but only the first GL instructions of t+2.
+  // Before barrier 2t every wave makes sure its own LDS-DMA of step t has landed; the 4 instructions each of steps
+  // t+1 and t+2 may stay in flight.
   auto wait_step = [&](int t) {
-    const int newer = (t + 1 < nt ? 4 : 0) + (t + 2 < nt ? (grp == 0 ? 4 : GL) : 0);
-    switch (newer) {
-      case 8: asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); break;
-      case 7: asm volatile("s_waitcnt vmcnt(7)" ::: "memory"); break;
-      case 6: asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); break;
-      case 5: asm volatile("s_waitcnt vmcnt(5)" ::: "memory"); break;
-      case 4: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
-      default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
-    }
+    if (t + 2 < nt) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    else if (t + 1 < nt) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   };
   auto load_segment = [&](int t) {
     load_frags(t);
     if (t + 3 < nt && !(ABL & 1)) {
 #pragma unroll
-      for (int j = 0; j < GL; ++j) issue_one(t + 3, j);
+      for (int j = 0; j < 4; ++j) issue_one(t + 3, j);
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   };
@@ -288,12 +280,12 @@ __global__ __launch_bounds__(512, 2) void gemm_pp256_kernel(const bf16* __restri
   }
 }
 
-template <bool TA, bool TB, int GL>
+template <bool TA, bool TB, int ABL>
 int launch_one(const void* A, int64_t lda, const void* B, int64_t ldb, void* C, int64_t ldc, const void* R, int64_t ldr,
                int64_t M, int64_t N, int64_t K, float alpha, float beta, int splitk, void* workspace, hipStream_t st) {
   static bool attr_set = false;
   if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_pp256_kernel<TA, TB, GL>),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_pp256_kernel<TA, TB, ABL>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
     if (e != hipSuccess) {
       mh_set_error("gemm_pp256: cannot raise dynamic LDS to %d bytes: %s", LDS_BYTES, hipGetErrorString(e));
@@ -305,7 +297,7 @@ int launch_one(const void* A, int64_t lda, const void* B, int64_t ldb, void* C, 
   const int nwg = (int)(tiles_m * tiles_n);
   const int64_t kps = ((K + splitk - 1) / splitk + QBK - 1) / QBK * QBK;
   dim3 grid(nwg, 1, splitk);
-  gemm_pp256_kernel<TA, TB, GL><<<grid, 512, LDS_BYTES, st>>>((const bf16*)A, lda, (const bf16*)B, ldb, (bf16*)C, ldc,
+  gemm_pp256_kernel<TA, TB, ABL><<<grid, 512, LDS_BYTES, st>>>((const bf16*)A, lda, (const bf16*)B, ldb, (bf16*)C, ldc,
                                                           (const bf16*)R, ldr, M, N, K, alpha, beta, (int)tiles_n, nwg, kps,
                                                           (float*)workspace);
   MH_LAUNCH_CHECK();
@@ -316,26 +308,23 @@ int launch_one(const void* A, int64_t lda, const void* B, int64_t ldb, void* C, 
 
 extern int g_mh_gemm_ablate;  // api.cpp
 
-// called by gemm.hip after argument validation (bf16 only).  gl = LDS-DMA instructions (of 4 per K-step) issued in the
-// LOAD segment; the rest go between the MFMAs.
+// called by gemm.hip after argument validation (bf16 only)
 int mh_gemm_pp256_bf16(const void* A, int64_t lda, int ta, const void* B, int64_t ldb, int tb, void* C, int64_t ldc,
                        const void* R, int64_t ldr, int64_t M, int64_t N, int64_t K, float alpha, float beta, int splitk,
-                       void* workspace, int gl, hipStream_t st) {
-  if (ta == tb && g_mh_gemm_ablate) {
-#define MH_AB(X_) case X_: if (ta) return launch_one<true, true, 4 + 8 * X_>(A, lda, B, ldb, C, ldc, R, ldr, M, N, K, alpha, beta, splitk, workspace, st); \
-    return launch_one<false, false, 4 + 8 * X_>(A, lda, B, ldb, C, ldc, R, ldr, M, N, K, alpha, beta, splitk, workspace, st);
-    switch (g_mh_gemm_ablate) { MH_AB(1) MH_AB(3) MH_AB(4) MH_AB(5) default: break; }
+                       void* workspace, hipStream_t st) {
+#define MH_PP(TA_, TB_, ABL_) \
+  return launch_one<TA_, TB_, ABL_>(A, lda, B, ldb, C, ldc, R, ldr, M, N, K, alpha, beta, splitk, workspace, st)
+  if (ta == tb && g_mh_gemm_ablate) {  // micro-benchmark builds (wrong results), both-row-major / both-contraction-major
+#define MH_AB(X_) \
+  case X_:        \
+    if (ta) MH_PP(true, true, X_); \
+    MH_PP(false, false, X_);
+    switch (g_mh_gemm_ablate) { MH_AB(1) MH_AB(3) MH_AB(4) MH_AB(5) MH_AB(8) MH_AB(12) default: break; }
 #undef MH_AB
   }
-#define MH_PP(TA_, TB_)                                                                                                   \
-  switch (gl) {                                                                                                           \
-    case 0: return launch_one<TA_, TB_, 0>(A, lda, B, ldb, C, ldc, R, ldr, M, N, K, alpha, beta, splitk, workspace, st);  \
-    case 2: return launch_one<TA_, TB_, 2>(A, lda, B, ldb, C, ldc, R, ldr, M, N, K, alpha, beta, splitk, workspace, st);  \
-    default: return launch_one<TA_, TB_, 4>(A, lda, B, ldb, C, ldc, R, ldr, M, N, K, alpha, beta, splitk, workspace, st); \
-  }
-  if (ta && tb) { MH_PP(true, true) }
-  if (ta) { MH_PP(true, false) }
-  if (tb) { MH_PP(false, true) }
-  MH_PP(false, false)
+  if (ta && tb) MH_PP(true, true, 0);
+  if (ta) MH_PP(true, false, 0);
+  if (tb) MH_PP(false, true, 0);
+  MH_PP(false, false, 0);
 #undef MH_PP
 }

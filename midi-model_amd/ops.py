@@ -60,10 +60,9 @@ def _pick_splitk(M: int, N: int, K: int) -> int:
     global _gemm_variant
     if _gemm_variant is None:
         _gemm_variant = lib().cdll.mh_get_option(b"gemm")
-    bm = 256 if _gemm_variant in (1, 2, 3, 4, 5, 6, 7) else 128
-    bn = 256 if _gemm_variant in (3, 4, 5, 6, 7) else 128
+    bm = bn = 256 if _gemm_variant != 0 else 128
     tiles = ((M + bm - 1) // bm) * ((N + bn - 1) // bn)
-    per_cu = 1 if _gemm_variant in (1, 2, 3, 4, 5, 6, 7) else 2   # resident workgroups per CU of the active kernel
+    per_cu = 1 if _gemm_variant != 0 else 2   # resident workgroups per CU of the active kernel
     if tiles >= 192 * per_cu or K < 1024:
         return 1
     # fill the 256 CUs once (or twice for the two-per-CU kernel) but never spill a few workgroups into an extra
