@@ -68,6 +68,87 @@ def cpu_baseline(sample_S: int, seed: int = 0):
             "loss": float(loss)}
 
 
+def decode_bytes_per_event(B: int, n_cached: float, token_steps: float, L=12, D=1024, I=4096, Lt=3, It=1024, V=3406) -> float:
+    """SURVEY.md 8(d) algorithmic bytes of one generated event at batch B with n cached events, bf16: the net's
+    non-embedding weights once, its K/V cache once, and net_token + lm_head weights once per token step."""
+    w_net = 2.0 * L * (4 * D * D + 3 * D * I)
+    kv = 2.0 * 2 * L * B * n_cached * D
+    w_tok = 2.0 * (Lt * (4 * D * D + 3 * D * It) + V * D)
+    return w_net + kv + token_steps * w_tok
+
+
+def bench_generate(args):
+    """BASELINE.json configs[3]: generate(), batch 64, BOS prompt, 1024 new events, temp 1 / top_p 0.98 / top_k 20,
+    seeded, EOS masked so that every row runs the full length (ban_eos; stated in config).  One step = one generate()
+    call.  Replicas only across GPUs: every rank generates its own batch, no collective."""
+    import midi_model_amd as mm
+    import torch.distributed as dist
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a ROCm GPU (the HIP path has no CPU implementation)")
+    torch.cuda.set_device(local)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
+    dtype = torch.bfloat16 if args.dtype == "bf16" else torch.float32
+    torch.manual_seed(0)
+    model = mm.MIDIModel(mm.MIDIModelConfig.from_name(args.config)).to(torch.device("cuda", local), dtype).eval()
+    B, n_new = args.gen_batch, args.gen_events
+    gen = torch.Generator(device="cuda")
+
+    def run(n_events, seed):
+        gen.manual_seed(seed)
+        with torch.no_grad():
+            return model.generate(None, batch_size=B, max_len=1 + n_events, temp=1.0, top_p=0.98, top_k=20, generator=gen,
+                                  ban_eos=True)
+
+    for i in range(args.warmup):  # full length: the decode session (K/V capacity, captured graphs) is sized by max_len
+        run(n_new, 100 + i)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    tok_steps = 0
+    for i in range(args.steps):
+        out = run(n_new, 1000 * rank + i)
+        assert out.shape == (B, 1 + n_new, 8), out.shape
+        tok_steps += int((out[:, 1:, :] != 0).any(axis=0).sum())  # token positions some row filled (lower bound of steps run)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    dt = float(t.item())
+    if rank == 0:
+        events = world * B * n_new * args.steps
+        per_event_s = dt / (n_new * args.steps)
+        steps_per_event = tok_steps / (n_new * args.steps)
+        by = decode_bytes_per_event(B, (1 + n_new) / 2.0, steps_per_event)
+        out_d = {
+            "metric": "MIDI events/sec, KV-cached generate(), tv2o-medium", "value": events / dt, "unit": "events/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
+            "config": {"workload": f"{args.config} {args.dtype} generate(): batch {B} per GPU, BOS prompt, {n_new} new events, "
+                                   f"temp 1.0 top_p 0.98 top_k 20, seeded; EOS masked so every row runs the full length "
+                                   f"(BASELINE.json configs[3]); random-init weights",
+                       "global_batch": world * B, "new_events": n_new, "parallelism": f"replicas x{world}",
+                       "ms_per_event_step": 1e3 * per_event_s, "token_steps_per_event": steps_per_event},
+            "roofline": {"bound": "hbm", "kernel": "decode step (weights + K/V cache streamed once per event / token step)",
+                         "achieved": by / per_event_s / 1e9, "peak": 8000.0, "unit": "GB/s",
+                         "frac": by / per_event_s / 8.0e12, "traffic": None, "algorithmic_bytes_per_event_step": by},
+        }
+        print(json.dumps(out_d))
+    if world > 1:
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -80,7 +161,13 @@ def main():
     ap.add_argument("--cpu-sample-seq", type=int, default=512)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-gemm-events", action="store_true")
+    ap.add_argument("--mode", default="train", choices=["train", "generate"],
+                    help="train: the headline metric (BASELINE.json configs[1]); generate: KV-cached generate(), configs[3]")
+    ap.add_argument("--gen-batch", type=int, default=64)
+    ap.add_argument("--gen-events", type=int, default=1024, help="new events per sequence per generate() call")
     args = ap.parse_args()
+    if args.mode == "generate":
+        return bench_generate(args)
 
     import midi_model_amd as mm
     from midi_model_amd import ops

@@ -159,11 +159,14 @@ int mh_adamw(void* p, const void* g, void* m, void* v, int64_t n, float lr, floa
 /* ---- KV-cached single-event decode (midi_model.py:195-246; TF:cache_utils.py:127-147) -----------------------
  * Cache layout per layer: k,v [B,H,Lmax,hd].  mh_kv_append: rotate q,k of qkv[B,3*H*hd] at position `pos`
  * in place and store k,v rows at index pos.  mh_attn_decode: o[B,H*hd] = softmax(q K^T * scale) V over
- * the first `len` cached rows (q_len == 1: no causal mask, sdpa_attention.py:120).  hd in {64,256}.     */
+ * the first `len` cached rows (q_len == 1: no causal mask, sdpa_attention.py:120).  hd in {64,256}.
+ * pos_dev (optional, device int32): when non-null the kernels read the position from it at run time -- row index
+ * *pos_dev for the append, rows [0, *pos_dev] for the attention -- so that a captured hipGraph of one decode step
+ * can be replayed for every event; `pos` / `len` are then ignored.                                         */
 int mh_kv_append(void* qkv, const float* cos_t, const float* sin_t, void* kcache, void* vcache, int64_t B, int H,
-                 int hd, int64_t Lmax, int64_t pos, int dtype, void* stream);
+                 int hd, int64_t Lmax, int64_t pos, const int32_t* pos_dev, int dtype, void* stream);
 int mh_attn_decode(const void* qkv, const void* kcache, const void* vcache, void* o, int64_t B, int H, int hd,
-                   int64_t Lmax, int64_t len, float scale, int dtype, void* stream);
+                   int64_t Lmax, int64_t len, float scale, const int32_t* pos_dev, int dtype, void* stream);
 /* copy rotated K and V of a prefill (qkv[B*S,3*H*hd]) into the cache rows [0,S).                           */
 int mh_kv_store_prefill(const void* qkv, void* kcache, void* vcache, int64_t B, int64_t S, int H, int hd,
                         int64_t Lmax, int dtype, void* stream);

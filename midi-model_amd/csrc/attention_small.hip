@@ -187,8 +187,10 @@ template <typename T>
 __global__ __launch_bounds__(256) void kv_append_kernel(T* __restrict__ qkv, const float* __restrict__ cos_t,
                                                         const float* __restrict__ sin_t, T* __restrict__ kc,
                                                         T* __restrict__ vc, int64_t B, int H, int hd, int64_t Lmax,
-                                                        int64_t pos) {
+                                                        int64_t pos, const int32_t* __restrict__ pos_dev) {
   // one thread per (b, h, pair index i < hd/2): rotate q and k, store k and v rows
+  if (pos_dev != nullptr) pos = *pos_dev;  // graph replay: the position lives in device memory
+  if (pos >= Lmax) return;
   const int half = hd / 2;
   const int64_t total = B * H * half;
   const int64_t D = (int64_t)H * hd;
@@ -216,12 +218,12 @@ __global__ __launch_bounds__(256) void kv_append_kernel(T* __restrict__ qkv, con
 }
 
 extern "C" int mh_kv_append(void* qkv, const float* cos_t, const float* sin_t, void* kcache, void* vcache, int64_t B,
-                            int H, int hd, int64_t Lmax, int64_t pos, int dtype, void* stream) {
-  MH_REQUIRE(B > 0 && H > 0 && hd % 2 == 0 && pos >= 0 && pos < Lmax, "kv_append: bad args (pos=%ld Lmax=%ld)", (long)pos,
-             (long)Lmax);
+                            int H, int hd, int64_t Lmax, int64_t pos, const int32_t* pos_dev, int dtype, void* stream) {
+  MH_REQUIRE(B > 0 && H > 0 && hd % 2 == 0 && ((pos >= 0 && pos < Lmax) || pos_dev != nullptr),
+             "kv_append: bad args (pos=%ld Lmax=%ld)", (long)pos, (long)Lmax);
   const int64_t total = B * H * (hd / 2);
   DISPATCH_T(dtype, (kv_append_kernel<T><<<(int)((total + 255) / 256), 256, 0, (hipStream_t)stream>>>(
-                        (T*)qkv, cos_t, sin_t, (T*)kcache, (T*)vcache, B, H, hd, Lmax, pos)));
+                        (T*)qkv, cos_t, sin_t, (T*)kcache, (T*)vcache, B, H, hd, Lmax, pos, pos_dev)));
   MH_LAUNCH_CHECK();
   return MH_OK;
 }
@@ -264,7 +266,10 @@ extern "C" int mh_kv_store_prefill(const void* qkv, void* kcache, void* vcache, 
 template <typename T, int HD>
 __global__ __launch_bounds__(256) void attn_decode_kernel(const T* __restrict__ qkv, const T* __restrict__ kc,
                                                           const T* __restrict__ vc, T* __restrict__ o, int H,
-                                                          int64_t Lmax, int64_t len, float scale) {
+                                                          int64_t Lmax, int64_t len, float scale,
+                                                          const int32_t* __restrict__ pos_dev) {
+  if (pos_dev != nullptr) len = (int64_t)*pos_dev + 1;  // graph replay: attend to rows [0, pos]
+  if (len > Lmax) len = Lmax;
   constexpr int N = Pack<T>::N;
   constexpr int LPK = HD / N;       // lanes per key row
   constexpr int KPW = 64 / LPK;     // keys per wave per iteration
@@ -340,13 +345,14 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(const T* __restrict__ 
 }
 
 extern "C" int mh_attn_decode(const void* qkv, const void* kcache, const void* vcache, void* o, int64_t B, int H, int hd,
-                              int64_t Lmax, int64_t len, float scale, int dtype, void* stream) {
-  MH_REQUIRE(B > 0 && H > 0 && len > 0 && len <= Lmax, "attn_decode: bad args len=%ld Lmax=%ld", (long)len, (long)Lmax);
+                              int64_t Lmax, int64_t len, float scale, const int32_t* pos_dev, int dtype, void* stream) {
+  MH_REQUIRE(B > 0 && H > 0 && ((len > 0 && len <= Lmax) || pos_dev != nullptr), "attn_decode: bad args len=%ld Lmax=%ld",
+             (long)len, (long)Lmax);
   MH_REQUIRE(hd == 64 || hd == 256, "attn_decode: head_dim %d unsupported (64 or 256)", hd);
   hipStream_t st = (hipStream_t)stream;
   const int grid = (int)(B * H);
 #define LAUNCH_DEC(TT, HDV) \
-  attn_decode_kernel<TT, HDV><<<grid, 256, 0, st>>>((const TT*)qkv, (const TT*)kcache, (const TT*)vcache, (TT*)o, H, Lmax, len, scale)
+  attn_decode_kernel<TT, HDV><<<grid, 256, 0, st>>>((const TT*)qkv, (const TT*)kcache, (const TT*)vcache, (TT*)o, H, Lmax, len, scale, pos_dev)
   if (dtype == MH_BF16) {
     if (hd == 64) LAUNCH_DEC(bf16, 64); else LAUNCH_DEC(bf16, 256);
   } else if (dtype == MH_F32) {

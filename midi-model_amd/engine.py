@@ -227,23 +227,27 @@ def stack_prefill(spec: StackSpec, W: StackTensors, x: torch.Tensor, nseq: int, 
     return y
 
 
-def stack_decode(spec: StackSpec, W: StackTensors, x: torch.Tensor, rope: RopeTable, kv: KVState):
+def stack_decode(spec: StackSpec, W: StackTensors, x: torch.Tensor, rope: RopeTable, kv: KVState, pos_dev=None):
     """x [B, D]: one new position per sequence at index kv.len (q_len == 1 => no causal mask,
-    TF:integrations/sdpa_attention.py:120)."""
+    TF:integrations/sdpa_attention.py:120).
+
+    With ``pos_dev`` (device int32[1]) the kernels take the position from device memory instead -- the form a captured
+    hipGraph replays (decode.py); capacity and rope table must already cover it and kv.len is left to the caller."""
     _check_heads(spec)
     B, D = x.shape
     H, I, hd = spec.H, spec.I, spec.hd
-    pos = kv.len
-    kv.reserve(pos + 1)
-    rope.ensure(pos + 1)
+    pos = kv.len if pos_dev is None else 0
+    if pos_dev is None:
+        kv.reserve(pos + 1)
+        rope.ensure(pos + 1)
     for li, lw in enumerate(W.layers):
         h1 = _empty((B, D), x)
         ops.rmsnorm_fwd(x, lw.n1, h1, None, spec.eps)
         qkv = _empty((B, 3 * D), x)
         ops.gemm_nt(h1, lw.wqkv, qkv)
-        ops.kv_append(qkv, rope.cos, rope.sin, kv.k[li], kv.v[li], B, H, hd, kv.cap, pos)
+        ops.kv_append(qkv, rope.cos, rope.sin, kv.k[li], kv.v[li], B, H, hd, kv.cap, pos, pos_dev)
         o = h1
-        ops.attn_decode(qkv, kv.k[li], kv.v[li], o, B, H, hd, kv.cap, pos + 1, spec.scale)
+        ops.attn_decode(qkv, kv.k[li], kv.v[li], o, B, H, hd, kv.cap, pos + 1, spec.scale, pos_dev)
         x2 = _empty((B, D), x)
         ops.gemm_nt(o, lw.wo, x2, beta=1.0, res=x)
         h2 = o
@@ -257,5 +261,6 @@ def stack_decode(spec: StackSpec, W: StackTensors, x: torch.Tensor, rope: RopeTa
         x = x3
     y = _empty((B, D), x)
     ops.rmsnorm_fwd(x, W.norm, y, None, spec.eps)
-    kv.len = pos + 1
+    if pos_dev is None:
+        kv.len = pos + 1
     return y

@@ -14,6 +14,7 @@ from __future__ import annotations
 import json
 import math
 import os
+import threading
 from typing import List, Optional, Tuple
 
 import numpy as np
@@ -23,6 +24,20 @@ import torch.nn as nn
 from . import engine, ops
 from .config import MIDIModelConfig, NetConfig
 from .engine import KVState, LayerTensors, RopeTable, StackSpec, StackTensors
+
+
+class _SessionPool:
+    """Idle decode sessions of one model (buffers + captured graphs).  Copies and pickles of the model start empty."""
+
+    def __init__(self):
+        self.lock = threading.Lock()
+        self.idle = []
+
+    def __deepcopy__(self, memo):
+        return _SessionPool()
+
+    def __reduce__(self):
+        return (_SessionPool, ())
 
 
 class _W(nn.Module):
@@ -88,6 +103,7 @@ class MIDIModel(nn.Module):
         self._wt_version = -1
         self._ropes = {}
         self._tables = None
+        self._sessions = _SessionPool()  # idle decode sessions (decode.py)
         self._reset_parameters()
         self._repack()
 
@@ -152,6 +168,7 @@ class MIDIModel(nn.Module):
         self._wt_version = -1
         self._ropes = {}
         self._tables = None
+        self._sessions = _SessionPool()  # idle decode sessions (decode.py)
         self._W = {k: self._stack_views(k, flat) for k in ("net", "net_token")}
 
     def _apply(self, fn, recurse=True):
@@ -361,65 +378,69 @@ class MIDIModel(nn.Module):
         total = max(max_len, cur_len)
         out = torch.full((B, total, T), tok.pad_id, dtype=torch.long, device=dev)
         out[:, :cur_len] = inp
-        first_mask, lo_tab, hi_tab, arity = self._grammar()
-        if ban_eos:
-            first_mask = first_mask.clone()
-            first_mask[tok.eos_id] = 0
-        spec, tspec = self._specs["net"], self._specs["net_token"]
-        Wn, Wt = self._W["net"], self._W["net_token"]
-        kv1 = KVState(spec, B, ops.round_up(total + 1, 64), self._flat)
-        kv2 = KVState(tspec, B, T, self._flat)
-        neg1 = torch.full((B,), -1, dtype=torch.int32, device=dev)
-        probs = torch.empty((B, 1, V), dtype=torch.float32, device=dev)
-        logits = torch.empty((B, Vp), dtype=self.dtype, device=dev)
-        past_len = 0
-        lm_w = self.lm_head.weight.data
-        while cur_len < max_len:
-            S_new = cur_len - past_len
-            e = torch.empty((B * S_new, spec.D), dtype=self.dtype, device=dev)
-            ops.embed_sum_fwd(out[:, past_len:cur_len].contiguous().view(B * S_new, T), Wn.embed, e)
-            if past_len == 0:
-                hidden = engine.stack_prefill(spec, Wn, e, B, S_new, self.rope("net"), kv1).view(B, S_new, spec.D)[:, -1].contiguous()
-            else:
-                hidden = engine.stack_decode(spec, Wn, e, self.rope("net"), kv1)
-            kv2.len = 0
-            seq = torch.full((B, T), tok.pad_id, dtype=torch.long, device=dev)
-            x_in = hidden
-            n_steps = T
-            ev_dev = None
-            end_all = False
-            i = 0
-            while i < n_steps:
-                h = engine.stack_decode(tspec, Wt, x_in, self.rope("net_token"), kv2)
-                ops.gemm_nt(h, lm_w, logits[:, :V])
-                if i == 0:
-                    lo, hi = neg1, neg1
-                else:
-                    lo, hi = lo_tab[ev_dev, i].contiguous(), hi_tab[ev_dev, i].contiguous()
-                ops.masked_softmax(logits, lo, hi, first_mask, probs.view(B, V), V, temp)
-                samples = self.sample_top_p_k(probs, top_p, top_k, generator=generator)  # (B, 1)
-                seq[:, i] = samples[:, 0]
-                if i == 0:
-                    ev_dev = samples[:, 0]
-                    ids = ev_dev.tolist()  # the one host sync per event
-                    alive = [a for a in (arity[t] for t in ids if t != tok.eos_id)]
-                    end_all = len(alive) == 0
-                    # reference break rule: the inner loop stops after position i iff every live row's event has
-                    # exactly i parameters (vacuously true at i == 1 when no row is live)
-                    if end_all:
-                        n_steps = 2
-                    elif all(a == alive[0] for a in alive):
-                        n_steps = alive[0] + 1
-                    else:
-                        n_steps = T
-                x_in = Wt.embed[samples[:, 0]]
-                i += 1
-            out[:, cur_len] = seq
-            past_len = cur_len
-            cur_len += 1
-            if end_all:
-                break
+        if cur_len >= max_len:
+            return out[:, :cur_len].cpu().numpy()
+        _, _, _, arity = self._grammar()
+        ses = self._checkout_session(B, total + 1, float(temp))
+        try:
+            first_mask = self._grammar()[0]
+            ses.first_mask.copy_(first_mask)
+            if ban_eos:
+                ses.first_mask[tok.eos_id] = 0
+            ses.reset()
+            ses.prefill(inp)  # causal forward over the prompt; hidden = last position
+            while cur_len < max_len:
+                seq = torch.full((B, T), tok.pad_id, dtype=torch.long, device=dev)
+                n_steps = T
+                end_all = False
+                i = 0
+                while i < n_steps:
+                    probs = ses.tok_step(i)
+                    samples = self.sample_top_p_k(probs, top_p, top_k, generator=generator)  # (B, 1)
+                    seq[:, i] = samples[:, 0]
+                    ses.samples_in.copy_(samples[:, 0])
+                    if i == 0:
+                        ses.ev.copy_(samples[:, 0])
+                        ids = samples[:, 0].tolist()  # the one host sync per event
+                        alive = [a for a in (arity[t] for t in ids if t != tok.eos_id)]
+                        end_all = len(alive) == 0
+                        # reference break rule: the inner loop stops after position i iff every live row's event has
+                        # exactly i parameters (vacuously true at i == 1 when no row is live)
+                        if end_all:
+                            n_steps = 2
+                        elif all(a == alive[0] for a in alive):
+                            n_steps = alive[0] + 1
+                        else:
+                            n_steps = T
+                    i += 1
+                out[:, cur_len] = seq
+                cur_len += 1
+                if end_all or cur_len >= max_len:
+                    break
+                ses.net_step(seq)  # decode the event just written; hidden = its net output
+        finally:
+            self._return_session(ses)
         return out[:, :cur_len].cpu().numpy()
+
+    # decode sessions: buffers + captured graphs, one per concurrent generate() call (decode.py)
+    def _checkout_session(self, B: int, need: int, temp: float):
+        from .decode import DecodeSession
+        cap = 256
+        while cap < need:
+            cap *= 2
+        key = (self._flat.data_ptr(), self._flat.dtype, B, cap, temp)
+        pool = self._sessions
+        with pool.lock:
+            for k, ses in enumerate(pool.idle):
+                if ses.key == key:
+                    return pool.idle.pop(k)
+            while len(pool.idle) >= 4:  # bound the memory held by idle sessions
+                pool.idle.pop(0)
+        return DecodeSession(self, B, cap, temp)
+
+    def _return_session(self, ses) -> None:
+        with self._sessions.lock:
+            self._sessions.idle.append(ses)
 
     # ------------------------------------------------------------------------------------ persistence
     def save_pretrained(self, save_directory: str):

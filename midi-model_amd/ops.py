@@ -290,12 +290,14 @@ def adamw(p, g, m, v, lr, b1, b2, eps, wd, bc1, bc2, coef_dev):
 
 
 # -------------------------------------------------------------------------------------------- decode
-def kv_append(qkv, cos_t, sin_t, kc, vc, B: int, H: int, hd: int, Lmax: int, pos: int):
-    lib().call("mh_kv_append", _p(qkv), _p(cos_t), _p(sin_t), _p(kc), _p(vc), B, H, hd, Lmax, pos, dt(qkv), _stream())
+def kv_append(qkv, cos_t, sin_t, kc, vc, B: int, H: int, hd: int, Lmax: int, pos: int, pos_dev=None):
+    lib().call("mh_kv_append", _p(qkv), _p(cos_t), _p(sin_t), _p(kc), _p(vc), B, H, hd, Lmax, pos, _p(pos_dev), dt(qkv),
+               _stream())
 
 
-def attn_decode(qkv, kc, vc, o, B: int, H: int, hd: int, Lmax: int, length: int, scale: float):
-    lib().call("mh_attn_decode", _p(qkv), _p(kc), _p(vc), _p(o), B, H, hd, Lmax, length, scale, dt(qkv), _stream())
+def attn_decode(qkv, kc, vc, o, B: int, H: int, hd: int, Lmax: int, length: int, scale: float, pos_dev=None):
+    lib().call("mh_attn_decode", _p(qkv), _p(kc), _p(vc), _p(o), B, H, hd, Lmax, length, scale, _p(pos_dev), dt(qkv),
+               _stream())
     return o
 
 

@@ -255,14 +255,18 @@ def adamw(p, g, m, v, lr, b1, b2, eps, wd, bc1, bc2, coef_dev):
     v.copy_(ve.to(T))
 
 
-def kv_append(qkv, cos_t, sin_t, kc, vc, B, H, hd, Lmax, pos):
+def kv_append(qkv, cos_t, sin_t, kc, vc, B, H, hd, Lmax, pos, pos_dev=None):
+    if pos_dev is not None:
+        pos = int(pos_dev.item())
     rope_(qkv, cos_t, sin_t, 1, pos, H, hd, 1)
     D = H * hd
     kc[:, :, pos] = qkv[:, D:2 * D].view(B, H, hd)
     vc[:, :, pos] = qkv[:, 2 * D:].view(B, H, hd)
 
 
-def attn_decode(qkv, kc, vc, o, B, H, hd, Lmax, length, scale):
+def attn_decode(qkv, kc, vc, o, B, H, hd, Lmax, length, scale, pos_dev=None):
+    if pos_dev is not None:
+        length = int(pos_dev.item()) + 1
     q = qkv[:, : H * hd].float().view(B, H, 1, hd)
     k, v = kc[:, :, :length].float(), vc[:, :, :length].float()
     p = torch.softmax((q @ k.transpose(-1, -2)) * scale, -1)
