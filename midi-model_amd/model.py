@@ -99,8 +99,6 @@ class MIDIModel(nn.Module):
         }
         self._flat = None
         self._flat_grad = None
-        self._wt = None
-        self._wt_version = -1
         self._ropes = {}
         self._tables = None
         self._sessions = _SessionPool()  # idle decode sessions (decode.py)
@@ -164,8 +162,6 @@ class MIDIModel(nn.Module):
         self._flat = flat
         self._n_mat = sum(n for (_, n, g) in self._offsets.values() if g == "mat")
         self._flat_grad = None
-        self._wt = None
-        self._wt_version = -1
         self._ropes = {}
         self._tables = None
         self._sessions = _SessionPool()  # idle decode sessions (decode.py)
