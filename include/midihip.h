@@ -57,6 +57,18 @@ int mh_gemm(const void* A, int64_t lda, int transA, const void* B, int64_t ldb, 
             void* workspace, void* stream);
 int mh_gemm_splitk_reduce(const void* workspace, void* C, int64_t ldc, const void* R, int64_t ldr, int64_t M,
                           int64_t N, int splitk, float alpha, float beta, int dtype, void* stream);
+/* Skinny projection of the decode step (replaces the per-token nn.Linear calls of LlamaAttention / LlamaMLP /
+ * lm_head when q_len == 1, modeling_llama.py:243-281, 174-176; midi_model.py:135): C[M,N] = op(A)[M,K] * W[N,K]^T
+ * (+ R), 1 <= M <= 64 rows, bf16, K a multiple of 128.  `mode` fuses the elementwise op that precedes the projection:
+ *   MH_SKINNY_PLAIN   op(A) = A
+ *   MH_SKINNY_NORM    op(A) = norm_w * round(A * rsqrt(mean_k(A^2) + eps))   (LlamaRMSNorm :62-67; K <= 1024)
+ *   MH_SKINNY_SWIGLU  A is gate|up [M, 2K]; op(A) = round(silu(gate)) * up    (LlamaMLP :174-176)             */
+#define MH_SKINNY_PLAIN 0
+#define MH_SKINNY_NORM 1
+#define MH_SKINNY_SWIGLU 2
+int mh_gemm_skinny(const void* A, int64_t lda, const void* W, int64_t ldw, void* C, int64_t ldc, const void* R,
+                   int64_t ldr, const void* norm_w, float eps, int mode, int64_t M, int64_t N, int64_t K, int dtype,
+                   void* stream);
 /* out[C,R] = in[R,C]^T (operand re-layout for dgrad/wgrad). */
 int mh_transpose(const void* in, int64_t ldi, void* out, int64_t ldo, int64_t rows, int64_t cols, int dtype,
                  void* stream);
@@ -177,6 +189,15 @@ int mh_kv_store_prefill(const void* qkv, void* kcache, void* vcache, int64_t B, 
 int mh_masked_softmax(const void* logits, int64_t ldl, const int32_t* lo, const int32_t* hi,
                       const uint8_t* first_mask, float* probs, int64_t B, int V, float temp, int dtype,
                       void* stream);
+/* Fused sampler of one token position (midi_model.py:202-228, 152-165; torch.multinomial's single-draw path):
+ * masked softmax as above, keep the top_k largest (value descending, index ascending), zero those whose preceding
+ * cumulative mass exceeds top_p, renormalise, and return for every row the id maximising p_j / q[b, j], where q
+ * [B, V] holds Exp(1) draws (only the first top_k of a row are read) taken by the caller from the caller's generator
+ * (torch.Tensor.exponential_), which is what keeps a seeded generator's stream identical to the reference's.
+ * out[b * out_stride] = sampled id (int64).  1 <= top_k <= 64.                                              */
+int mh_sample_top_p_k(const void* logits, int64_t ldl, const int32_t* lo, const int32_t* hi,
+                      const uint8_t* first_mask, const float* q, int64_t* out, int64_t out_stride, int64_t B, int V,
+                      float temp, float top_p, int top_k, int dtype, void* stream);
 
 #ifdef __cplusplus
 }

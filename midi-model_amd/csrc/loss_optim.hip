@@ -273,3 +273,131 @@ extern "C" int mh_masked_softmax(const void* logits, int64_t ldl, const int32_t*
   MH_LAUNCH_CHECK();
   return MH_OK;
 }
+
+// ---------------------------------------------------------------------------------------------------
+// Fused sampler of generate(): grammar-masked softmax -> top-p / top-k filter -> draw, one block per row.
+// Follows midi_model.py:202-228 + sample_top_p_k (:152-165) + torch.multinomial's single-draw path
+// (argmax(p / q), q ~ Exp(1), ATen/native/Distributions.cpp) with q SUPPLIED by the caller, who draws it with
+// torch.Tensor.exponential_ from the caller's generator exactly as multinomial would: q[b, j] belongs to the j-th
+// largest probability of row b.  Only the top_k largest entries can have non-zero filtered probability, so the full
+// sort is replaced by top_k rounds of a block-wide arg-max (value descending, index ascending = the order of torch's
+// stable radix sort).  Differences from the op-by-op path are confined to fp32 summation order (softmax
+// denominator, cumulative sum, renormalisation): ulp-level, affecting the draw only at exact ties.
+// ---------------------------------------------------------------------------------------------------
+constexpr int SAMPLE_MAX_K = 64;
+
+template <typename T>
+__global__ __launch_bounds__(256) void sample_top_p_k_kernel(const T* __restrict__ logits, int64_t ldl,
+                                                             const int32_t* __restrict__ lo, const int32_t* __restrict__ hi,
+                                                             const uint8_t* __restrict__ first_mask,
+                                                             const float* __restrict__ q, int64_t* __restrict__ out,
+                                                             int64_t out_stride, int V, float inv_temp, float top_p,
+                                                             int top_k) {
+  extern __shared__ float sp[];  // [V] probabilities
+  __shared__ float red_v[4];
+  __shared__ int red_i[4];
+  __shared__ float sel_v[SAMPLE_MAX_K];
+  __shared__ int sel_i[SAMPLE_MAX_K];
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int64_t b = blockIdx.x;
+  const T* row = logits + b * ldl;
+  float mx = -INFINITY;
+  for (int c = tid; c < V; c += 256) {
+    const float z = rnd<T>(to_f(row[c]) * inv_temp);
+    sp[c] = z;
+    mx = fmaxf(mx, z);
+  }
+  mx = wave_max(mx);
+  if (lane == 0) red_v[wv] = mx;
+  __syncthreads();
+  mx = fmaxf(fmaxf(red_v[0], red_v[1]), fmaxf(red_v[2], red_v[3]));
+  __syncthreads();
+  float sum = 0.f;
+  for (int c = tid; c < V; c += 256) {
+    const float e = __expf(sp[c] - mx);
+    sp[c] = e;
+    sum += e;
+  }
+  sum = wave_sum(sum);
+  if (lane == 0) red_v[wv] = sum;
+  __syncthreads();
+  const float inv = 1.f / (red_v[0] + red_v[1] + red_v[2] + red_v[3]);
+  const int l = lo[b], h = hi[b];
+  for (int c = tid; c < V; c += 256) {
+    const bool ok = (l < 0) ? (first_mask[c] != 0) : (c >= l && c < h);
+    sp[c] = ok ? sp[c] * inv : 0.f;
+  }
+  __syncthreads();
+  // top_k rounds of block arg-max; a taken entry is marked -1
+  for (int j = 0; j < top_k; ++j) {
+    float bv = -1.f;
+    int bi = 0x7fffffff;
+    for (int c = tid; c < V; c += 256) {
+      const float v = sp[c];
+      if (v > bv) {  // ascending c: the first (lowest index) of equal values stays
+        bv = v;
+        bi = c;
+      }
+    }
+#pragma unroll
+    for (int x = 32; x >= 1; x >>= 1) {
+      const float ov = __shfl_xor(bv, x, 64);
+      const int oi = __shfl_xor(bi, x, 64);
+      if (ov > bv || (ov == bv && oi < bi)) {
+        bv = ov;
+        bi = oi;
+      }
+    }
+    if (lane == 0) {
+      red_v[wv] = bv;
+      red_i[wv] = bi;
+    }
+    __syncthreads();
+    if (tid == 0) {
+      float v = red_v[0];
+      int i = red_i[0];
+      for (int w = 1; w < 4; ++w)
+        if (red_v[w] > v || (red_v[w] == v && red_i[w] < i)) {
+          v = red_v[w];
+          i = red_i[w];
+        }
+      sel_v[j] = v;
+      sel_i[j] = i;
+      sp[i] = -1.f;
+    }
+    __syncthreads();
+  }
+  if (tid == 0) {
+    // probs_sort[cumsum - probs_sort > p] = 0; keep the first k; renormalise; argmax(p / q)
+    float cum = 0.f, s = 0.f;
+    for (int j = 0; j < top_k; ++j) {
+      cum += sel_v[j];
+      if (cum - sel_v[j] > top_p) sel_v[j] = 0.f;
+      s += sel_v[j];
+    }
+    float best = -1.f;
+    int bj = 0;
+    const float* qr = q + b * (int64_t)V;
+    for (int j = 0; j < top_k; ++j) {
+      const float r = (sel_v[j] / s) / qr[j];
+      if (r > best) {
+        best = r;
+        bj = j;
+      }
+    }
+    out[b * out_stride] = (int64_t)sel_i[bj];
+  }
+}
+
+extern "C" int mh_sample_top_p_k(const void* logits, int64_t ldl, const int32_t* lo, const int32_t* hi,
+                                 const uint8_t* first_mask, const float* q, int64_t* out, int64_t out_stride, int64_t B,
+                                 int V, float temp, float top_p, int top_k, int dtype, void* stream) {
+  MH_REQUIRE(B > 0 && V > 0 && temp > 0.f, "sample_top_p_k: bad args");
+  MH_REQUIRE(top_k >= 1 && top_k <= SAMPLE_MAX_K && top_k <= V, "sample_top_p_k: top_k=%d outside [1, %d]", top_k,
+             SAMPLE_MAX_K);
+  MH_REQUIRE((size_t)V * 4 <= 60 * 1024, "sample_top_p_k: vocabulary %d too large for the LDS row buffer", V);
+  DISPATCH_T(dtype, (sample_top_p_k_kernel<T><<<(int)B, 256, (size_t)V * 4, (hipStream_t)stream>>>(
+                        (const T*)logits, ldl, lo, hi, first_mask, q, out, out_stride, V, 1.f / temp, top_p, top_k)));
+  MH_LAUNCH_CHECK();
+  return MH_OK;
+}

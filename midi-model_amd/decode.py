@@ -5,13 +5,14 @@ The reference spends a generated event in ~1000 launches and B host syncs.  Here
     1 graph replay   net step: embedding sum of the previous event's 8 tokens -> 12 decoder layers on one position
                      per sequence -> final norm; K/V appended to preallocated caches at a position kept in DEVICE memory
     <=8 graph replays  token step i: (embedding of the token just sampled) -> 3 decoder layers at position i ->
-                     lm_head -> grammar-masked softmax
-    + the reference's own sampling ops after each token step (torch.sort / cumsum / multinomial, eager, so that a seeded
-      torch.Generator is consumed exactly as the reference consumes it) and ONE device->host copy per event.
+                     lm_head -> grammar-masked softmax -> the reference's own sampling ops (torch.sort / cumsum /
+                     multinomial, midi_model.py:152-165) drawing from a session generator that carries the caller's
+                     generator state in and out, so a seeded torch.Generator is consumed exactly as the reference does
+    + ONE device->host copy per event (the sampled event ids, for the reference's break rule).
 
 The graphs are hipGraphs captured through torch.cuda.CUDAGraph from the same Python schedule the eager path runs
 (``engine.stack_decode``), so there is one implementation of the step.  A session owns every buffer the graphs touch and
-is keyed by (parameter buffer, batch, capacity, temperature); ``MIDIModel`` keeps a pool of them and hands one to each
+is keyed by (parameter buffer, batch, capacity, temperature, top_p, top_k); ``MIDIModel`` keeps a pool of them and hands one to each
 ``generate`` call, so concurrent generators on one model (app.py:496) never share scratch.
 """
 from __future__ import annotations
@@ -30,10 +31,11 @@ def graphs_enabled(device: torch.device) -> bool:
 
 
 class DecodeSession:
-    def __init__(self, model, B: int, capacity: int, temp: float):
+    def __init__(self, model, B: int, capacity: int, temp: float, top_p: float, top_k: int):
         tok = model.tokenizer
         self.model, self.B, self.cap, self.temp = model, B, capacity, float(temp)
-        self.key = (model._flat.data_ptr(), model._flat.dtype, B, capacity, float(temp))
+        self.top_p, self.top_k = float(top_p), int(top_k)
+        self.key = self.make_key(model, B, capacity, temp, top_p, top_k)
         dev, dt = model.device, model.dtype
         self.T, self.V, self.Vp = tok.max_token_seq, tok.vocab_size, model.vocab_padded
         spec, tspec = model._specs["net"], model._specs["net_token"]
@@ -46,41 +48,68 @@ class DecodeSession:
         self.first_mask = first.clone()           # generate() overwrites it (ban_eos)
         self.lo_tab, self.hi_tab = lo, hi
         self.pos = torch.zeros(1, dtype=torch.int32, device=dev)           # cached events so far (device side)
-        self.tokens_in = torch.zeros((B, self.T), dtype=torch.long, device=dev)
         self.hidden = torch.zeros((B, spec.D), dtype=dt, device=dev)
+        self.seq = torch.zeros((B, self.T), dtype=torch.long, device=dev)  # tokens of the event being sampled
         self.samples_in = torch.zeros((B,), dtype=torch.long, device=dev)  # token sampled at the previous position
         self.ev = torch.zeros((B,), dtype=torch.long, device=dev)          # event id (token 0) of the current event
+        self.pad_id = tok.pad_id
         self.neg1 = torch.full((B,), -1, dtype=torch.int32, device=dev)
         self.probs = torch.zeros((B, 1, self.V), dtype=torch.float32, device=dev)
+        self.q = torch.zeros((B, self.V), dtype=torch.float32, device=dev)  # Exp(1) noise of the sampler
         self.logits = torch.zeros((B, self.Vp), dtype=dt, device=dev)
         self.g_net = None
         self.g_tok: List[Optional[torch.cuda.CUDAGraph]] = [None] * self.T
         self.use_graphs = graphs_enabled(dev)
+        self.gen = torch.Generator(device=dev) if self.use_graphs else None  # the generator the captured sampler draws from
+        self._user_gen = None
         if self.use_graphs:
             self._capture()
+
+    @staticmethod
+    def make_key(model, B, capacity, temp, top_p, top_k):
+        return (model._flat.data_ptr(), model._flat.dtype, B, capacity, float(temp), float(top_p), int(top_k))
 
     # ---- the step bodies (run eagerly, or once under capture) ---------------------------------------------
     def _net_body(self):
         m = self.model
         spec = m._specs["net"]
         e = torch.empty((self.B, spec.D), dtype=m.dtype, device=m.device)
-        ops.embed_sum_fwd(self.tokens_in, m._W["net"].embed, e)
+        ops.embed_sum_fwd(self.seq, m._W["net"].embed, e)  # the event sampled last
         y = engine.stack_decode(spec, m._W["net"], e, self.rope1, self.kv1, pos_dev=self.pos)
         self.hidden.copy_(y)
         self.pos.add_(1)
 
-    def _tok_body(self, i: int):
+    def _tok_body(self, i: int, generator=None):
         m = self.model
         tspec, Wt = m._specs["net_token"], m._W["net_token"]
         x = self.hidden if i == 0 else Wt.embed.index_select(0, self.samples_in)
         self.kv2.len = i
-        h = engine.stack_decode(tspec, Wt, x, self.rope2, self.kv2)
-        ops.gemm_nt(h, m.lm_head.weight.data, self.logits[:, : self.V])
+        lm_w = m.lm_head.weight.data
+        if ops.skinny_ok(x, tspec.D, norm=True):  # final RMSNorm fused into the lm_head projection
+            h = engine.stack_decode(tspec, Wt, x, self.rope2, self.kv2, final_norm=False)
+            ops.gemm_skinny(h, lm_w, self.logits[:, : self.V], mode=ops.SKINNY_NORM, norm_w=Wt.norm, eps=tspec.eps)
+        else:
+            h = engine.stack_decode(tspec, Wt, x, self.rope2, self.kv2)
+            ops.gemm_nt(h, lm_w, self.logits[:, : self.V])
         if i == 0:
             lo, hi = self.neg1, self.neg1
         else:
             lo, hi = self.lo_tab[self.ev, i].contiguous(), self.hi_tab[self.ev, i].contiguous()
-        ops.masked_softmax(self.logits, lo, hi, self.first_mask, self.probs.view(self.B, self.V), self.V, self.temp)
+        if i == 0:
+            self.seq.fill_(self.pad_id)
+        if 1 <= self.top_k <= min(ops.SAMPLE_MAX_K, self.V):
+            # one launch instead of sample_top_p_k's ~25: the Exp(1) noise torch.multinomial would draw internally
+            # (empty_like(probs).exponential_(1, generator)) is drawn here, the rest is mh_sample_top_p_k
+            self.q.exponential_(1.0, generator=generator)
+            ops.sample_top_p_k(self.logits, lo, hi, self.first_mask, self.q, self.seq[:, i], self.V, self.temp,
+                               self.top_p, self.top_k)
+        else:
+            ops.masked_softmax(self.logits, lo, hi, self.first_mask, self.probs.view(self.B, self.V), self.V, self.temp)
+            samples = m.sample_top_p_k(self.probs, self.top_p, self.top_k, generator=generator)  # (B, 1)
+            self.seq[:, i] = samples[:, 0]
+        if i == 0:
+            self.ev.copy_(self.seq[:, 0])
+        self.samples_in.copy_(self.seq[:, i])
 
     def _capture(self):
         # one eager pass on a side stream first: lazy initialisation (kernel attributes, allocator pools) must not
@@ -91,7 +120,7 @@ class DecodeSession:
         with torch.cuda.stream(side):
             self._net_body()
             for i in range(self.T):
-                self._tok_body(i)
+                self._tok_body(i, self.gen)
         cur.wait_stream(side)
         torch.cuda.synchronize()
         pool = torch.cuda.graph_pool_handle()
@@ -100,8 +129,9 @@ class DecodeSession:
             self._net_body()
         for i in range(self.T):
             g = torch.cuda.CUDAGraph()
+            g.register_generator_state(self.gen)  # philox seed/offset are read at replay time, offsets advance per replay
             with torch.cuda.graph(g, pool=pool):
-                self._tok_body(i)
+                self._tok_body(i, self.gen)
             self.g_tok[i] = g
         self.reset()
 
@@ -123,19 +153,31 @@ class DecodeSession:
         self.hidden.copy_(y.view(B, S, spec.D)[:, -1])
         self.pos.fill_(S)
 
-    def net_step(self, prev_event: torch.Tensor) -> None:
-        """prev_event [B, T]: decode one position; hidden <- net output."""
-        self.tokens_in.copy_(prev_event)
+    def begin(self, generator) -> None:
+        """take over the caller's random stream (None = the device's default generator)"""
+        self._user_gen = generator
+        if self.gen is not None:
+            src = generator if generator is not None else torch.cuda.default_generators[self.model.device.index or 0]
+            self.gen.set_state(src.get_state())
+
+    def end(self) -> None:
+        """hand the advanced random stream back to the caller's generator"""
+        if self.gen is not None:
+            dst = self._user_gen if self._user_gen is not None else torch.cuda.default_generators[self.model.device.index or 0]
+            dst.set_state(self.gen.get_state())
+        self._user_gen = None
+
+    def net_step(self) -> None:
+        """decode the event in ``seq`` (the one just sampled) at the next position; hidden <- net output"""
         if self.g_net is not None:
             self.g_net.replay()
         else:
             self._net_body()
         self.kv1.len += 1
 
-    def tok_step(self, i: int) -> torch.Tensor:
-        """token position i of the current event -> probs [B, 1, V] (a view of session memory)"""
+    def tok_step(self, i: int) -> None:
+        """sample token position i of the current event into seq[:, i] (and ev for i == 0)"""
         if self.g_tok[i] is not None:
             self.g_tok[i].replay()
         else:
-            self._tok_body(i)
-        return self.probs
+            self._tok_body(i, self._user_gen)

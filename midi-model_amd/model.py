@@ -377,27 +377,22 @@ class MIDIModel(nn.Module):
         if cur_len >= max_len:
             return out[:, :cur_len].cpu().numpy()
         _, _, _, arity = self._grammar()
-        ses = self._checkout_session(B, total + 1, float(temp))
+        ses = self._checkout_session(B, total + 1, float(temp), float(top_p), int(top_k))
         try:
-            first_mask = self._grammar()[0]
-            ses.first_mask.copy_(first_mask)
+            ses.first_mask.copy_(self._grammar()[0])
             if ban_eos:
                 ses.first_mask[tok.eos_id] = 0
             ses.reset()
+            ses.begin(generator)
             ses.prefill(inp)  # causal forward over the prompt; hidden = last position
             while cur_len < max_len:
-                seq = torch.full((B, T), tok.pad_id, dtype=torch.long, device=dev)
                 n_steps = T
                 end_all = False
                 i = 0
                 while i < n_steps:
-                    probs = ses.tok_step(i)
-                    samples = self.sample_top_p_k(probs, top_p, top_k, generator=generator)  # (B, 1)
-                    seq[:, i] = samples[:, 0]
-                    ses.samples_in.copy_(samples[:, 0])
+                    ses.tok_step(i)  # ... lm_head -> masked softmax -> sample_top_p_k -> ses.seq[:, i]
                     if i == 0:
-                        ses.ev.copy_(samples[:, 0])
-                        ids = samples[:, 0].tolist()  # the one host sync per event
+                        ids = ses.ev.tolist()  # the one host sync per event
                         alive = [a for a in (arity[t] for t in ids if t != tok.eos_id)]
                         end_all = len(alive) == 0
                         # reference break rule: the inner loop stops after position i iff every live row's event has
@@ -409,22 +404,23 @@ class MIDIModel(nn.Module):
                         else:
                             n_steps = T
                     i += 1
-                out[:, cur_len] = seq
+                out[:, cur_len] = ses.seq
                 cur_len += 1
                 if end_all or cur_len >= max_len:
                     break
-                ses.net_step(seq)  # decode the event just written; hidden = its net output
+                ses.net_step()  # decode the event just written; hidden = its net output
         finally:
+            ses.end()
             self._return_session(ses)
         return out[:, :cur_len].cpu().numpy()
 
     # decode sessions: buffers + captured graphs, one per concurrent generate() call (decode.py)
-    def _checkout_session(self, B: int, need: int, temp: float):
+    def _checkout_session(self, B: int, need: int, temp: float, top_p: float, top_k: int):
         from .decode import DecodeSession
         cap = 256
         while cap < need:
             cap *= 2
-        key = (self._flat.data_ptr(), self._flat.dtype, B, cap, temp)
+        key = DecodeSession.make_key(self, B, cap, temp, top_p, top_k)
         pool = self._sessions
         with pool.lock:
             for k, ses in enumerate(pool.idle):
@@ -432,7 +428,7 @@ class MIDIModel(nn.Module):
                     return pool.idle.pop(k)
             while len(pool.idle) >= 4:  # bound the memory held by idle sessions
                 pool.idle.pop(0)
-        return DecodeSession(self, B, cap, temp)
+        return DecodeSession(self, B, cap, temp, top_p, top_k)
 
     def _return_session(self, ses) -> None:
         with self._sessions.lock:

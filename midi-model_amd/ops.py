@@ -120,6 +120,25 @@ def gemm_nt(a: torch.Tensor, b: torch.Tensor, out: torch.Tensor, *, K: Optional[
     return out
 
 
+SKINNY_PLAIN, SKINNY_NORM, SKINNY_SWIGLU = 0, 1, 2
+
+
+def gemm_skinny(a: torch.Tensor, w: torch.Tensor, out: torch.Tensor, *, mode: int = SKINNY_PLAIN,
+                norm_w: Optional[torch.Tensor] = None, eps: float = 0.0, res: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """decode-step projection out[M,N] = op(a) @ w[N,K]^T (+ res), M <= 64, bf16; see mh_gemm_skinny"""
+    M, N = out.shape
+    K = w.shape[1]
+    assert a.shape[0] == M and a.shape[1] == (2 * K if mode == SKINNY_SWIGLU else K), (a.shape, w.shape, mode)
+    lib().call("mh_gemm_skinny", _p(a), _rowmajor(a), _p(w), _rowmajor(w), _p(out), _rowmajor(out), _p(res),
+               _rowmajor(res) if res is not None else 0, _p(norm_w), eps, mode, M, N, K, dt(out), _stream())
+    return out
+
+
+def skinny_ok(x: torch.Tensor, K: int, norm: bool = False) -> bool:
+    """whether mh_gemm_skinny serves this decode projection (else: rmsnorm / swiglu kernels + mh_gemm)"""
+    return x.dtype == torch.bfloat16 and x.shape[0] <= 64 and K % 128 == 0 and (not norm or K <= 1024)
+
+
 gemm_profile = None  # set to a list to collect (start_event, end_event, flops, shape) per GEMM launch
 
 
@@ -303,6 +322,18 @@ def attn_decode(qkv, kc, vc, o, B: int, H: int, hd: int, Lmax: int, length: int,
 
 def kv_store_prefill(qkv, kc, vc, B: int, S: int, H: int, hd: int, Lmax: int):
     lib().call("mh_kv_store_prefill", _p(qkv), _p(kc), _p(vc), B, S, H, hd, Lmax, dt(qkv), _stream())
+
+
+SAMPLE_MAX_K = 64
+
+
+def sample_top_p_k(logits, lo, hi, first_mask, q, out, V: int, temp: float, top_p: float, top_k: int):
+    """fused masked softmax + top-p/top-k + draw; q [B, V] fp32 Exp(1) noise, out a strided int64 view [B]"""
+    B = logits.shape[0]
+    assert q.dtype == torch.float32 and q.is_contiguous() and q.shape == (B, V) and out.dtype == torch.int64
+    lib().call("mh_sample_top_p_k", _p(logits), _rowmajor(logits), _p(lo), _p(hi), _p(first_mask), _p(q), _p(out),
+               out.stride(0), B, V, temp, top_p, top_k, dt(logits), _stream())
+    return out
 
 
 def masked_softmax(logits, lo, hi, first_mask, probs, V: int, temp: float):

@@ -37,6 +37,30 @@ def gemm_nt(a, b, out, *, K=None, alpha=1.0, beta=0.0, res=None, splitk=0, ta=Fa
     return out
 
 
+SKINNY_PLAIN, SKINNY_NORM, SKINNY_SWIGLU = 0, 1, 2
+
+
+def skinny_ok(x, K, norm=False):
+    return x.dtype == torch.bfloat16 and x.shape[0] <= 64 and K % 128 == 0 and (not norm or K <= 1024)
+
+
+def gemm_skinny(a, w, out, *, mode=0, norm_w=None, eps=0.0, res=None):
+    K = w.shape[1]
+    if mode == SKINNY_NORM:
+        an = torch.empty_like(a)
+        rmsnorm_fwd(a, norm_w, an, None, eps)
+    elif mode == SKINNY_SWIGLU:
+        an = torch.empty((a.shape[0], K), dtype=a.dtype)
+        swiglu_fwd(a, an)
+    else:
+        an = a
+    r = an.float() @ w.float().T
+    if res is not None:
+        r = r + res.float()
+    out.copy_(r.to(out.dtype))
+    return out
+
+
 def transpose(x, out=None, pad_to=8):
     R, C = x.shape
     if out is None:
@@ -278,6 +302,23 @@ def kv_store_prefill(qkv, kc, vc, B, S, H, hd, Lmax):
     D = H * hd
     kc[:, :, :S] = qkv[:, D:2 * D].view(B, S, H, hd).transpose(1, 2)
     vc[:, :, :S] = qkv[:, 2 * D:].view(B, S, H, hd).transpose(1, 2)
+
+
+SAMPLE_MAX_K = 64
+
+
+def sample_top_p_k(logits, lo, hi, first_mask, q, out, V, temp, top_p, top_k):
+    B = logits.shape[0]
+    probs = torch.empty((B, V), dtype=torch.float32)
+    masked_softmax(logits, lo, hi, first_mask, probs, V, temp)
+    ps, pi = torch.sort(probs, dim=-1, descending=True, stable=True)
+    cum = torch.cumsum(ps, -1)
+    ps[cum - ps > top_p] = 0.0
+    ps[:, top_k:] = 0.0
+    ps = ps / ps.sum(-1, keepdim=True)
+    j = torch.argmax(ps / q, -1)
+    out.copy_(pi.gather(-1, j[:, None])[:, 0])
+    return out
 
 
 def masked_softmax(logits, lo, hi, first_mask, probs, V, temp):

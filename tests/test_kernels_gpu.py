@@ -79,6 +79,26 @@ def test_gemm_contraction_major_operands(ops, gemm_variant, dtype, ta, tb, M, N,
         cmp(out, want, dtype, k=max(1.0, K / 256), what=f"gemm ta={ta} tb={tb} {M}x{N}x{K} splitk={sk}")
 
 
+@pytest.mark.parametrize("mode", [0, 1, 2])
+@pytest.mark.parametrize("M,N,K", [(64, 3072, 1024), (1, 1024, 1024), (5, 3406, 1024), (64, 1024, 4096), (33, 2048, 128),
+                                   (64, 8192, 1024)])
+def test_gemm_skinny(ops, mode, M, N, K):
+    """decode-step projection with the RMSNorm / SwiGLU prologue fused (mh_gemm_skinny, bf16 only) against the unfused
+    chain rmsnorm_fwd / swiglu_fwd -> gemm on the CPU; residual epilogue; a narrowed output view (logits layout)"""
+    dtype = torch.bfloat16
+    if mode == 1 and K > 1024:
+        pytest.skip("the RMSNorm prologue serves K <= 1024 (every preset has D = 1024)")
+    a = rnd((M, 2 * K if mode == 2 else K), dtype, 11)
+    w, r, nw = rnd((N, K), dtype, 12, 0.05), rnd((M, N), dtype, 13), (1.0 + 0.1 * rnd((K,), torch.float32, 14)).to(dtype)
+    want = emu.gemm_skinny(a, w, torch.empty((M, N), dtype=dtype), mode=mode, norm_w=nw, eps=1e-6, res=r)
+    buf = torch.zeros((M, N + 24), dtype=dtype, device="cuda")
+    ops.gemm_skinny(a.cuda(), w.cuda(), buf[:, :N], mode=mode, norm_w=nw.cuda(), eps=1e-6, res=r.cuda())
+    cmp(buf[:, :N], want, dtype, k=max(1.0, K / 512), what=f"gemm_skinny mode={mode} {M}x{N}x{K}")
+    assert (buf[:, N:] == 0).all()
+    with pytest.raises(RuntimeError):
+        ops.gemm_skinny(torch.zeros((65, K), dtype=dtype, device="cuda"), w.cuda(), torch.zeros((65, N), dtype=dtype, device="cuda"))
+
+
 @pytest.mark.parametrize("dtype", DTYPES)
 def test_gemm_epilogue_views_splitk(ops, gemm_variant, dtype):
     M, N, K = 300, 520, 2048 + 64
@@ -374,3 +394,30 @@ def test_masked_softmax(ops, dtype):
     ops.masked_softmax(logits.cuda(), lo.cuda(), hi.cuda(), fm.cuda(), got, V, 0.8)
     cmp(got, want, torch.float32, k=(1 if dtype == torch.float32 else 20), what="masked softmax")
     assert ((got > 0).cpu() == (want > 0)).all()
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("top_p,top_k", [(0.98, 20), (0.5, 8), (1.0, 1), (0.9, 64)])
+def test_sample_top_p_k_fused(ops, dtype, top_p, top_k):
+    """the fused sampler against the op-by-op chain (masked softmax -> stable sort -> cumsum/top-p/top-k ->
+    argmax(p / q)) on the same Exp(1) noise: ids must agree.  bf16 logits produce many exactly-equal probabilities, so
+    the tie order (value descending, index ascending) is exercised; summation-order ulps may move a draw only at an
+    exact tie of p/q, which random noise does not produce."""
+    import midi_model_amd as mm
+    tok = mm.MIDITokenizerV2()
+    first, lo_t, hi_t, _ = tok.grammar_tables()
+    B, V, Vp = 64, tok.vocab_size, 3456
+    g = torch.Generator().manual_seed(77)
+    logits = torch.zeros((B, Vp), dtype=dtype)
+    logits[:, :V] = rnd((B, V), dtype, 37, 3.0)
+    ev = torch.randint(3, 9, (B,), generator=g)
+    pos = torch.randint(0, 3, (B,), generator=g)  # 0 = event id position (first_mask), else a parameter position
+    lo = torch.tensor([-1 if p == 0 else lo_t[e][p] for e, p in zip(ev.tolist(), pos.tolist())], dtype=torch.int32)
+    hi = torch.tensor([-1 if p == 0 else hi_t[e][p] for e, p in zip(ev.tolist(), pos.tolist())], dtype=torch.int32)
+    fm = torch.tensor(first, dtype=torch.uint8)
+    q = torch.empty((B, V)).exponential_(1.0, generator=g)
+    want = emu.sample_top_p_k(logits, lo, hi, fm, q, torch.empty((B,), dtype=torch.int64), V, 0.9, top_p, top_k)
+    buf = torch.full((B, 8), -7, dtype=torch.int64, device="cuda")
+    ops.sample_top_p_k(logits.cuda(), lo.cuda(), hi.cuda(), fm.cuda(), q.cuda(), buf[:, 3], V, 0.9, top_p, top_k)
+    assert (buf[:, 3].cpu() == want).all(), (buf[:, 3].cpu() != want).nonzero().flatten().tolist()
+    assert (buf[:, :3] == -7).all() and (buf[:, 4:] == -7).all()
