@@ -58,17 +58,14 @@ int mh_gemm(const void* A, int64_t lda, int transA, const void* B, int64_t ldb, 
 int mh_gemm_splitk_reduce(const void* workspace, void* C, int64_t ldc, const void* R, int64_t ldr, int64_t M,
                           int64_t N, int splitk, float alpha, float beta, int dtype, void* stream);
 /* Skinny projection of the decode step (replaces the per-token nn.Linear calls of LlamaAttention / LlamaMLP /
- * lm_head when q_len == 1, modeling_llama.py:243-281, 174-176; midi_model.py:135): C[M,N] = op(A)[M,K] * W[N,K]^T
- * (+ R), 1 <= M <= 64 rows, bf16, K a multiple of 128.  `mode` fuses the elementwise op that precedes the projection:
- *   MH_SKINNY_PLAIN   op(A) = A
- *   MH_SKINNY_NORM    op(A) = norm_w * round(A * rsqrt(mean_k(A^2) + eps))   (LlamaRMSNorm :62-67; K <= 1024)
- *   MH_SKINNY_SWIGLU  A is gate|up [M, 2K]; op(A) = round(silu(gate)) * up    (LlamaMLP :174-176)             */
+ * lm_head when q_len == 1, modeling_llama.py:243-281, 174-176; midi_model.py:135): 1 <= M <= 64 rows, bf16.
+ *   MH_SKINNY_PLAIN   C[M,N] = A[M,K] * W[N,K]^T (+ R)
+ *   MH_SKINNY_GATEUP  W = [gate; up] (2N rows): C[M,N] = round(silu(round(A gate^T))) * round(A up^T)   (LlamaMLP)
+ * K a multiple of 128.                                                                                         */
 #define MH_SKINNY_PLAIN 0
-#define MH_SKINNY_NORM 1
-#define MH_SKINNY_SWIGLU 2
+#define MH_SKINNY_GATEUP 1
 int mh_gemm_skinny(const void* A, int64_t lda, const void* W, int64_t ldw, void* C, int64_t ldc, const void* R,
-                   int64_t ldr, const void* norm_w, float eps, int mode, int64_t M, int64_t N, int64_t K, int dtype,
-                   void* stream);
+                   int64_t ldr, int mode, int64_t M, int64_t N, int64_t K, int dtype, void* stream);
 /* out[C,R] = in[R,C]^T (operand re-layout for dgrad/wgrad). */
 int mh_transpose(const void* in, int64_t ldi, void* out, int64_t ldo, int64_t rows, int64_t cols, int dtype,
                  void* stream);
@@ -179,6 +176,11 @@ int mh_kv_append(void* qkv, const float* cos_t, const float* sin_t, void* kcache
                  int hd, int64_t Lmax, int64_t pos, const int32_t* pos_dev, int dtype, void* stream);
 int mh_attn_decode(const void* qkv, const void* kcache, const void* vcache, void* o, int64_t B, int H, int hd,
                    int64_t Lmax, int64_t len, float scale, const int32_t* pos_dev, int dtype, void* stream);
+/* Both in one launch: qkv holds the unrotated q,k,v of position `pos` (or *pos_dev); every (b,h) block stores its rotated
+ * k row and v row in the cache, rotates q in registers and attends over rows [0, pos].  qkv is left untouched.        */
+int mh_attn_decode_append(const void* qkv, const float* cos_t, const float* sin_t, void* kcache, void* vcache, void* o,
+                          int64_t B, int H, int hd, int64_t Lmax, int64_t pos, float scale, const int32_t* pos_dev,
+                          int dtype, void* stream);
 /* copy rotated K and V of a prefill (qkv[B*S,3*H*hd]) into the cache rows [0,S).                           */
 int mh_kv_store_prefill(const void* qkv, void* kcache, void* vcache, int64_t B, int64_t S, int H, int hd,
                         int64_t Lmax, int dtype, void* stream);

@@ -263,11 +263,13 @@ extern "C" int mh_kv_store_prefill(const void* qkv, void* kcache, void* vcache, 
 
 // One block (4 waves) per (b,h).  LPK lanes cover one cached key row with 16-byte loads; every lane group
 // keeps an online-softmax state over its own subset of keys, merged at the end (groups, then waves).
-template <typename T, int HD>
-__global__ __launch_bounds__(256) void attn_decode_kernel(const T* __restrict__ qkv, const T* __restrict__ kc,
-                                                          const T* __restrict__ vc, T* __restrict__ o, int H,
+// APPEND: qkv holds the UNROTATED q,k,v of the new position; the block first rotates k and stores the k,v rows at index
+// len-1 of its (b,h) cache (what kv_append_kernel does), rotates q in registers, then attends over rows [0, len).
+template <typename T, int HD, bool APPEND>
+__global__ __launch_bounds__(256) void attn_decode_kernel(const T* __restrict__ qkv, T* kc, T* vc, T* __restrict__ o, int H,
                                                           int64_t Lmax, int64_t len, float scale,
-                                                          const int32_t* __restrict__ pos_dev) {
+                                                          const int32_t* __restrict__ pos_dev,
+                                                          const float* __restrict__ cos_t, const float* __restrict__ sin_t) {
   if (pos_dev != nullptr) len = (int64_t)*pos_dev + 1;  // graph replay: attend to rows [0, pos]
   if (len > Lmax) len = Lmax;
   constexpr int N = Pack<T>::N;
@@ -281,10 +283,37 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(const T* __restrict__ 
   const int h = (int)(bh - b * H);
   const int64_t D = (int64_t)H * HD;
   const int ch = lane % LPK, grp = lane / LPK;
-  Pack<T> qv = ld16(qkv + b * 3 * D + (int64_t)h * HD + ch * N);
+  const T* qrow = qkv + b * 3 * D + (int64_t)h * HD;
+  Pack<T> qv = ld16(qrow + ch * N);
   float q[N];
+  if constexpr (APPEND) {
+    constexpr int half = HD / 2;
+    const int64_t pos = len - 1;
+    if (threadIdx.x < half) {  // k row (rotated) and v row of the new position -> cache
+      const int i = threadIdx.x;
+      const float c = rnd<T>(cos_t[pos * half + i]), sn = rnd<T>(sin_t[pos * half + i]);
+      const float k1 = to_f(qrow[D + i]), k2 = to_f(qrow[D + i + half]);
+      T* kd = kc + (bh * Lmax + pos) * HD;
+      T* vd = vc + (bh * Lmax + pos) * HD;
+      kd[i] = from_f<T>(k1 * c - k2 * sn);
+      kd[i + half] = from_f<T>(k2 * c + k1 * sn);
+      vd[i] = qrow[2 * D + i];
+      vd[i + half] = qrow[2 * D + i + half];
+    }
+    const int base = ch * N;  // this lane's q elements and their rotation partners (i, i + half)
+    Pack<T> qp = ld16(qrow + (base + half) % HD);
 #pragma unroll
-  for (int e = 0; e < N; ++e) q[e] = qv.get(e) * scale;
+    for (int e = 0; e < N; ++e) {
+      const int i = (base + e) % half;
+      const float c = rnd<T>(cos_t[pos * half + i]), sn = rnd<T>(sin_t[pos * half + i]);
+      const float r = (base < half) ? qv.get(e) * c - qp.get(e) * sn : qv.get(e) * c + qp.get(e) * sn;
+      q[e] = rnd<T>(r) * scale;
+    }
+    __syncthreads();  // the new k,v rows are visible to the whole block
+  } else {
+#pragma unroll
+    for (int e = 0; e < N; ++e) q[e] = qv.get(e) * scale;
+  }
   float m = -INFINITY, l = 0.f, acc[N];
 #pragma unroll
   for (int e = 0; e < N; ++e) acc[e] = 0.f;
@@ -344,15 +373,24 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(const T* __restrict__ 
   }
 }
 
-extern "C" int mh_attn_decode(const void* qkv, const void* kcache, const void* vcache, void* o, int64_t B, int H, int hd,
-                              int64_t Lmax, int64_t len, float scale, const int32_t* pos_dev, int dtype, void* stream) {
+static int attn_decode_launch(const void* qkv, const float* cos_t, const float* sin_t, void* kcache, void* vcache, void* o,
+                              int64_t B, int H, int hd, int64_t Lmax, int64_t len, float scale, const int32_t* pos_dev,
+                              int dtype, void* stream) {
   MH_REQUIRE(B > 0 && H > 0 && ((len > 0 && len <= Lmax) || pos_dev != nullptr), "attn_decode: bad args len=%ld Lmax=%ld",
              (long)len, (long)Lmax);
   MH_REQUIRE(hd == 64 || hd == 256, "attn_decode: head_dim %d unsupported (64 or 256)", hd);
   hipStream_t st = (hipStream_t)stream;
   const int grid = (int)(B * H);
-#define LAUNCH_DEC(TT, HDV) \
-  attn_decode_kernel<TT, HDV><<<grid, 256, 0, st>>>((const TT*)qkv, (const TT*)kcache, (const TT*)vcache, (TT*)o, H, Lmax, len, scale, pos_dev)
+  const bool app = cos_t != nullptr;
+#define LAUNCH_DEC(TT, HDV)                                                                                               \
+  do {                                                                                                                    \
+    if (app)                                                                                                              \
+      attn_decode_kernel<TT, HDV, true><<<grid, 256, 0, st>>>((const TT*)qkv, (TT*)kcache, (TT*)vcache, (TT*)o, H, Lmax,    \
+                                                              len, scale, pos_dev, cos_t, sin_t);                         \
+    else                                                                                                                  \
+      attn_decode_kernel<TT, HDV, false><<<grid, 256, 0, st>>>((const TT*)qkv, (TT*)kcache, (TT*)vcache, (TT*)o, H, Lmax,   \
+                                                               len, scale, pos_dev, cos_t, sin_t);                        \
+  } while (0)
   if (dtype == MH_BF16) {
     if (hd == 64) LAUNCH_DEC(bf16, 64); else LAUNCH_DEC(bf16, 256);
   } else if (dtype == MH_F32) {
@@ -364,6 +402,19 @@ extern "C" int mh_attn_decode(const void* qkv, const void* kcache, const void* v
 #undef LAUNCH_DEC
   MH_LAUNCH_CHECK();
   return MH_OK;
+}
+
+extern "C" int mh_attn_decode(const void* qkv, const void* kcache, const void* vcache, void* o, int64_t B, int H, int hd,
+                              int64_t Lmax, int64_t len, float scale, const int32_t* pos_dev, int dtype, void* stream) {
+  return attn_decode_launch(qkv, nullptr, nullptr, (void*)kcache, (void*)vcache, o, B, H, hd, Lmax, len, scale, pos_dev, dtype,
+                            stream);
+}
+
+extern "C" int mh_attn_decode_append(const void* qkv, const float* cos_t, const float* sin_t, void* kcache, void* vcache,
+                                     void* o, int64_t B, int H, int hd, int64_t Lmax, int64_t pos, float scale,
+                                     const int32_t* pos_dev, int dtype, void* stream) {
+  MH_REQUIRE(cos_t != nullptr && sin_t != nullptr, "attn_decode_append: needs the rope tables");
+  return attn_decode_launch(qkv, cos_t, sin_t, kcache, vcache, o, B, H, hd, Lmax, pos + 1, scale, pos_dev, dtype, stream);
 }
 
 // ---------------------------------------------------------------------------------------------------

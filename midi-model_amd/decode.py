@@ -85,11 +85,10 @@ class DecodeSession:
         x = self.hidden if i == 0 else Wt.embed.index_select(0, self.samples_in)
         self.kv2.len = i
         lm_w = m.lm_head.weight.data
-        if ops.skinny_ok(x, tspec.D, norm=True):  # final RMSNorm fused into the lm_head projection
-            h = engine.stack_decode(tspec, Wt, x, self.rope2, self.kv2, final_norm=False)
-            ops.gemm_skinny(h, lm_w, self.logits[:, : self.V], mode=ops.SKINNY_NORM, norm_w=Wt.norm, eps=tspec.eps)
+        h = engine.stack_decode(tspec, Wt, x, self.rope2, self.kv2)
+        if ops.skinny_ok(h, tspec.D):
+            ops.gemm_skinny(h, lm_w, self.logits[:, : self.V])
         else:
-            h = engine.stack_decode(tspec, Wt, x, self.rope2, self.kv2)
             ops.gemm_nt(h, lm_w, self.logits[:, : self.V])
         if i == 0:
             lo, hi = self.neg1, self.neg1

@@ -227,18 +227,14 @@ def stack_prefill(spec: StackSpec, W: StackTensors, x: torch.Tensor, nseq: int, 
     return y
 
 
-def stack_decode(spec: StackSpec, W: StackTensors, x: torch.Tensor, rope: RopeTable, kv: KVState, pos_dev=None,
-                 final_norm: bool = True):
+def stack_decode(spec: StackSpec, W: StackTensors, x: torch.Tensor, rope: RopeTable, kv: KVState, pos_dev=None):
     """x [B, D]: one new position per sequence at index kv.len (q_len == 1 => no causal mask,
     TF:integrations/sdpa_attention.py:120).
 
     With ``pos_dev`` (device int32[1]) the kernels take the position from device memory instead -- the form a captured
     hipGraph replays (decode.py); capacity and rope table must already cover it and kv.len is left to the caller.
-    ``final_norm=False`` returns the residual stream before the stack's last RMSNorm (the caller fuses that norm into
-    its own projection, as decode.py does with lm_head).
-
-    bf16 with at most 64 sequences runs each layer as 6 launches (mh_gemm_skinny with the RMSNorm / SwiGLU prologues);
-    otherwise the general kernels are used (13 launches)."""
+    bf16 with at most 64 sequences runs the projections on mh_gemm_skinny: 7 launches per layer, K/V append fused into the attention, gate|up and SwiGLU
+    fused; otherwise the general GEMM is used (9 launches + split-K reductions)."""
     _check_heads(spec)
     B, D = x.shape
     H, I, hd = spec.H, spec.I, spec.hd
@@ -246,20 +242,23 @@ def stack_decode(spec: StackSpec, W: StackTensors, x: torch.Tensor, rope: RopeTa
     if pos_dev is None:
         kv.reserve(pos + 1)
         rope.ensure(pos + 1)
-    fused = ops.skinny_ok(x, D, norm=True) and ops.skinny_ok(x, I)
+    fused = ops.skinny_ok(x, D) and ops.skinny_ok(x, I)
     for li, lw in enumerate(W.layers):
         if fused:
+            h1 = _empty((B, D), x)
+            ops.rmsnorm_fwd(x, lw.n1, h1, None, spec.eps)
             qkv = _empty((B, 3 * D), x)
-            ops.gemm_skinny(x, lw.wqkv, qkv, mode=ops.SKINNY_NORM, norm_w=lw.n1, eps=spec.eps)
-            ops.kv_append(qkv, rope.cos, rope.sin, kv.k[li], kv.v[li], B, H, hd, kv.cap, pos, pos_dev)
-            o = _empty((B, D), x)
-            ops.attn_decode(qkv, kv.k[li], kv.v[li], o, B, H, hd, kv.cap, pos + 1, spec.scale, pos_dev)
+            ops.gemm_skinny(h1, lw.wqkv, qkv)
+            o = h1
+            ops.attn_decode_append(qkv, rope.cos, rope.sin, kv.k[li], kv.v[li], o, B, H, hd, kv.cap, pos, spec.scale, pos_dev)
             x2 = _empty((B, D), x)
             ops.gemm_skinny(o, lw.wo, x2, res=x)
-            gu = _empty((B, 2 * I), x)
-            ops.gemm_skinny(x2, lw.wgu, gu, mode=ops.SKINNY_NORM, norm_w=lw.n2, eps=spec.eps)
+            h2 = o
+            ops.rmsnorm_fwd(x2, lw.n2, h2, None, spec.eps)
+            a = _empty((B, I), x)
+            ops.gemm_skinny(h2, lw.wgu, a, mode=ops.SKINNY_GATEUP)  # gate|up never materialised
             x3 = _empty((B, D), x)
-            ops.gemm_skinny(gu, lw.wd, x3, mode=ops.SKINNY_SWIGLU, res=x2)
+            ops.gemm_skinny(a, lw.wd, x3, res=x2)
             x = x3
             continue
         h1 = _empty((B, D), x)
@@ -282,8 +281,6 @@ def stack_decode(spec: StackSpec, W: StackTensors, x: torch.Tensor, rope: RopeTa
         x = x3
     if pos_dev is None:
         kv.len = pos + 1
-    if not final_norm:
-        return x
     y = _empty((B, D), x)
     ops.rmsnorm_fwd(x, W.norm, y, None, spec.eps)
     return y

@@ -120,23 +120,24 @@ def gemm_nt(a: torch.Tensor, b: torch.Tensor, out: torch.Tensor, *, K: Optional[
     return out
 
 
-SKINNY_PLAIN, SKINNY_NORM, SKINNY_SWIGLU = 0, 1, 2
+SKINNY_PLAIN, SKINNY_GATEUP = 0, 1
 
 
 def gemm_skinny(a: torch.Tensor, w: torch.Tensor, out: torch.Tensor, *, mode: int = SKINNY_PLAIN,
-                norm_w: Optional[torch.Tensor] = None, eps: float = 0.0, res: Optional[torch.Tensor] = None) -> torch.Tensor:
-    """decode-step projection out[M,N] = op(a) @ w[N,K]^T (+ res), M <= 64, bf16; see mh_gemm_skinny"""
+                res: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """decode-step projection, M <= 64 rows, bf16 (mh_gemm_skinny): out[M,N] = a @ w[N,K]^T (+ res), or with
+    SKINNY_GATEUP w = [gate; up] ([2N,K]) and out[M,N] = silu(a @ gate^T) * (a @ up^T)."""
     M, N = out.shape
     K = w.shape[1]
-    assert a.shape[0] == M and a.shape[1] == (2 * K if mode == SKINNY_SWIGLU else K), (a.shape, w.shape, mode)
+    assert a.shape == (M, K) and w.shape[0] == (2 * N if mode == SKINNY_GATEUP else N), (a.shape, w.shape, out.shape, mode)
     lib().call("mh_gemm_skinny", _p(a), _rowmajor(a), _p(w), _rowmajor(w), _p(out), _rowmajor(out), _p(res),
-               _rowmajor(res) if res is not None else 0, _p(norm_w), eps, mode, M, N, K, dt(out), _stream())
+               _rowmajor(res) if res is not None else 0, mode, M, N, K, dt(out), _stream())
     return out
 
 
-def skinny_ok(x: torch.Tensor, K: int, norm: bool = False) -> bool:
-    """whether mh_gemm_skinny serves this decode projection (else: rmsnorm / swiglu kernels + mh_gemm)"""
-    return x.dtype == torch.bfloat16 and x.shape[0] <= 64 and K % 128 == 0 and (not norm or K <= 1024)
+def skinny_ok(x: torch.Tensor, K: int) -> bool:
+    """whether mh_gemm_skinny serves this decode projection (else mh_gemm)"""
+    return x.dtype == torch.bfloat16 and x.shape[0] <= 64 and K % 128 == 0
 
 
 gemm_profile = None  # set to a list to collect (start_event, end_event, flops, shape) per GEMM launch
@@ -317,6 +318,13 @@ def kv_append(qkv, cos_t, sin_t, kc, vc, B: int, H: int, hd: int, Lmax: int, pos
 def attn_decode(qkv, kc, vc, o, B: int, H: int, hd: int, Lmax: int, length: int, scale: float, pos_dev=None):
     lib().call("mh_attn_decode", _p(qkv), _p(kc), _p(vc), _p(o), B, H, hd, Lmax, length, scale, _p(pos_dev), dt(qkv),
                _stream())
+    return o
+
+
+def attn_decode_append(qkv, cos_t, sin_t, kc, vc, o, B: int, H: int, hd: int, Lmax: int, pos: int, scale: float, pos_dev=None):
+    """kv_append + attn_decode in one launch (qkv is read unrotated and left untouched)"""
+    lib().call("mh_attn_decode_append", _p(qkv), _p(cos_t), _p(sin_t), _p(kc), _p(vc), _p(o), B, H, hd, Lmax, pos, scale,
+               _p(pos_dev), dt(qkv), _stream())
     return o
 
 

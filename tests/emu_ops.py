@@ -37,24 +37,19 @@ def gemm_nt(a, b, out, *, K=None, alpha=1.0, beta=0.0, res=None, splitk=0, ta=Fa
     return out
 
 
-SKINNY_PLAIN, SKINNY_NORM, SKINNY_SWIGLU = 0, 1, 2
+SKINNY_PLAIN, SKINNY_GATEUP = 0, 1
 
 
-def skinny_ok(x, K, norm=False):
-    return x.dtype == torch.bfloat16 and x.shape[0] <= 64 and K % 128 == 0 and (not norm or K <= 1024)
+def skinny_ok(x, K):
+    return x.dtype == torch.bfloat16 and x.shape[0] <= 64 and K % 128 == 0
 
 
-def gemm_skinny(a, w, out, *, mode=0, norm_w=None, eps=0.0, res=None):
-    K = w.shape[1]
-    if mode == SKINNY_NORM:
-        an = torch.empty_like(a)
-        rmsnorm_fwd(a, norm_w, an, None, eps)
-    elif mode == SKINNY_SWIGLU:
-        an = torch.empty((a.shape[0], K), dtype=a.dtype)
-        swiglu_fwd(a, an)
-    else:
-        an = a
-    r = an.float() @ w.float().T
+def gemm_skinny(a, w, out, *, mode=0, res=None):
+    r = a.float() @ w.float().T
+    if mode == SKINNY_GATEUP:
+        gu = r.to(a.dtype)
+        swiglu_fwd(gu, out)
+        return out
     if res is not None:
         r = r + res.float()
     out.copy_(r.to(out.dtype))
@@ -296,6 +291,14 @@ def attn_decode(qkv, kc, vc, o, B, H, hd, Lmax, length, scale, pos_dev=None):
     p = torch.softmax((q @ k.transpose(-1, -2)) * scale, -1)
     o.copy_((p @ v).reshape(B, H * hd).to(o.dtype))
     return o
+
+
+def attn_decode_append(qkv, cos_t, sin_t, kc, vc, o, B, H, hd, Lmax, pos, scale, pos_dev=None):
+    if pos_dev is not None:
+        pos = int(pos_dev.item())
+    tmp = qkv.clone()
+    kv_append(tmp, cos_t, sin_t, kc, vc, B, H, hd, Lmax, pos)
+    return attn_decode(tmp, kc, vc, o, B, H, hd, Lmax, pos + 1, scale)
 
 
 def kv_store_prefill(qkv, kc, vc, B, S, H, hd, Lmax):
