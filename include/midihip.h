@@ -61,7 +61,7 @@ int mh_gemm_splitk_reduce(const void* workspace, void* C, int64_t ldc, const voi
  * lm_head when q_len == 1, modeling_llama.py:243-281, 174-176; midi_model.py:135): 1 <= M <= 64 rows, bf16.
  *   MH_SKINNY_PLAIN   C[M,N] = A[M,K] * W[N,K]^T (+ R)
  *   MH_SKINNY_GATEUP  W = [gate; up] (2N rows): C[M,N] = round(silu(round(A gate^T))) * round(A up^T)   (LlamaMLP)
- * K a multiple of 128.                                                                                         */
+ * K a multiple of 256.                                                                                         */
 #define MH_SKINNY_PLAIN 0
 #define MH_SKINNY_GATEUP 1
 int mh_gemm_skinny(const void* A, int64_t lda, const void* W, int64_t ldw, void* C, int64_t ldc, const void* R,
@@ -192,14 +192,20 @@ int mh_masked_softmax(const void* logits, int64_t ldl, const int32_t* lo, const 
                       const uint8_t* first_mask, float* probs, int64_t B, int V, float temp, int dtype,
                       void* stream);
 /* Fused sampler of one token position (midi_model.py:202-228, 152-165; torch.multinomial's single-draw path):
- * masked softmax as above, keep the top_k largest (value descending, index ascending), zero those whose preceding
- * cumulative mass exceeds top_p, renormalise, and return for every row the id maximising p_j / q[b, j], where q
- * [B, V] holds Exp(1) draws (only the first top_k of a row are read) taken by the caller from the caller's generator
- * (torch.Tensor.exponential_), which is what keeps a seeded generator's stream identical to the reference's.
- * out[b * out_stride] = sampled id (int64).  1 <= top_k <= 64.                                              */
-int mh_sample_top_p_k(const void* logits, int64_t ldl, const int32_t* lo, const int32_t* hi,
-                      const uint8_t* first_mask, const float* q, int64_t* out, int64_t out_stride, int64_t B, int V,
-                      float temp, float top_p, int top_k, int dtype, void* stream);
+ * softmax(logits / temp) masked by the grammar -- position 0: `first_mask` (event ids + EOS); position pos >= 1: ids in
+ * [lo_tab[e][pos], hi_tab[e][pos]) for the row's event id e = ev[b] (tables [*, tab_stride] int32) -- then keep the
+ * top_k largest (value descending, index ascending), zero those whose preceding cumulative mass exceeds top_p,
+ * renormalise, and return for every row the id maximising p_j / q[b, j], where q [B, V] holds Exp(1) draws (only the
+ * first top_k of a row are read) taken by the caller from the caller's generator (torch.Tensor.exponential_), which is
+ * what keeps a seeded generator's stream identical to the reference's.  The id goes to out[b * out_stride] and, when
+ * non-null, to out_b[b] and out_c[b] (all int64).  1 <= top_k <= 64.  The caller states the spans of the masks:
+ * first_mask is zero outside [first_lo, first_hi), no table range AT THIS POSITION is longer than max_range; both at most
+ * 2048 ids.                                                                                                 */
+int mh_sample_top_p_k(const void* logits, int64_t ldl, const uint8_t* first_mask, int first_lo, int first_hi,
+                      const int32_t* lo_tab, const int32_t* hi_tab, int tab_stride, int max_range, const int64_t* ev,
+                      int pos, const float* q, int64_t* out,
+                      int64_t out_stride, int64_t* out_b, int64_t* out_c, int64_t B, int V, float temp, float top_p,
+                      int top_k, int dtype, void* stream);
 
 #ifdef __cplusplus
 }

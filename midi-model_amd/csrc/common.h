@@ -57,15 +57,18 @@ template <typename T> __device__ inline T from_f(float x) { return (T)x; }
 template <typename T> __device__ inline float rnd(float x) { return (float)(T)x; }
 
 // ---- wave reductions --------------------------------------------------------------------------
+// All-lanes reductions.  The butterfly alone leaves every lane with the same value only if no lane's first addition is
+// contracted with the multiply that produced its operand (fma(a, b, partner) != fma(a', b', own) in the last bit, seen
+// as a 1-ulp difference between wave halves in the sampler), so the result is re-broadcast from one lane.
 __device__ inline float wave_sum(float v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-  return v;
+  return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(v)));
 }
 __device__ inline float wave_max(float v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
-  return v;
+  return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(v)));
 }
 
 // All-lanes sum without touching the LDS pipe: 4 DPP steps inside each 16-lane row (quad swaps, half-row and
@@ -86,6 +89,39 @@ __device__ inline float wave_sum_fast(float v) {
   const int iw = __float_as_int(v);
   auto b = __builtin_amdgcn_permlane32_swap(iw, iw, false, false);
   return __int_as_float(b[0]) + __int_as_float(b[1]);
+}
+
+// max over the wave of 64-bit keys (every lane gets it).  Same DPP / permlane ladder as wave_sum_fast, no LDS round
+// trips.  An arg-max with a tie rule is a max over keys (value bits << 32 | rank of the index), see the sampler.
+template <int CTRL> __device__ inline uint32_t dpp_move_u(uint32_t v) {
+  return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, 0xf, 0xf, true);
+}
+__device__ inline uint64_t wave_max_u64_fast(uint64_t k) {
+  uint32_t hi = (uint32_t)(k >> 32), lo = (uint32_t)k;
+  auto take = [&](uint32_t ohi, uint32_t olo) {
+    const bool better = ohi > hi || (ohi == hi && olo > lo);
+    hi = better ? ohi : hi;
+    lo = better ? olo : lo;
+  };
+  take(dpp_move_u<0xB1>(hi), dpp_move_u<0xB1>(lo));
+  take(dpp_move_u<0x4E>(hi), dpp_move_u<0x4E>(lo));
+  take(dpp_move_u<0x141>(hi), dpp_move_u<0x141>(lo));
+  take(dpp_move_u<0x140>(hi), dpp_move_u<0x140>(lo));
+  {
+    auto a = __builtin_amdgcn_permlane16_swap(hi, hi, false, false);
+    auto b = __builtin_amdgcn_permlane16_swap(lo, lo, false, false);
+    hi = a[0];
+    lo = b[0];
+    take(a[1], b[1]);
+  }
+  {
+    auto a = __builtin_amdgcn_permlane32_swap(hi, hi, false, false);
+    auto b = __builtin_amdgcn_permlane32_swap(lo, lo, false, false);
+    hi = a[0];
+    lo = b[0];
+    take(a[1], b[1]);
+  }
+  return ((uint64_t)hi << 32) | lo;
 }
 
 // ---- LDS tile format shared by the MFMA kernels -----------------------------------------------

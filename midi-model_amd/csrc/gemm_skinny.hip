@@ -19,16 +19,18 @@
 
 namespace {
 
-template <int MODE, int NBT>  // NBT: 16-column blocks of W per workgroup (GATEUP: 1 gate + 1 up block)
-__global__ __launch_bounds__(256) void gemm_skinny_kernel(const bf16* __restrict__ A, int64_t lda,
+// NBT: 16-column blocks of W per workgroup (GATEUP: 1 gate + 1 up block); NW: waves per workgroup (K is dealt to them in
+// 32-deep chunks: 8 chunks per wave are in flight at a time, so long contractions take 8 waves)
+template <int MODE, int NBT, int NW>
+__global__ __launch_bounds__(NW * 64) void gemm_skinny_kernel(const bf16* __restrict__ A, int64_t lda,
                                                           const bf16* __restrict__ W, int64_t ldw, bf16* __restrict__ C,
                                                           int64_t ldc, const bf16* __restrict__ R, int64_t ldr, int M, int N,
                                                           int K) {
   constexpr int NB = NBT * 16;
-  __shared__ float red[4][64][NB + 1];
+  __shared__ float red[NW][64][NB + 1];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int fi = lane & 15, fg = lane >> 4;
-  const int nc_w = K / 128;  // chunks of 32 per wave (wave w takes chunks w, w+4, ...)
+  const int nc_w = K / (32 * NW);  // chunks of 32 per wave (wave w takes chunks w, w+NW, ...)
 
   const bf16* arow[4];
   const bf16* wrow[NBT];
@@ -56,9 +58,9 @@ __global__ __launch_bounds__(256) void gemm_skinny_kernel(const bf16* __restrict
 #pragma unroll
     for (int nb = 0; nb < NBT; ++nb) acc[mb][nb] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-#pragma unroll 4
+#pragma unroll 8
   for (int ci = 0; ci < nc_w; ++ci) {
-    const int k = (wave + 4 * ci) * 32;
+    const int k = (wave + NW * ci) * 32;
     bf16x8 wf[NBT], xf[4];
 #pragma unroll
     for (int nb = 0; nb < NBT; ++nb) wf[nb] = *reinterpret_cast<const bf16x8*>(wrow[nb] + k);
@@ -79,9 +81,15 @@ __global__ __launch_bounds__(256) void gemm_skinny_kernel(const bf16* __restrict
 #pragma unroll
       for (int e = 0; e < 4; ++e) red[wave][mb * 16 + fi][nb * 16 + 4 * fg + e] = acc[mb][nb][e];
   __syncthreads();
+  if (threadIdx.x >= 256) return;  // the first four waves write the tile
   const int m = threadIdx.x >> 2;
   if (m >= M) return;
-  auto total = [&](int c) { return red[0][m][c] + red[1][m][c] + red[2][m][c] + red[3][m][c]; };
+  auto total = [&](int c) {
+    float t = red[0][m][c];
+#pragma unroll
+    for (int w = 1; w < NW; ++w) t += red[w][m][c];
+    return t;
+  };
   if constexpr (MODE == 1) {
     const int c0 = (threadIdx.x & 3) * 4;  // 16 output columns per workgroup, 4 per thread
 #pragma unroll
@@ -115,17 +123,18 @@ extern "C" int mh_gemm_skinny(const void* A, int64_t lda, const void* W, int64_t
   MH_REQUIRE(dtype == MH_BF16, "gemm_skinny: bf16 only (the fp32 verification mode uses mh_gemm)");
   MH_REQUIRE(M > 0 && M <= 64 && N > 0 && N < (1 << 24), "gemm_skinny: needs 1 <= M <= 64 rows (M=%ld N=%ld)", (long)M, (long)N);
   MH_REQUIRE(mode == MH_SKINNY_PLAIN || mode == MH_SKINNY_GATEUP, "gemm_skinny: mode %d", mode);
-  MH_REQUIRE(K > 0 && K % 128 == 0 && K < (1 << 24), "gemm_skinny: K=%ld must be a multiple of 128", (long)K);
+  MH_REQUIRE(K > 0 && K % 256 == 0 && K < (1 << 24), "gemm_skinny: K=%ld must be a multiple of 256", (long)K);
   MH_REQUIRE(lda % 8 == 0 && ldw % 8 == 0 && ((uintptr_t)A & 15) == 0 && ((uintptr_t)W & 15) == 0,
              "gemm_skinny: A/W rows must be 16-byte aligned");
   MH_REQUIRE(mode != MH_SKINNY_GATEUP || R == nullptr, "gemm_skinny: the gate|up epilogue takes no residual");
   hipStream_t st = (hipStream_t)stream;
-#define MH_SK(MODE_, NBT_, GRID_)                                                                                      \
-  gemm_skinny_kernel<MODE_, NBT_><<<(int)(GRID_), 256, 0, st>>>((const bf16*)A, lda, (const bf16*)W, ldw, (bf16*)C, ldc, \
-                                                               (const bf16*)R, ldr, (int)M, (int)N, (int)K)
-  if (mode == MH_SKINNY_GATEUP) MH_SK(1, 2, (N + 15) / 16);
-  else if (N <= 2048) MH_SK(0, 1, (N + 15) / 16);
-  else MH_SK(0, 2, (N + 31) / 32);
+#define MH_SK(MODE_, NBT_, NW_, GRID_)                                                                                  \
+  gemm_skinny_kernel<MODE_, NBT_, NW_><<<(int)(GRID_), NW_ * 64, 0, st>>>((const bf16*)A, lda, (const bf16*)W, ldw, (bf16*)C, \
+                                                                          ldc, (const bf16*)R, ldr, (int)M, (int)N, (int)K)
+  if (mode == MH_SKINNY_GATEUP) MH_SK(1, 2, 4, (N + 15) / 16);
+  else if (N > 2048) MH_SK(0, 2, 4, (N + 31) / 32);
+  else if (K >= 2048) MH_SK(0, 1, 8, (N + 15) / 16);
+  else MH_SK(0, 1, 4, (N + 15) / 16);
 #undef MH_SK
   MH_LAUNCH_CHECK();
   return MH_OK;

@@ -245,21 +245,21 @@ template <typename T>
 __global__ __launch_bounds__(256) void masked_softmax_kernel(const T* __restrict__ logits, int64_t ldl,
                                                              const int32_t* __restrict__ lo, const int32_t* __restrict__ hi,
                                                              const uint8_t* __restrict__ first_mask,
-                                                             float* __restrict__ probs, int64_t B, int V, float inv_temp) {
+                                                             float* __restrict__ probs, int64_t B, int V, float temp) {
   const int lane = threadIdx.x & 63;
   for (int64_t b = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); b < B; b += (int64_t)gridDim.x * 4) {
     const T* row = logits + b * ldl;
     float mx = -INFINITY;
-    for (int c = lane; c < V; c += 64) mx = fmaxf(mx, rnd<T>(to_f(row[c]) * inv_temp));
+    for (int c = lane; c < V; c += 64) mx = fmaxf(mx, rnd<T>(to_f(row[c]) / temp));
     mx = wave_max(mx);
     float sum = 0.f;
-    for (int c = lane; c < V; c += 64) sum += __expf(rnd<T>(to_f(row[c]) * inv_temp) - mx);
+    for (int c = lane; c < V; c += 64) sum += __expf(rnd<T>(to_f(row[c]) / temp) - mx);
     sum = wave_sum(sum);
     const float inv = 1.f / sum;
     const int l = lo[b], h = hi[b];
     for (int c = lane; c < V; c += 64) {
       const bool ok = (l < 0) ? (first_mask[c] != 0) : (c >= l && c < h);
-      probs[b * V + c] = ok ? __expf(rnd<T>(to_f(row[c]) * inv_temp) - mx) * inv : 0.f;
+      probs[b * V + c] = ok ? __expf(rnd<T>(to_f(row[c]) / temp) - mx) * inv : 0.f;
     }
   }
 }
@@ -269,7 +269,7 @@ extern "C" int mh_masked_softmax(const void* logits, int64_t ldl, const int32_t*
                                  void* stream) {
   MH_REQUIRE(B > 0 && V > 0 && temp > 0.f, "masked_softmax: bad args");
   DISPATCH_T(dtype, (masked_softmax_kernel<T><<<(int)((B + 3) / 4), 256, 0, (hipStream_t)stream>>>(
-                        (const T*)logits, ldl, lo, hi, first_mask, probs, B, V, 1.f / temp)));
+                        (const T*)logits, ldl, lo, hi, first_mask, probs, B, V, temp)));
   MH_LAUNCH_CHECK();
   return MH_OK;
 }
@@ -286,118 +286,141 @@ extern "C" int mh_masked_softmax(const void* logits, int64_t ldl, const int32_t*
 // ---------------------------------------------------------------------------------------------------
 constexpr int SAMPLE_MAX_K = 64;
 
-template <typename T>
+// One block per row.  Only ids inside the grammar mask can be drawn, and the mask of a position is a
+// contiguous id range of at most SAMPLE_MAX_RANGE ids (the largest parameter range, `duration`, has 2048): a lane keeps
+// the probabilities of its <= 32 candidates (c = lo + lane + 64 t) in registers with a bit mask of the ones already taken,
+// and a round is a register arg-max plus one DPP ladder over the wave -- no LDS traffic, no block barrier; this part
+// runs on wave 0.  The softmax denominator runs over the whole vocabulary: one online max/sum pass shared by the block's
+// four waves (the exact fp32 division by the temperature makes it the expensive part).
+constexpr int SAMPLE_MAX_RANGE = 2048;
+
+template <typename T, int TMAX>  // TMAX: candidates per lane (64 * TMAX >= the longest mask range of this position)
 __global__ __launch_bounds__(256) void sample_top_p_k_kernel(const T* __restrict__ logits, int64_t ldl,
-                                                             const int32_t* __restrict__ lo, const int32_t* __restrict__ hi,
                                                              const uint8_t* __restrict__ first_mask,
-                                                             const float* __restrict__ q, int64_t* __restrict__ out,
-                                                             int64_t out_stride, int V, float inv_temp, float top_p,
-                                                             int top_k) {
-  extern __shared__ float sp[];  // [V] probabilities
-  __shared__ float red_v[4];
-  __shared__ int red_i[4];
-  __shared__ float sel_v[SAMPLE_MAX_K];
-  __shared__ int sel_i[SAMPLE_MAX_K];
-  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+                                                             const int32_t* __restrict__ lo_tab,
+                                                             const int32_t* __restrict__ hi_tab, int tab_stride,
+                                                             const int64_t* __restrict__ ev, int pos, int first_lo,
+                                                             int first_hi, const float* __restrict__ q,
+                                                             int64_t* __restrict__ out, int64_t out_stride,
+                                                             int64_t* __restrict__ out_b, int64_t* __restrict__ out_c,
+                                                             int64_t B, int V, float temp, float top_p, int top_k) {
+  __shared__ float sel_v[1][SAMPLE_MAX_K];
+  __shared__ int sel_i[1][SAMPLE_MAX_K];
+  __shared__ float part_m[4], part_s[4];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  constexpr int wv = 0;
   const int64_t b = blockIdx.x;
   const T* row = logits + b * ldl;
-  float mx = -INFINITY;
-  for (int c = tid; c < V; c += 256) {
-    const float z = rnd<T>(to_f(row[c]) * inv_temp);
-    sp[c] = z;
-    mx = fmaxf(mx, z);
+  // softmax statistics over the whole vocabulary
+  float m = -INFINITY, ssum = 0.f;
+  for (int c = threadIdx.x; c < V; c += 256) {
+    const float z = rnd<T>(to_f(row[c]) / temp);  // logits / temp in the activation dtype, as the reference
+    if (z > m) {
+      ssum = ssum * __expf(m - z) + 1.f;
+      m = z;
+    } else {
+      ssum += __expf(z - m);
+    }
   }
-  mx = wave_max(mx);
-  if (lane == 0) red_v[wv] = mx;
-  __syncthreads();
-  mx = fmaxf(fmaxf(red_v[0], red_v[1]), fmaxf(red_v[2], red_v[3]));
-  __syncthreads();
-  float sum = 0.f;
-  for (int c = tid; c < V; c += 256) {
-    const float e = __expf(sp[c] - mx);
-    sp[c] = e;
-    sum += e;
-  }
-  sum = wave_sum(sum);
-  if (lane == 0) red_v[wv] = sum;
-  __syncthreads();
-  const float inv = 1.f / (red_v[0] + red_v[1] + red_v[2] + red_v[3]);
-  const int l = lo[b], h = hi[b];
-  for (int c = tid; c < V; c += 256) {
-    const bool ok = (l < 0) ? (first_mask[c] != 0) : (c >= l && c < h);
-    sp[c] = ok ? sp[c] * inv : 0.f;
+  {
+    const float wm = wave_max(m);
+    const float ws = wave_sum(ssum * __expf(m - wm));
+    if (lane == 0) {
+      part_m[wave] = wm;
+      part_s[wave] = ws;
+    }
   }
   __syncthreads();
-  // top_k rounds of block arg-max; a taken entry is marked -1
+  if (wave != 0) return;
+  const float mx = fmaxf(fmaxf(part_m[0], part_m[1]), fmaxf(part_m[2], part_m[3]));
+  float tot = 0.f;
+#pragma unroll
+  for (int w = 0; w < 4; ++w) tot += part_s[w] * __expf(part_m[w] - mx);
+  const float inv = 1.f / tot;
+  int l = first_lo, h = first_hi;
+  if (pos > 0) {
+    const int64_t e = ev[b];
+    l = lo_tab[e * tab_stride + pos];
+    h = hi_tab[e * tab_stride + pos];
+  }
+  if (h > V) h = V;
+  float pv[TMAX];
+#pragma unroll
+  for (int t = 0; t < TMAX; ++t) {
+    const int c = l + lane + 64 * t;
+    const bool ok = c < h && (pos > 0 || first_mask[c] != 0);
+    pv[t] = ok ? __expf(rnd<T>(to_f(row[c < V ? c : V - 1]) / temp) - mx) * inv : -1.f;  // -1: not a candidate
+  }
+  uint32_t taken = 0;
   for (int j = 0; j < top_k; ++j) {
     float bv = -1.f;
-    int bi = 0x7fffffff;
-    for (int c = tid; c < V; c += 256) {
-      const float v = sp[c];
-      if (v > bv) {  // ascending c: the first (lowest index) of equal values stays
-        bv = v;
-        bi = c;
-      }
-    }
+    int bt = TMAX;
 #pragma unroll
-    for (int x = 32; x >= 1; x >>= 1) {
-      const float ov = __shfl_xor(bv, x, 64);
-      const int oi = __shfl_xor(bi, x, 64);
-      if (ov > bv || (ov == bv && oi < bi)) {
-        bv = ov;
-        bi = oi;
+    for (int t = 0; t < TMAX; ++t)
+      if (!((taken >> t) & 1u) && pv[t] > bv) {  // ascending t = ascending id: the lowest id of equal values stays
+        bv = pv[t];
+        bt = t;
       }
-    }
+    // key = (probability bits, 0x7fffffff - id): larger probability first, lower id among equal probabilities; a lane
+    // without candidates left offers key 0 (below every candidate, whose low word is positive)
+    const uint64_t mykey = (bt < TMAX) ? ((uint64_t)__float_as_uint(bv) << 32) | (uint32_t)(0x7fffffff - (l + lane + 64 * bt)) : 0ull;
+    const uint64_t wkey = wave_max_u64_fast(mykey);
+    const float wvv = __uint_as_float((uint32_t)(wkey >> 32));
+    const int wi = (wkey != 0ull) ? 0x7fffffff - (int)(uint32_t)wkey : 0x7fffffff;
     if (lane == 0) {
-      red_v[wv] = bv;
-      red_i[wv] = bi;
+      sel_v[wv][j] = wvv;  // fewer than top_k candidates: the tail has probability 0
+      sel_i[wv][j] = wi;
     }
-    __syncthreads();
-    if (tid == 0) {
-      float v = red_v[0];
-      int i = red_i[0];
-      for (int w = 1; w < 4; ++w)
-        if (red_v[w] > v || (red_v[w] == v && red_i[w] < i)) {
-          v = red_v[w];
-          i = red_i[w];
-        }
-      sel_v[j] = v;
-      sel_i[j] = i;
-      sp[i] = -1.f;
-    }
-    __syncthreads();
+    if (wi != 0x7fffffff && ((wi - l) & 63) == lane) taken |= 1u << ((wi - l) >> 6);
   }
-  if (tid == 0) {
+  if (lane == 0) {
     // probs_sort[cumsum - probs_sort > p] = 0; keep the first k; renormalise; argmax(p / q)
     float cum = 0.f, s = 0.f;
     for (int j = 0; j < top_k; ++j) {
-      cum += sel_v[j];
-      if (cum - sel_v[j] > top_p) sel_v[j] = 0.f;
-      s += sel_v[j];
+      const float v = sel_v[wv][j];
+      cum += v;
+      const float kept = (cum - v > top_p) ? 0.f : v;
+      sel_v[wv][j] = kept;
+      s += kept;
     }
     float best = -1.f;
     int bj = 0;
     const float* qr = q + b * (int64_t)V;
     for (int j = 0; j < top_k; ++j) {
-      const float r = (sel_v[j] / s) / qr[j];
+      const float r = (sel_v[wv][j] / s) / qr[j];
       if (r > best) {
         best = r;
         bj = j;
       }
     }
-    out[b * out_stride] = (int64_t)sel_i[bj];
+    const int64_t id = (int64_t)sel_i[wv][bj];
+    out[b * out_stride] = id;
+    if (out_b != nullptr) out_b[b] = id;
+    if (out_c != nullptr) out_c[b] = id;
   }
 }
 
-extern "C" int mh_sample_top_p_k(const void* logits, int64_t ldl, const int32_t* lo, const int32_t* hi,
-                                 const uint8_t* first_mask, const float* q, int64_t* out, int64_t out_stride, int64_t B,
-                                 int V, float temp, float top_p, int top_k, int dtype, void* stream) {
-  MH_REQUIRE(B > 0 && V > 0 && temp > 0.f, "sample_top_p_k: bad args");
+extern "C" int mh_sample_top_p_k(const void* logits, int64_t ldl, const uint8_t* first_mask, int first_lo, int first_hi,
+                                 const int32_t* lo_tab, const int32_t* hi_tab, int tab_stride, int max_range,
+                                 const int64_t* ev, int pos, const float* q,
+                                 int64_t* out, int64_t out_stride, int64_t* out_b, int64_t* out_c, int64_t B, int V,
+                                 float temp, float top_p, int top_k, int dtype, void* stream) {
+  MH_REQUIRE(B > 0 && V > 0 && temp > 0.f && pos >= 0 && pos < tab_stride, "sample_top_p_k: bad args");
+  MH_REQUIRE(pos == 0 || (ev != nullptr && lo_tab != nullptr && hi_tab != nullptr), "sample_top_p_k: position %d needs the event ids and range tables", pos);
   MH_REQUIRE(top_k >= 1 && top_k <= SAMPLE_MAX_K && top_k <= V, "sample_top_p_k: top_k=%d outside [1, %d]", top_k,
              SAMPLE_MAX_K);
-  MH_REQUIRE((size_t)V * 4 <= 60 * 1024, "sample_top_p_k: vocabulary %d too large for the LDS row buffer", V);
-  DISPATCH_T(dtype, (sample_top_p_k_kernel<T><<<(int)B, 256, (size_t)V * 4, (hipStream_t)stream>>>(
-                        (const T*)logits, ldl, lo, hi, first_mask, q, out, out_stride, V, 1.f / temp, top_p, top_k)));
+  MH_REQUIRE(first_lo >= 0 && first_hi <= V && first_hi - first_lo <= SAMPLE_MAX_RANGE && max_range <= SAMPLE_MAX_RANGE,
+             "sample_top_p_k: a grammar mask spans more than %d ids (first %d..%d, parameters %d)", SAMPLE_MAX_RANGE, first_lo,
+             first_hi, max_range);
+  const int span = pos == 0 ? first_hi - first_lo : max_range;
+#define MH_SAMPLE(TMAX_)                                                                                                  \
+  DISPATCH_T(dtype, (sample_top_p_k_kernel<T, TMAX_><<<(int)B, 256, 0, (hipStream_t)stream>>>(               \
+                        (const T*)logits, ldl, first_mask, lo_tab, hi_tab, tab_stride, ev, pos, first_lo, first_hi, q, out, \
+                        out_stride, out_b, out_c, B, V, temp, top_p, top_k)))
+  if (span <= 128) MH_SAMPLE(2);
+  else if (span <= 512) MH_SAMPLE(8);
+  else MH_SAMPLE(32);
+#undef MH_SAMPLE
   MH_LAUNCH_CHECK();
   return MH_OK;
 }

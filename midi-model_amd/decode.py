@@ -47,6 +47,9 @@ class DecodeSession:
         first, lo, hi, _ = model._grammar()
         self.first_mask = first.clone()           # generate() overwrites it (ban_eos)
         self.lo_tab, self.hi_tab = lo, hi
+        self.first_span, self.max_range = ops.mask_spans(first, lo, hi)  # (generate() only ever clears bits of first_mask)
+        self.fused_sampler = (1 <= self.top_k <= min(ops.SAMPLE_MAX_K, self.V) and max(self.max_range) <= ops.SAMPLE_MAX_RANGE
+                              and self.first_span[1] - self.first_span[0] <= ops.SAMPLE_MAX_RANGE)
         self.pos = torch.zeros(1, dtype=torch.int32, device=dev)           # cached events so far (device side)
         self.hidden = torch.zeros((B, spec.D), dtype=dt, device=dev)
         self.seq = torch.zeros((B, self.T), dtype=torch.long, device=dev)  # tokens of the event being sampled
@@ -91,21 +94,22 @@ class DecodeSession:
         else:
             ops.gemm_nt(h, lm_w, self.logits[:, : self.V])
         if i == 0:
-            lo, hi = self.neg1, self.neg1
-        else:
-            lo, hi = self.lo_tab[self.ev, i].contiguous(), self.hi_tab[self.ev, i].contiguous()
-        if i == 0:
             self.seq.fill_(self.pad_id)
-        if 1 <= self.top_k <= min(ops.SAMPLE_MAX_K, self.V):
+        if self.fused_sampler:
             # one launch instead of sample_top_p_k's ~25: the Exp(1) noise torch.multinomial would draw internally
             # (empty_like(probs).exponential_(1, generator)) is drawn here, the rest is mh_sample_top_p_k
             self.q.exponential_(1.0, generator=generator)
-            ops.sample_top_p_k(self.logits, lo, hi, self.first_mask, self.q, self.seq[:, i], self.V, self.temp,
-                               self.top_p, self.top_k)
+            ops.sample_top_p_k(self.logits, self.first_mask, self.lo_tab, self.hi_tab, self.ev, i, self.q, self.seq[:, i],
+                               self.V, self.temp, self.top_p, self.top_k, out_b=self.samples_in,
+                               out_c=self.ev if i == 0 else None, first_span=self.first_span, max_range=self.max_range[i])
+            return
+        if i == 0:
+            lo, hi = self.neg1, self.neg1
         else:
-            ops.masked_softmax(self.logits, lo, hi, self.first_mask, self.probs.view(self.B, self.V), self.V, self.temp)
-            samples = m.sample_top_p_k(self.probs, self.top_p, self.top_k, generator=generator)  # (B, 1)
-            self.seq[:, i] = samples[:, 0]
+            lo, hi = self.lo_tab[self.ev, i].contiguous(), self.hi_tab[self.ev, i].contiguous()
+        ops.masked_softmax(self.logits, lo, hi, self.first_mask, self.probs.view(self.B, self.V), self.V, self.temp)
+        samples = m.sample_top_p_k(self.probs, self.top_p, self.top_k, generator=generator)  # (B, 1)
+        self.seq[:, i] = samples[:, 0]
         if i == 0:
             self.ev.copy_(self.seq[:, 0])
         self.samples_in.copy_(self.seq[:, i])

@@ -137,7 +137,7 @@ def gemm_skinny(a: torch.Tensor, w: torch.Tensor, out: torch.Tensor, *, mode: in
 
 def skinny_ok(x: torch.Tensor, K: int) -> bool:
     """whether mh_gemm_skinny serves this decode projection (else mh_gemm)"""
-    return x.dtype == torch.bfloat16 and x.shape[0] <= 64 and K % 128 == 0
+    return x.dtype == torch.bfloat16 and x.shape[0] <= 64 and K % 256 == 0
 
 
 gemm_profile = None  # set to a list to collect (start_event, end_event, flops, shape) per GEMM launch
@@ -335,12 +335,30 @@ def kv_store_prefill(qkv, kc, vc, B: int, S: int, H: int, hd: int, Lmax: int):
 SAMPLE_MAX_K = 64
 
 
-def sample_top_p_k(logits, lo, hi, first_mask, q, out, V: int, temp: float, top_p: float, top_k: int):
-    """fused masked softmax + top-p/top-k + draw; q [B, V] fp32 Exp(1) noise, out a strided int64 view [B]"""
+SAMPLE_MAX_RANGE = 2048
+
+
+def mask_spans(first_mask: torch.Tensor, lo_tab: torch.Tensor, hi_tab: torch.Tensor):
+    """((first_lo, first_hi), [longest range per position]) of a grammar, computed once on the host"""
+    nz = first_mask.nonzero().flatten()
+    span = (int(nz.min()), int(nz.max()) + 1) if nz.numel() else (0, 0)
+    return span, [int(x) for x in (hi_tab - lo_tab).max(dim=0).values.tolist()]
+
+
+def sample_top_p_k(logits, first_mask, lo_tab, hi_tab, ev, pos: int, q, out, V: int, temp: float, top_p: float,
+                   top_k: int, out_b=None, out_c=None, first_span=(0, 0), max_range: int = 0):
+    """fused grammar-masked softmax + top-p/top-k + draw of token position `pos`; q [B, V] fp32 Exp(1) noise; the id goes
+    to `out` (a strided int64 view [B]) and to the contiguous int64 [B] tensors out_b / out_c when given.  first_span =
+    [lo, hi) outside of which first_mask is zero; max_range = the longest [lo_tab, hi_tab) range at this position
+    (host-side facts about the tables, see mask_spans)"""
     B = logits.shape[0]
     assert q.dtype == torch.float32 and q.is_contiguous() and q.shape == (B, V) and out.dtype == torch.int64
-    lib().call("mh_sample_top_p_k", _p(logits), _rowmajor(logits), _p(lo), _p(hi), _p(first_mask), _p(q), _p(out),
-               out.stride(0), B, V, temp, top_p, top_k, dt(logits), _stream())
+    assert lo_tab.dtype == torch.int32 and lo_tab.is_contiguous() and hi_tab.is_contiguous() and ev.dtype == torch.int64
+    for t in (out_b, out_c):
+        assert t is None or (t.dtype == torch.int64 and t.is_contiguous() and t.numel() == B)
+    lib().call("mh_sample_top_p_k", _p(logits), _rowmajor(logits), _p(first_mask), int(first_span[0]), int(first_span[1]),
+               _p(lo_tab), _p(hi_tab), lo_tab.shape[1], int(max_range), _p(ev), pos, _p(q), _p(out), out.stride(0),
+               _p(out_b), _p(out_c), B, V, temp, top_p, top_k, dt(logits), _stream())
     return out
 
 

@@ -41,7 +41,7 @@ SKINNY_PLAIN, SKINNY_GATEUP = 0, 1
 
 
 def skinny_ok(x, K):
-    return x.dtype == torch.bfloat16 and x.shape[0] <= 64 and K % 128 == 0
+    return x.dtype == torch.bfloat16 and x.shape[0] <= 64 and K % 256 == 0
 
 
 def gemm_skinny(a, w, out, *, mode=0, res=None):
@@ -310,8 +310,21 @@ def kv_store_prefill(qkv, kc, vc, B, S, H, hd, Lmax):
 SAMPLE_MAX_K = 64
 
 
-def sample_top_p_k(logits, lo, hi, first_mask, q, out, V, temp, top_p, top_k):
+SAMPLE_MAX_RANGE = 2048
+
+
+def mask_spans(first_mask, lo_tab, hi_tab):
+    nz = first_mask.nonzero().flatten()
+    return (int(nz.min()), int(nz.max()) + 1), [int(x) for x in (hi_tab - lo_tab).max(dim=0).values.tolist()]
+
+
+def sample_top_p_k(logits, first_mask, lo_tab, hi_tab, ev, pos, q, out, V, temp, top_p, top_k, out_b=None, out_c=None,
+                   first_span=(0, 0), max_range=0):
     B = logits.shape[0]
+    if pos == 0:
+        lo = hi = torch.full((B,), -1, dtype=torch.int32)
+    else:
+        lo, hi = lo_tab[ev, pos], hi_tab[ev, pos]
     probs = torch.empty((B, V), dtype=torch.float32)
     masked_softmax(logits, lo, hi, first_mask, probs, V, temp)
     ps, pi = torch.sort(probs, dim=-1, descending=True, stable=True)
@@ -320,7 +333,11 @@ def sample_top_p_k(logits, lo, hi, first_mask, q, out, V, temp, top_p, top_k):
     ps[:, top_k:] = 0.0
     ps = ps / ps.sum(-1, keepdim=True)
     j = torch.argmax(ps / q, -1)
-    out.copy_(pi.gather(-1, j[:, None])[:, 0])
+    ids = pi.gather(-1, j[:, None])[:, 0]
+    out.copy_(ids)
+    for t in (out_b, out_c):
+        if t is not None:
+            t.copy_(ids)
     return out
 
 

@@ -80,7 +80,7 @@ def test_gemm_contraction_major_operands(ops, gemm_variant, dtype, ta, tb, M, N,
 
 
 @pytest.mark.parametrize("mode", [0, 1])
-@pytest.mark.parametrize("M,N,K", [(64, 3072, 1024), (1, 1024, 1024), (5, 3406, 1024), (64, 1024, 4096), (33, 2048, 128),
+@pytest.mark.parametrize("M,N,K", [(64, 3072, 1024), (1, 1024, 1024), (5, 3406, 1024), (64, 1024, 4096), (33, 2048, 256),
                                    (64, 4096, 1024)])
 def test_gemm_skinny(ops, mode, M, N, K):
     """decode-step projection (mh_gemm_skinny, bf16 only): plain + residual into a narrowed output view (logits layout),
@@ -418,13 +418,17 @@ def test_sample_top_p_k_fused(ops, dtype, top_p, top_k):
     logits = torch.zeros((B, Vp), dtype=dtype)
     logits[:, :V] = rnd((B, V), dtype, 37, 3.0)
     ev = torch.randint(3, 9, (B,), generator=g)
-    pos = torch.randint(0, 3, (B,), generator=g)  # 0 = event id position (first_mask), else a parameter position
-    lo = torch.tensor([-1 if p == 0 else lo_t[e][p] for e, p in zip(ev.tolist(), pos.tolist())], dtype=torch.int32)
-    hi = torch.tensor([-1 if p == 0 else hi_t[e][p] for e, p in zip(ev.tolist(), pos.tolist())], dtype=torch.int32)
     fm = torch.tensor(first, dtype=torch.uint8)
+    lo_tab, hi_tab = torch.tensor(lo_t, dtype=torch.int32), torch.tensor(hi_t, dtype=torch.int32)
     q = torch.empty((B, V)).exponential_(1.0, generator=g)
-    want = emu.sample_top_p_k(logits, lo, hi, fm, q, torch.empty((B,), dtype=torch.int64), V, 0.9, top_p, top_k)
-    buf = torch.full((B, 8), -7, dtype=torch.int64, device="cuda")
-    ops.sample_top_p_k(logits.cuda(), lo.cuda(), hi.cuda(), fm.cuda(), q.cuda(), buf[:, 3], V, 0.9, top_p, top_k)
-    assert (buf[:, 3].cpu() == want).all(), (buf[:, 3].cpu() != want).nonzero().flatten().tolist()
+    for pos in (0, 1, 2, 4, 5):  # 0 = event id position (first_mask), else a parameter position of the row's event
+        want = emu.sample_top_p_k(logits, fm, lo_tab, hi_tab, ev, pos, q, torch.empty((B,), dtype=torch.int64), V, 0.9,
+                                  top_p, top_k)
+        buf = torch.full((B, 8), -7, dtype=torch.int64, device="cuda")
+        ob, oc = torch.zeros((B,), dtype=torch.int64, device="cuda"), torch.zeros((B,), dtype=torch.int64, device="cuda")
+        span, mr = ops.mask_spans(fm, lo_tab, hi_tab)
+        ops.sample_top_p_k(logits.cuda(), fm.cuda(), lo_tab.cuda(), hi_tab.cuda(), ev.cuda(), pos, q.cuda(), buf[:, 3], V,
+                           0.9, top_p, top_k, out_b=ob, out_c=oc if pos == 0 else None, first_span=span, max_range=mr[pos])
+        assert (buf[:, 3].cpu() == want).all(), (pos, (buf[:, 3].cpu() != want).nonzero().flatten().tolist())
+        assert torch.equal(ob, buf[:, 3]) and (pos != 0 or torch.equal(oc, buf[:, 3]))
     assert (buf[:, :3] == -7).all() and (buf[:, 4:] == -7).all()
