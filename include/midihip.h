@@ -198,10 +198,12 @@ int mh_masked_softmax(const void* logits, int64_t ldl, const int32_t* lo, const 
  * renormalise, and return for every row the id maximising p_j / q[b, j], where q [B, V] holds Exp(1) draws (only the
  * first top_k of a row are read) taken by the caller from the caller's generator (torch.Tensor.exponential_), which is
  * what keeps a seeded generator's stream identical to the reference's.  The id goes to out[b * out_stride] and, when
- * non-null, to out_b[b] and out_c[b] (all int64).  1 <= top_k <= 64.  The caller states the spans of the masks:
+ * non-null, to out_b[b] and out_c[b] (all int64).  1 <= top_k <= 64.  ban_mask (optional, [V] bytes): ids with a
+ * non-zero byte are removed from every mask (app.py:30-31,85-86 disable_channels).  The caller states the spans of the masks:
  * first_mask is zero outside [first_lo, first_hi), no table range AT THIS POSITION is longer than max_range; both at most
  * 2048 ids.                                                                                                 */
-int mh_sample_top_p_k(const void* logits, int64_t ldl, const uint8_t* first_mask, int first_lo, int first_hi,
+int mh_sample_top_p_k(const void* logits, int64_t ldl, const uint8_t* first_mask, const uint8_t* ban_mask, int first_lo,
+                      int first_hi,
                       const int32_t* lo_tab, const int32_t* hi_tab, int tab_stride, int max_range, const int64_t* ev,
                       int pos, const float* q, int64_t* out,
                       int64_t out_stride, int64_t* out_b, int64_t* out_c, int64_t B, int V, float temp, float top_p,

@@ -297,6 +297,7 @@ constexpr int SAMPLE_MAX_RANGE = 2048;
 template <typename T, int TMAX>  // TMAX: candidates per lane (64 * TMAX >= the longest mask range of this position)
 __global__ __launch_bounds__(256) void sample_top_p_k_kernel(const T* __restrict__ logits, int64_t ldl,
                                                              const uint8_t* __restrict__ first_mask,
+                                                             const uint8_t* __restrict__ ban_mask,
                                                              const int32_t* __restrict__ lo_tab,
                                                              const int32_t* __restrict__ hi_tab, int tab_stride,
                                                              const int64_t* __restrict__ ev, int pos, int first_lo,
@@ -348,7 +349,7 @@ __global__ __launch_bounds__(256) void sample_top_p_k_kernel(const T* __restrict
 #pragma unroll
   for (int t = 0; t < TMAX; ++t) {
     const int c = l + lane + 64 * t;
-    const bool ok = c < h && (pos > 0 || first_mask[c] != 0);
+    const bool ok = c < h && (pos > 0 || first_mask[c] != 0) && (ban_mask == nullptr || ban_mask[c] == 0);
     pv[t] = ok ? __expf(rnd<T>(to_f(row[c < V ? c : V - 1]) / temp) - mx) * inv : -1.f;  // -1: not a candidate
   }
   uint32_t taken = 0;
@@ -400,7 +401,8 @@ __global__ __launch_bounds__(256) void sample_top_p_k_kernel(const T* __restrict
   }
 }
 
-extern "C" int mh_sample_top_p_k(const void* logits, int64_t ldl, const uint8_t* first_mask, int first_lo, int first_hi,
+extern "C" int mh_sample_top_p_k(const void* logits, int64_t ldl, const uint8_t* first_mask, const uint8_t* ban_mask,
+                                 int first_lo, int first_hi,
                                  const int32_t* lo_tab, const int32_t* hi_tab, int tab_stride, int max_range,
                                  const int64_t* ev, int pos, const float* q,
                                  int64_t* out, int64_t out_stride, int64_t* out_b, int64_t* out_c, int64_t B, int V,
@@ -415,7 +417,7 @@ extern "C" int mh_sample_top_p_k(const void* logits, int64_t ldl, const uint8_t*
   const int span = pos == 0 ? first_hi - first_lo : max_range;
 #define MH_SAMPLE(TMAX_)                                                                                                  \
   DISPATCH_T(dtype, (sample_top_p_k_kernel<T, TMAX_><<<(int)B, 256, 0, (hipStream_t)stream>>>(               \
-                        (const T*)logits, ldl, first_mask, lo_tab, hi_tab, tab_stride, ev, pos, first_lo, first_hi, q, out, \
+                        (const T*)logits, ldl, first_mask, ban_mask, lo_tab, hi_tab, tab_stride, ev, pos, first_lo, first_hi, q, out, \
                         out_stride, out_b, out_c, B, V, temp, top_p, top_k)))
   if (span <= 128) MH_SAMPLE(2);
   else if (span <= 512) MH_SAMPLE(8);

@@ -45,7 +45,8 @@ class DecodeSession:
         self.rope1 = RopeTable(spec.hd, spec.theta, dev, capacity)
         self.rope2 = RopeTable(tspec.hd, tspec.theta, dev, self.T)
         first, lo, hi, _ = model._grammar()
-        self.first_mask = first.clone()           # generate() overwrites it (ban_eos)
+        self.first_mask = first.clone()           # generate() overwrites it (ban_eos, disable_patch/control_change)
+        self.ban = torch.zeros_like(first)        # ids removed from every mask (disable_channels); generate() fills it
         self.lo_tab, self.hi_tab = lo, hi
         self.first_span, self.max_range = ops.mask_spans(first, lo, hi)  # (generate() only ever clears bits of first_mask)
         self.fused_sampler = (1 <= self.top_k <= min(ops.SAMPLE_MAX_K, self.V) and max(self.max_range) <= ops.SAMPLE_MAX_RANGE
@@ -101,13 +102,15 @@ class DecodeSession:
             self.q.exponential_(1.0, generator=generator)
             ops.sample_top_p_k(self.logits, self.first_mask, self.lo_tab, self.hi_tab, self.ev, i, self.q, self.seq[:, i],
                                self.V, self.temp, self.top_p, self.top_k, out_b=self.samples_in,
-                               out_c=self.ev if i == 0 else None, first_span=self.first_span, max_range=self.max_range[i])
+                               out_c=self.ev if i == 0 else None, first_span=self.first_span, max_range=self.max_range[i],
+                               ban_mask=self.ban)
             return
         if i == 0:
             lo, hi = self.neg1, self.neg1
         else:
             lo, hi = self.lo_tab[self.ev, i].contiguous(), self.hi_tab[self.ev, i].contiguous()
         ops.masked_softmax(self.logits, lo, hi, self.first_mask, self.probs.view(self.B, self.V), self.V, self.temp)
+        self.probs.mul_((self.ban == 0).view(1, 1, self.V))
         samples = m.sample_top_p_k(self.probs, self.top_p, self.top_k, generator=generator)  # (B, 1)
         self.seq[:, i] = samples[:, 0]
         if i == 0:

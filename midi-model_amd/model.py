@@ -340,79 +340,115 @@ class MIDIModel(nn.Module):
                             torch.tensor(hi, dtype=torch.int32, device=dev), arity)
         return self._tables
 
-    @torch.inference_mode()
     def generate(self, prompt=None, batch_size=1, max_len=512, temp=1.0, top_p=0.98, top_k=20, generator=None,
-                 ban_eos: bool = False):
+                 ban_eos: bool = False, disable_patch_change: bool = False, disable_control_change: bool = False,
+                 disable_channels=None):
         """midi_model.py:167-250 with the host-bound parts moved to the device: grammar masks come from
-        per-event-id range tables (no Python loop over the batch), K/V live in preallocated buffers, and the
-        only device->host traffic is ONE copy of the B sampled event ids per event (the reference does B
-        ``.item()`` calls).  The number of sampling calls per event follows the reference's break rule exactly,
-        so a seeded generator yields the reference's stream.  ``ban_eos`` (ours; throughput runs) removes EOS
-        from the first-token mask."""
+        per-event-id range tables (no Python loop over the batch), K/V live in preallocated buffers, every decode /
+        sampling step is a replayed hipGraph (decode.py) and the only device->host traffic is ONE copy of the B sampled
+        event ids per event (the reference does B ``.item()`` calls).  The number of sampling calls per event follows
+        the reference's break rule exactly, so a seeded generator yields the reference's stream.
+
+        Returns ``np.ndarray (B, <= max_len, 8) int64`` including the prompt.  Extras (ours): ``ban_eos`` removes EOS
+        from the first-token mask (throughput runs); ``disable_patch_change`` / ``disable_control_change`` /
+        ``disable_channels`` are the mask options of the serving loop (app.py:27-31, 73-86)."""
+        inp = self._prompt_tensor(prompt, batch_size)
+        parts = [inp.cpu().numpy()]
+        for ev in self._generate_events(inp, batch_size, max_len, temp, top_p, top_k, generator, ban_eos,
+                                        disable_patch_change, disable_control_change, disable_channels):
+            parts.append(ev[:, None, :])
+        return np.concatenate(parts, axis=1)
+
+    def generate_stream(self, prompt=None, batch_size=1, max_len=512, temp=1.0, top_p=0.98, top_k=20,
+                        disable_patch_change=False, disable_control_change=False, disable_channels=None, generator=None):
+        """The serving loop of the reference (app.py:27-120, same arguments): a Python generator that yields every new
+        event as ``np.ndarray (B, 8) int64`` as soon as it is sampled; the prompt is cropped to its last 4096 events
+        (app.py:53).  Same kernels and sessions as ``generate``."""
+        inp = self._prompt_tensor(prompt, batch_size)[:, -4096:]
+        return self._generate_events(inp, batch_size, max_len, temp, top_p, top_k, generator, False,
+                                     disable_patch_change, disable_control_change, disable_channels)
+
+    def _prompt_tensor(self, prompt, batch_size: int) -> torch.Tensor:
+        """prompt handling of midi_model.py:171-188 (and app.py:35-52): None -> one BOS event per sequence"""
         self._require_gpu()
         tok = self.tokenizer
-        T, V, Vp = tok.max_token_seq, tok.vocab_size, self.vocab_padded
-        dev = self.device
+        T, dev = tok.max_token_seq, self.device
         if prompt is None:
             inp = torch.full((batch_size, 1, T), tok.pad_id, dtype=torch.long, device=dev)
             inp[:, 0, 0] = tok.bos_id
-        else:
-            prompt = np.asarray(prompt)
-            if prompt.ndim == 2:
-                prompt = np.repeat(prompt[None, :], repeats=batch_size, axis=0)
-            elif prompt.shape[0] == 1:
-                prompt = np.repeat(prompt, repeats=batch_size, axis=0)
-            elif prompt.ndim != 3 or prompt.shape[0] != batch_size:
-                raise ValueError(f"invalid shape for prompt, {prompt.shape}")
-            prompt = prompt[..., :T]
-            if prompt.shape[-1] < T:
-                prompt = np.pad(prompt, ((0, 0), (0, 0), (0, T - prompt.shape[-1])), mode="constant",
-                                constant_values=tok.pad_id)
-            inp = torch.from_numpy(np.ascontiguousarray(prompt)).to(dtype=torch.long, device=dev)
+            return inp
+        prompt = np.asarray(prompt)
+        if prompt.ndim == 2:
+            prompt = np.repeat(prompt[None, :], repeats=batch_size, axis=0)
+        elif prompt.shape[0] == 1:
+            prompt = np.repeat(prompt, repeats=batch_size, axis=0)
+        elif prompt.ndim != 3 or prompt.shape[0] != batch_size:
+            raise ValueError(f"invalid shape for prompt, {prompt.shape}")
+        prompt = prompt[..., :T]
+        if prompt.shape[-1] < T:
+            prompt = np.pad(prompt, ((0, 0), (0, 0), (0, T - prompt.shape[-1])), mode="constant",
+                            constant_values=tok.pad_id)
+        return torch.from_numpy(np.ascontiguousarray(prompt)).to(dtype=torch.long, device=dev)
+
+    def _generate_events(self, inp, batch_size, max_len, temp, top_p, top_k, generator, ban_eos, disable_patch_change,
+                         disable_control_change, disable_channels):
+        """generator over the new events ((B, 8) int64 numpy each); the session is returned to the pool when the
+        generator finishes or is closed"""
+        tok = self.tokenizer
+        T = tok.max_token_seq
         B = batch_size
         cur_len = inp.shape[1]
-        total = max(max_len, cur_len)
-        out = torch.full((B, total, T), tok.pad_id, dtype=torch.long, device=dev)
-        out[:, :cur_len] = inp
         if cur_len >= max_len:
-            return out[:, :cur_len].cpu().numpy()
-        _, _, _, arity = self._grammar()
-        ses = self._checkout_session(B, total + 1, float(temp), float(top_p), int(top_k))
+            return
+        with torch.inference_mode():
+            arity = self._grammar()[3]
+            ses = self._checkout_session(B, max(max_len, cur_len) + 1, float(temp), float(top_p), int(top_k))
         try:
-            ses.first_mask.copy_(self._grammar()[0])
-            if ban_eos:
-                ses.first_mask[tok.eos_id] = 0
-            ses.reset()
-            ses.begin(generator)
-            ses.prefill(inp)  # causal forward over the prompt; hidden = last position
+            with torch.inference_mode():
+                ses.first_mask.copy_(self._grammar()[0])
+                if ban_eos:
+                    ses.first_mask[tok.eos_id] = 0
+                if disable_patch_change:
+                    ses.first_mask[tok.event_ids["patch_change"]] = 0
+                if disable_control_change:
+                    ses.first_mask[tok.event_ids["control_change"]] = 0
+                ses.ban.zero_()
+                for c in (disable_channels or []):
+                    ses.ban[tok.parameter_ids["channel"][c]] = 1
+                ses.reset()
+                ses.begin(generator)
+                ses.prefill(inp)  # causal forward over the prompt; hidden = last position
             while cur_len < max_len:
-                n_steps = T
-                end_all = False
-                i = 0
-                while i < n_steps:
-                    ses.tok_step(i)  # ... lm_head -> masked softmax -> sample_top_p_k -> ses.seq[:, i]
-                    if i == 0:
-                        ids = ses.ev.tolist()  # the one host sync per event
-                        alive = [a for a in (arity[t] for t in ids if t != tok.eos_id)]
-                        end_all = len(alive) == 0
-                        # reference break rule: the inner loop stops after position i iff every live row's event has
-                        # exactly i parameters (vacuously true at i == 1 when no row is live)
-                        if end_all:
-                            n_steps = 2
-                        elif all(a == alive[0] for a in alive):
-                            n_steps = alive[0] + 1
-                        else:
-                            n_steps = T
-                    i += 1
-                out[:, cur_len] = ses.seq
-                cur_len += 1
-                if end_all or cur_len >= max_len:
+                with torch.inference_mode():
+                    n_steps = T
+                    end_all = False
+                    i = 0
+                    while i < n_steps:
+                        ses.tok_step(i)  # ... lm_head -> masked softmax -> sample_top_p_k -> ses.seq[:, i]
+                        if i == 0:
+                            ids = ses.ev.tolist()  # the one host sync per event
+                            alive = [a for a in (arity[t] for t in ids if t != tok.eos_id)]
+                            end_all = len(alive) == 0
+                            # reference break rule: the inner loop stops after position i iff every live row's event
+                            # has exactly i parameters (vacuously true at i == 1 when no row is live)
+                            if end_all:
+                                n_steps = 2
+                            elif all(a == alive[0] for a in alive):
+                                n_steps = alive[0] + 1
+                            else:
+                                n_steps = T
+                        i += 1
+                    event = ses.seq.cpu().numpy().copy()  # (a CPU tensor would share memory with the session buffer)
+                    cur_len += 1
+                    last = end_all or cur_len >= max_len
+                    if not last:
+                        ses.net_step()  # decode the event just sampled; hidden = its net output (overlaps the consumer)
+                yield event
+                if last:
                     break
-                ses.net_step()  # decode the event just written; hidden = its net output
         finally:
             ses.end()
             self._return_session(ses)
-        return out[:, :cur_len].cpu().numpy()
 
     # decode sessions: buffers + captured graphs, one per concurrent generate() call (decode.py)
     def _checkout_session(self, B: int, need: int, temp: float, top_p: float, top_k: int):

@@ -346,7 +346,7 @@ def mask_spans(first_mask: torch.Tensor, lo_tab: torch.Tensor, hi_tab: torch.Ten
 
 
 def sample_top_p_k(logits, first_mask, lo_tab, hi_tab, ev, pos: int, q, out, V: int, temp: float, top_p: float,
-                   top_k: int, out_b=None, out_c=None, first_span=(0, 0), max_range: int = 0):
+                   top_k: int, out_b=None, out_c=None, first_span=(0, 0), max_range: int = 0, ban_mask=None):
     """fused grammar-masked softmax + top-p/top-k + draw of token position `pos`; q [B, V] fp32 Exp(1) noise; the id goes
     to `out` (a strided int64 view [B]) and to the contiguous int64 [B] tensors out_b / out_c when given.  first_span =
     [lo, hi) outside of which first_mask is zero; max_range = the longest [lo_tab, hi_tab) range at this position
@@ -356,7 +356,8 @@ def sample_top_p_k(logits, first_mask, lo_tab, hi_tab, ev, pos: int, q, out, V: 
     assert lo_tab.dtype == torch.int32 and lo_tab.is_contiguous() and hi_tab.is_contiguous() and ev.dtype == torch.int64
     for t in (out_b, out_c):
         assert t is None or (t.dtype == torch.int64 and t.is_contiguous() and t.numel() == B)
-    lib().call("mh_sample_top_p_k", _p(logits), _rowmajor(logits), _p(first_mask), int(first_span[0]), int(first_span[1]),
+    lib().call("mh_sample_top_p_k", _p(logits), _rowmajor(logits), _p(first_mask), _p(ban_mask), int(first_span[0]),
+               int(first_span[1]),
                _p(lo_tab), _p(hi_tab), lo_tab.shape[1], int(max_range), _p(ev), pos, _p(q), _p(out), out.stride(0),
                _p(out_b), _p(out_c), B, V, temp, top_p, top_k, dt(logits), _stream())
     return out

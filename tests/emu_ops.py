@@ -319,7 +319,7 @@ def mask_spans(first_mask, lo_tab, hi_tab):
 
 
 def sample_top_p_k(logits, first_mask, lo_tab, hi_tab, ev, pos, q, out, V, temp, top_p, top_k, out_b=None, out_c=None,
-                   first_span=(0, 0), max_range=0):
+                   first_span=(0, 0), max_range=0, ban_mask=None):
     B = logits.shape[0]
     if pos == 0:
         lo = hi = torch.full((B,), -1, dtype=torch.int32)
@@ -327,6 +327,8 @@ def sample_top_p_k(logits, first_mask, lo_tab, hi_tab, ev, pos, q, out, V, temp,
         lo, hi = lo_tab[ev, pos], hi_tab[ev, pos]
     probs = torch.empty((B, V), dtype=torch.float32)
     masked_softmax(logits, lo, hi, first_mask, probs, V, temp)
+    if ban_mask is not None:
+        probs = probs * (ban_mask == 0)[None, :]
     ps, pi = torch.sort(probs, dim=-1, descending=True, stable=True)
     cum = torch.cumsum(ps, -1)
     ps[cum - ps > top_p] = 0.0

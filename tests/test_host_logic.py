@@ -184,6 +184,22 @@ def test_generate_matches_reference(tiny, golden, tok):
         # ban_eos: every row runs to max_len and never emits EOS as an event id
         out = model.generate(None, batch_size=2, max_len=10, generator=torch.Generator().manual_seed(5), ban_eos=True)
         assert out.shape == (2, 10, 8) and (out[:, 1:, 0] != tok.eos_id).all()
+        # the serving form (app.py:27-120): one (B, 8) array per event, same stream as generate()
+        evs = list(model.generate_stream(None, batch_size=3, max_len=14, generator=torch.Generator().manual_seed(1234)))
+        assert all(e.shape == (3, 8) and e.dtype == np.int64 for e in evs)
+        assert (np.stack(evs, 1) == g["sampled_b3"][:, 1:]).all()
+        # mask options of the serving loop: no patch_change / control_change events, no banned channel ids
+        banned = [tok.parameter_ids["channel"][c] for c in (0, 9)]
+        out = model.generate(None, batch_size=4, max_len=24, generator=torch.Generator().manual_seed(11), ban_eos=True,
+                             disable_patch_change=True, disable_control_change=True, disable_channels=[0, 9])
+        assert out.shape == (4, 24, 8)
+        assert not np.isin(out[:, 1:, 0], [tok.event_ids["patch_change"], tok.event_ids["control_change"]]).any()
+        assert not np.isin(out, banned).any()
+        # a closed stream returns its session to the pool
+        it = model.generate_stream(None, batch_size=3, max_len=14)
+        next(it)
+        it.close()
+        assert len(model._sessions.idle) >= 1
 
 
 def test_forward_token_decode_path(tiny, orc):

@@ -134,6 +134,21 @@ def test_tiny_fp32_generate_token_ids(tiny, golden, tok):
             assert tok.tokens2event(row.tolist()) != [], row  # every generated octet is a well-formed event
     with pytest.raises(ValueError):
         model.generate(np.zeros((3, 2, 8), dtype=np.int64), batch_size=2, max_len=4)
+    # serving form (app.py:27-120): streamed events equal the batch call on the same seed; mask options hold
+    gen = torch.Generator(device="cuda")
+    ref = model.generate(None, batch_size=3, max_len=12, generator=gen.manual_seed(5))
+    evs = list(model.generate_stream(None, batch_size=3, max_len=12, generator=gen.manual_seed(5)))
+    assert (np.stack(evs, 1) == ref[:, 1:]).all()
+    banned = [tok.parameter_ids["channel"][c] for c in (0, 9)]
+    out = model.generate(None, batch_size=4, max_len=24, generator=gen.manual_seed(6), ban_eos=True,
+                         disable_patch_change=True, disable_control_change=True, disable_channels=[0, 9])
+    assert out.shape == (4, 24, 8)
+    assert not np.isin(out[:, 1:, 0], [tok.event_ids["patch_change"], tok.event_ids["control_change"]]).any()
+    assert not np.isin(out, banned).any()
+    # bf16 + graphs: same API, well-formed events
+    mb = build(mm.MIDIModel, tiny_config(), sd, dtype=torch.bfloat16)
+    out = mb.generate(None, batch_size=2, max_len=10, ban_eos=True, generator=gen.manual_seed(7))
+    assert out.shape == (2, 10, 8) and all(tok.tokens2event(r.tolist()) != [] for b in range(2) for r in out[b, 1:])
 
 
 def test_medium_fp32_matches_reference(orc, golden, tok):
