@@ -61,11 +61,12 @@ int mh_gemm_splitk_reduce(const void* workspace, void* C, int64_t ldc, const voi
  * lm_head when q_len == 1, modeling_llama.py:243-281, 174-176; midi_model.py:135): 1 <= M <= 64 rows, bf16.
  *   MH_SKINNY_PLAIN   C[M,N] = A[M,K] * W[N,K]^T (+ R)
  *   MH_SKINNY_GATEUP  W = [gate; up] (2N rows): C[M,N] = round(silu(round(A gate^T))) * round(A up^T)   (LlamaMLP)
- * K a multiple of 256.                                                                                         */
+ * K a multiple of 256.  norm_eps > 0: every row of the product is scaled by rsqrt(mean_k A[m,k]^2 + norm_eps) before
+ * the epilogue -- with the RMSNorm weight folded into W by the caller this is LlamaRMSNorm (:62-67) + projection.    */
 #define MH_SKINNY_PLAIN 0
 #define MH_SKINNY_GATEUP 1
 int mh_gemm_skinny(const void* A, int64_t lda, const void* W, int64_t ldw, void* C, int64_t ldc, const void* R,
-                   int64_t ldr, int mode, int64_t M, int64_t N, int64_t K, int dtype, void* stream);
+                   int64_t ldr, int mode, float norm_eps, int64_t M, int64_t N, int64_t K, int dtype, void* stream);
 /* out[C,R] = in[R,C]^T (operand re-layout for dgrad/wgrad). */
 int mh_transpose(const void* in, int64_t ldi, void* out, int64_t ldo, int64_t rows, int64_t cols, int dtype,
                  void* stream);

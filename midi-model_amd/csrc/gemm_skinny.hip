@@ -9,6 +9,11 @@
 // Splitting K across workgroups instead was measured 2x slower end to end: the partial tiles have to meet through
 // agent-scope fences, which on this part write back / invalidate the whole L2 of an XCD.
 //
+// Optional row scaling (norm_eps > 0): every output row m is multiplied by rsqrt(mean_k A[m,k]^2 + norm_eps), the sum of
+// squares being taken from the A fragments the waves load anyway.  With the RMSNorm weight folded into W beforehand
+// (W' = W * w_norm, decode.py) this is LlamaRMSNorm + projection in one launch: rstd * (x . (w_norm * W)) instead of
+// (w_norm * round(x * rstd)) . W -- the same product up to where the bf16 roundings fall.
+//
 // Epilogues:
 //   MH_SKINNY_PLAIN   C = acc (+ R)
 //   MH_SKINNY_GATEUP  W = [gate rows; up rows] (2N x K); a workgroup takes 16 gate and the 16 matching up columns and
@@ -21,13 +26,14 @@ namespace {
 
 // NBT: 16-column blocks of W per workgroup (GATEUP: 1 gate + 1 up block); NW: waves per workgroup (K is dealt to them in
 // 32-deep chunks: 8 chunks per wave are in flight at a time, so long contractions take 8 waves)
-template <int MODE, int NBT, int NW>
+template <int MODE, int NBT, int NW, bool RSTD>
 __global__ __launch_bounds__(NW * 64) void gemm_skinny_kernel(const bf16* __restrict__ A, int64_t lda,
                                                           const bf16* __restrict__ W, int64_t ldw, bf16* __restrict__ C,
                                                           int64_t ldc, const bf16* __restrict__ R, int64_t ldr, int M, int N,
-                                                          int K) {
+                                                          int K, float norm_eps) {
   constexpr int NB = NBT * 16;
   __shared__ float red[NW][64][NB + 1];
+  __shared__ float ssq[RSTD ? NW : 1][64];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int fi = lane & 15, fg = lane >> 4;
   const int nc_w = K / (32 * NW);  // chunks of 32 per wave (wave w takes chunks w, w+NW, ...)
@@ -58,6 +64,7 @@ __global__ __launch_bounds__(NW * 64) void gemm_skinny_kernel(const bf16* __rest
 #pragma unroll
     for (int nb = 0; nb < NBT; ++nb) acc[mb][nb] = f32x4{0.f, 0.f, 0.f, 0.f};
 
+  float ss[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll 8
   for (int ci = 0; ci < nc_w; ++ci) {
     const int k = (wave + NW * ci) * 32;
@@ -66,6 +73,12 @@ __global__ __launch_bounds__(NW * 64) void gemm_skinny_kernel(const bf16* __rest
     for (int nb = 0; nb < NBT; ++nb) wf[nb] = *reinterpret_cast<const bf16x8*>(wrow[nb] + k);
 #pragma unroll
     for (int mb = 0; mb < 4; ++mb) xf[mb] = *reinterpret_cast<const bf16x8*>(arow[mb] + k);
+    if constexpr (RSTD) {
+#pragma unroll
+      for (int mb = 0; mb < 4; ++mb)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) ss[mb] += (float)xf[mb][e] * (float)xf[mb][e];
+    }
 #pragma unroll
     for (int nb = 0; nb < NBT; ++nb)
 #pragma unroll
@@ -80,15 +93,31 @@ __global__ __launch_bounds__(NW * 64) void gemm_skinny_kernel(const bf16* __rest
     for (int nb = 0; nb < NBT; ++nb)
 #pragma unroll
       for (int e = 0; e < 4; ++e) red[wave][mb * 16 + fi][nb * 16 + 4 * fg + e] = acc[mb][nb][e];
+  if constexpr (RSTD) {
+#pragma unroll
+    for (int mb = 0; mb < 4; ++mb) {  // the four lane groups hold different k of the same row
+      float t = ss[mb];
+      t += __shfl_xor(t, 16, 64);
+      t += __shfl_xor(t, 32, 64);
+      if (fg == 0) ssq[wave][mb * 16 + fi] = t;
+    }
+  }
   __syncthreads();
   if (threadIdx.x >= 256) return;  // the first four waves write the tile
   const int m = threadIdx.x >> 2;
   if (m >= M) return;
+  float rs = 1.f;
+  if constexpr (RSTD) {
+    float t = ssq[0][m];
+#pragma unroll
+    for (int w = 1; w < NW; ++w) t += ssq[w][m];
+    rs = rsqrtf(t / (float)K + norm_eps);
+  }
   auto total = [&](int c) {
     float t = red[0][m][c];
 #pragma unroll
     for (int w = 1; w < NW; ++w) t += red[w][m][c];
-    return t;
+    return t * rs;
   };
   if constexpr (MODE == 1) {
     const int c0 = (threadIdx.x & 3) * 4;  // 16 output columns per workgroup, 4 per thread
@@ -119,7 +148,8 @@ __global__ __launch_bounds__(NW * 64) void gemm_skinny_kernel(const bf16* __rest
 }  // namespace
 
 extern "C" int mh_gemm_skinny(const void* A, int64_t lda, const void* W, int64_t ldw, void* C, int64_t ldc, const void* R,
-                              int64_t ldr, int mode, int64_t M, int64_t N, int64_t K, int dtype, void* stream) {
+                              int64_t ldr, int mode, float norm_eps, int64_t M, int64_t N, int64_t K, int dtype,
+                              void* stream) {
   MH_REQUIRE(dtype == MH_BF16, "gemm_skinny: bf16 only (the fp32 verification mode uses mh_gemm)");
   MH_REQUIRE(M > 0 && M <= 64 && N > 0 && N < (1 << 24), "gemm_skinny: needs 1 <= M <= 64 rows (M=%ld N=%ld)", (long)M, (long)N);
   MH_REQUIRE(mode == MH_SKINNY_PLAIN || mode == MH_SKINNY_GATEUP, "gemm_skinny: mode %d", mode);
@@ -128,9 +158,15 @@ extern "C" int mh_gemm_skinny(const void* A, int64_t lda, const void* W, int64_t
              "gemm_skinny: A/W rows must be 16-byte aligned");
   MH_REQUIRE(mode != MH_SKINNY_GATEUP || R == nullptr, "gemm_skinny: the gate|up epilogue takes no residual");
   hipStream_t st = (hipStream_t)stream;
-#define MH_SK(MODE_, NBT_, NW_, GRID_)                                                                                  \
-  gemm_skinny_kernel<MODE_, NBT_, NW_><<<(int)(GRID_), NW_ * 64, 0, st>>>((const bf16*)A, lda, (const bf16*)W, ldw, (bf16*)C, \
-                                                                          ldc, (const bf16*)R, ldr, (int)M, (int)N, (int)K)
+#define MH_SK(MODE_, NBT_, NW_, GRID_)                                                                                    \
+  do {                                                                                                                    \
+    if (norm_eps > 0.f)                                                                                                   \
+      gemm_skinny_kernel<MODE_, NBT_, NW_, true><<<(int)(GRID_), NW_ * 64, 0, st>>>(                                      \
+          (const bf16*)A, lda, (const bf16*)W, ldw, (bf16*)C, ldc, (const bf16*)R, ldr, (int)M, (int)N, (int)K, norm_eps); \
+    else                                                                                                                  \
+      gemm_skinny_kernel<MODE_, NBT_, NW_, false><<<(int)(GRID_), NW_ * 64, 0, st>>>(                                     \
+          (const bf16*)A, lda, (const bf16*)W, ldw, (bf16*)C, ldc, (const bf16*)R, ldr, (int)M, (int)N, (int)K, norm_eps); \
+  } while (0)
   if (mode == MH_SKINNY_GATEUP) MH_SK(1, 2, 4, (N + 15) / 16);
   else if (N > 2048) MH_SK(0, 2, 4, (N + 31) / 32);
   else if (K >= 2048) MH_SK(0, 1, 8, (N + 15) / 16);

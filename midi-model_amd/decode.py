@@ -61,6 +61,15 @@ class DecodeSession:
         self.probs = torch.zeros((B, 1, self.V), dtype=torch.float32, device=dev)
         self.q = torch.zeros((B, self.V), dtype=torch.float32, device=dev)  # Exp(1) noise of the sampler
         self.logits = torch.zeros((B, self.Vp), dtype=dt, device=dev)
+        # RMSNorm weights folded into the projections that follow them (one launch for norm + projection)
+        self.fold1 = self.fold2 = self.lm_fold = None
+        probe = torch.empty((B, 1), dtype=dt, device=dev)
+        if ops.skinny_ok(probe, spec.D) and ops.skinny_ok(probe, spec.I) and ops.skinny_ok(probe, tspec.I) \
+                and os.environ.get("MH_DECODE_FOLD", "1") != "0":
+            self.fold1 = engine.fold_norm_weights(model._W["net"])
+            self.fold2 = engine.fold_norm_weights(model._W["net_token"])
+            lm_w = model.lm_head.weight.data
+            self.lm_fold = (lm_w.float() * model._W["net_token"].norm.float()[None, :]).to(lm_w.dtype)
         self.g_net = None
         self.g_tok: List[Optional[torch.cuda.CUDAGraph]] = [None] * self.T
         self.use_graphs = graphs_enabled(dev)
@@ -71,7 +80,9 @@ class DecodeSession:
 
     @staticmethod
     def make_key(model, B, capacity, temp, top_p, top_k):
-        return (model._flat.data_ptr(), model._flat.dtype, B, capacity, float(temp), float(top_p), int(top_k))
+        # (_version: the folded weights below are derived from the parameters as they were when the session was built)
+        return (model._flat.data_ptr(), model._flat._version, model._flat.dtype, B, capacity, float(temp), float(top_p),
+                int(top_k))
 
     # ---- the step bodies (run eagerly, or once under capture) ---------------------------------------------
     def _net_body(self):
@@ -79,7 +90,7 @@ class DecodeSession:
         spec = m._specs["net"]
         e = torch.empty((self.B, spec.D), dtype=m.dtype, device=m.device)
         ops.embed_sum_fwd(self.seq, m._W["net"].embed, e)  # the event sampled last
-        y = engine.stack_decode(spec, m._W["net"], e, self.rope1, self.kv1, pos_dev=self.pos)
+        y = engine.stack_decode(spec, m._W["net"], e, self.rope1, self.kv1, pos_dev=self.pos, folded=self.fold1)
         self.hidden.copy_(y)
         self.pos.add_(1)
 
@@ -89,11 +100,15 @@ class DecodeSession:
         x = self.hidden if i == 0 else Wt.embed.index_select(0, self.samples_in)
         self.kv2.len = i
         lm_w = m.lm_head.weight.data
-        h = engine.stack_decode(tspec, Wt, x, self.rope2, self.kv2)
-        if ops.skinny_ok(h, tspec.D):
-            ops.gemm_skinny(h, lm_w, self.logits[:, : self.V])
+        if self.lm_fold is not None:  # the stack's final RMSNorm rides on the lm_head projection
+            h = engine.stack_decode(tspec, Wt, x, self.rope2, self.kv2, folded=self.fold2, final_norm=False)
+            ops.gemm_skinny(h, self.lm_fold, self.logits[:, : self.V], norm_eps=tspec.eps)
         else:
-            ops.gemm_nt(h, lm_w, self.logits[:, : self.V])
+            h = engine.stack_decode(tspec, Wt, x, self.rope2, self.kv2)
+            if ops.skinny_ok(h, tspec.D):
+                ops.gemm_skinny(h, lm_w, self.logits[:, : self.V])
+            else:
+                ops.gemm_nt(h, lm_w, self.logits[:, : self.V])
         if i == 0:
             self.seq.fill_(self.pad_id)
         if self.fused_sampler:

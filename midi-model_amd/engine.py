@@ -227,14 +227,27 @@ def stack_prefill(spec: StackSpec, W: StackTensors, x: torch.Tensor, nseq: int, 
     return y
 
 
-def stack_decode(spec: StackSpec, W: StackTensors, x: torch.Tensor, rope: RopeTable, kv: KVState, pos_dev=None):
+def fold_norm_weights(W: StackTensors):
+    """[(wqkv * n1, wgu * n2) per layer]: the RMSNorm weights folded into the projections that follow them, for the
+    decode path's one-launch norm + projection (mh_gemm_skinny with norm_eps).  Derived data: rebuild when W changes."""
+    out = []
+    for lw in W.layers:
+        out.append(((lw.wqkv.float() * lw.n1.float()[None, :]).to(lw.wqkv.dtype),
+                    (lw.wgu.float() * lw.n2.float()[None, :]).to(lw.wgu.dtype)))
+    return out
+
+
+def stack_decode(spec: StackSpec, W: StackTensors, x: torch.Tensor, rope: RopeTable, kv: KVState, pos_dev=None,
+                 folded=None, final_norm: bool = True):
     """x [B, D]: one new position per sequence at index kv.len (q_len == 1 => no causal mask,
     TF:integrations/sdpa_attention.py:120).
 
     With ``pos_dev`` (device int32[1]) the kernels take the position from device memory instead -- the form a captured
     hipGraph replays (decode.py); capacity and rope table must already cover it and kv.len is left to the caller.
-    bf16 with at most 64 sequences runs the projections on mh_gemm_skinny: 7 launches per layer, K/V append fused into the attention, gate|up and SwiGLU
-    fused; otherwise the general GEMM is used (9 launches + split-K reductions)."""
+    bf16 with at most 64 sequences runs the projections on mh_gemm_skinny: 7 launches per layer (K/V append fused
+    into the attention, gate|up and SwiGLU fused), 5 with ``folded`` (fold_norm_weights: the two RMSNorms ride on the
+    q|k|v and gate|up projections); otherwise the general GEMM is used (9 launches + split-K reductions).
+    ``final_norm=False`` returns the residual stream before the stack's last RMSNorm (decode.py folds it into lm_head)."""
     _check_heads(spec)
     B, D = x.shape
     H, I, hd = spec.H, spec.I, spec.hd
@@ -244,6 +257,20 @@ def stack_decode(spec: StackSpec, W: StackTensors, x: torch.Tensor, rope: RopeTa
         rope.ensure(pos + 1)
     fused = ops.skinny_ok(x, D) and ops.skinny_ok(x, I)
     for li, lw in enumerate(W.layers):
+        if fused and folded is not None:
+            wqkv_n, wgu_n = folded[li]
+            qkv = _empty((B, 3 * D), x)
+            ops.gemm_skinny(x, wqkv_n, qkv, norm_eps=spec.eps)
+            o = _empty((B, D), x)
+            ops.attn_decode_append(qkv, rope.cos, rope.sin, kv.k[li], kv.v[li], o, B, H, hd, kv.cap, pos, spec.scale, pos_dev)
+            x2 = _empty((B, D), x)
+            ops.gemm_skinny(o, lw.wo, x2, res=x)
+            a = _empty((B, I), x)
+            ops.gemm_skinny(x2, wgu_n, a, mode=ops.SKINNY_GATEUP, norm_eps=spec.eps)
+            x3 = _empty((B, D), x)
+            ops.gemm_skinny(a, lw.wd, x3, res=x2)
+            x = x3
+            continue
         if fused:
             h1 = _empty((B, D), x)
             ops.rmsnorm_fwd(x, lw.n1, h1, None, spec.eps)
@@ -281,6 +308,8 @@ def stack_decode(spec: StackSpec, W: StackTensors, x: torch.Tensor, rope: RopeTa
         x = x3
     if pos_dev is None:
         kv.len = pos + 1
+    if not final_norm:
+        return x
     y = _empty((B, D), x)
     ops.rmsnorm_fwd(x, W.norm, y, None, spec.eps)
     return y

@@ -124,14 +124,15 @@ SKINNY_PLAIN, SKINNY_GATEUP = 0, 1
 
 
 def gemm_skinny(a: torch.Tensor, w: torch.Tensor, out: torch.Tensor, *, mode: int = SKINNY_PLAIN,
-                res: Optional[torch.Tensor] = None) -> torch.Tensor:
+                res: Optional[torch.Tensor] = None, norm_eps: float = 0.0) -> torch.Tensor:
     """decode-step projection, M <= 64 rows, bf16 (mh_gemm_skinny): out[M,N] = a @ w[N,K]^T (+ res), or with
-    SKINNY_GATEUP w = [gate; up] ([2N,K]) and out[M,N] = silu(a @ gate^T) * (a @ up^T)."""
+    SKINNY_GATEUP w = [gate; up] ([2N,K]) and out[M,N] = silu(a @ gate^T) * (a @ up^T).  norm_eps > 0 scales row m of
+    the product by rsqrt(mean(a[m]^2) + norm_eps) first (RMSNorm with its weight folded into w)."""
     M, N = out.shape
     K = w.shape[1]
     assert a.shape == (M, K) and w.shape[0] == (2 * N if mode == SKINNY_GATEUP else N), (a.shape, w.shape, out.shape, mode)
     lib().call("mh_gemm_skinny", _p(a), _rowmajor(a), _p(w), _rowmajor(w), _p(out), _rowmajor(out), _p(res),
-               _rowmajor(res) if res is not None else 0, mode, M, N, K, dt(out), _stream())
+               _rowmajor(res) if res is not None else 0, mode, norm_eps, M, N, K, dt(out), _stream())
     return out
 
 

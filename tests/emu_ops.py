@@ -44,8 +44,10 @@ def skinny_ok(x, K):
     return x.dtype == torch.bfloat16 and x.shape[0] <= 64 and K % 256 == 0
 
 
-def gemm_skinny(a, w, out, *, mode=0, res=None):
+def gemm_skinny(a, w, out, *, mode=0, res=None, norm_eps=0.0):
     r = a.float() @ w.float().T
+    if norm_eps > 0:
+        r = r * torch.rsqrt(a.float().pow(2).mean(-1, keepdim=True) + norm_eps)
     if mode == SKINNY_GATEUP:
         gu = r.to(a.dtype)
         swiglu_fwd(gu, out)

@@ -94,6 +94,11 @@ def test_gemm_skinny(ops, mode, M, N, K):
     ops.gemm_skinny(a.cuda(), w.cuda(), buf[:, :N], mode=mode, res=None if r is None else r.cuda())
     cmp(buf[:, :N], want, dtype, k=max(1.0, K / 512), what=f"gemm_skinny mode={mode} {M}x{N}x{K}")
     assert (buf[:, N:] == 0).all()
+    # row scaling by rsqrt(mean(a^2) + eps): RMSNorm with its weight folded into w
+    want = emu.gemm_skinny(a, w, torch.empty((M, N), dtype=dtype), mode=mode, res=r, norm_eps=1e-6)
+    out = torch.empty((M, N), dtype=dtype, device="cuda")
+    ops.gemm_skinny(a.cuda(), w.cuda(), out, mode=mode, res=None if r is None else r.cuda(), norm_eps=1e-6)
+    cmp(out, want, dtype, k=max(1.0, K / 512), what=f"gemm_skinny rstd mode={mode} {M}x{N}x{K}")
     with pytest.raises(RuntimeError):
         ops.gemm_skinny(torch.zeros((65, K), dtype=dtype, device="cuda"), w.cuda(), torch.zeros((65, N), dtype=dtype, device="cuda"), mode=mode)
 

@@ -151,6 +151,45 @@ def test_tiny_fp32_generate_token_ids(tiny, golden, tok):
     assert out.shape == (2, 10, 8) and all(tok.tokens2event(r.tolist()) != [] for b in range(2) for r in out[b, 1:])
 
 
+def test_bf16_decode_session_variants_agree(tiny, tok, monkeypatch):
+    """The bf16 decode step has three forms -- eager, captured graphs, graphs with the RMSNorm weights folded into the
+    projections -- which differ only in where bf16 roundings fall: after a prompt prefill and one decoded event their
+    hidden states and lm_head logits must agree within bf16 noise, and the eager and graph forms (same kernels) exactly."""
+    from midi_model_amd.decode import DecodeSession
+    shp, sd, batch = tiny
+    model = build(mm.MIDIModel, tiny_config(), sd, dtype=torch.bfloat16)
+    prompt = batch[:2, :5].cuda()
+
+    def run(graphs: str, fold: str):
+        monkeypatch.setenv("MH_DECODE_GRAPHS", graphs)
+        monkeypatch.setenv("MH_DECODE_FOLD", fold)
+        with torch.inference_mode():
+            ses = DecodeSession(model, 2, 256, 1.0, 0.98, 1)
+            ses.first_mask.copy_(model._grammar()[0])
+            ses.reset()
+            ses.begin(torch.Generator(device="cuda").manual_seed(3))
+            ses.prefill(prompt)
+            h0 = ses.hidden.float().clone()
+            ses.tok_step(0)
+            l0 = ses.logits[:, : tok.vocab_size].float().clone()
+            ses.seq.copy_(batch[:2, 5].cuda())
+            ses.net_step()
+            h1 = ses.hidden.float().clone()
+            ses.tok_step(0)
+            l1 = ses.logits[:, : tok.vocab_size].float().clone()
+            ses.end()
+        return h0, l0, h1, l1
+
+    eager = run("0", "0")
+    graph = run("1", "0")
+    folded = run("1", "1")
+    for a, b in zip(eager, graph):
+        assert torch.equal(a, b)
+    for a, b, what in zip(graph, folded, ("prefill hidden", "logits 0", "decoded hidden", "logits 1")):
+        err = (a - b).abs().max().item()
+        assert err <= 0.03 * a.abs().max().item() + 1e-3, (what, err, a.abs().max().item())
+
+
 def test_medium_fp32_matches_reference(orc, golden, tok):
     g = golden("medium_forward.npz")
     shp = orc.Shape(vocab=tok.vocab_size)
