@@ -135,10 +135,14 @@ int mh_attn_bwd_plain(const void* qkv, const void* dout, const float* lse, const
                       int64_t S, int H, float scale, int dtype, void* stream);
 
 /* ---- token-level attention: sequences of T<=8 tokens, head_dim 256 (net_token) --------------------------
- * qkv[N*T, 3*H*256] -> o[N*T, H*256], causal within each sequence of T rows.                           */
-int mh_tokattn_fwd(const void* qkv, void* o, int64_t N, int T, int H, float scale, int dtype, void* stream);
-int mh_tokattn_bwd(const void* qkv, const void* dout, void* dqkv, int64_t N, int T, int H, float scale, int dtype,
-                   void* stream);
+ * qkv[N*T, 3*H*256] -> o[N*T, H*256], causal within each sequence of T rows.
+ * cos_t/sin_t (optional, fp32 [>=T, 128]): apply_rotary_pos_emb (modeling_llama.py:130-160) fused in -- q,k are read
+ * unrotated and rotated in registers at position = token index; the backward then returns the gradient with respect
+ * to the unrotated q,k.  Null: q,k are taken as they are (rotated beforehand with mh_rope).                  */
+int mh_tokattn_fwd(const void* qkv, void* o, int64_t N, int T, int H, float scale, const float* cos_t, const float* sin_t,
+                   int dtype, void* stream);
+int mh_tokattn_bwd(const void* qkv, const void* dout, void* dqkv, int64_t N, int T, int H, float scale, const float* cos_t,
+                   const float* sin_t, int dtype, void* stream);
 
 /* ---- SwiGLU (TF:models/llama/modeling_llama.py:174-176) -------------------------------------------------
  * gu[M,2I] = [gate | up];  a = silu(gate) * up;  dgu = [da*up*silu'(gate) | da*silu(gate)]            */

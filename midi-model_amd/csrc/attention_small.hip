@@ -38,32 +38,95 @@ template <> __device__ inline void st4<bf16>(bf16* p, const float (&o)[4]) {
 
 constexpr int TK = 8;  // max tokens per sequence (the octet)
 
+// Lane layout of a 256-wide head row in the token-level kernels: elements {2l, 2l+1, 128+2l, 128+2l+1} for lane l, i.e.
+// the two RoPE partners (i, i + 128) of a pair sit in the same lane, so the rotation needs no cross-lane traffic.
+// Every instruction still covers two contiguous 128-byte (bf16) runs of the row.
+template <typename T> __device__ inline void ldp(const T* row, int lane, float (&o)[4]);
+template <> __device__ inline void ldp<float>(const float* row, int lane, float (&o)[4]) {
+  const float2 a = *reinterpret_cast<const float2*>(row + 2 * lane), b = *reinterpret_cast<const float2*>(row + 128 + 2 * lane);
+  o[0] = a.x; o[1] = a.y; o[2] = b.x; o[3] = b.y;
+}
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;
+template <> __device__ inline void ldp<bf16>(const bf16* row, int lane, float (&o)[4]) {
+  const bf16x2_t a = *reinterpret_cast<const bf16x2_t*>(row + 2 * lane), b = *reinterpret_cast<const bf16x2_t*>(row + 128 + 2 * lane);
+  o[0] = (float)a[0]; o[1] = (float)a[1]; o[2] = (float)b[0]; o[3] = (float)b[1];
+}
+template <typename T> __device__ inline void stp(T* row, int lane, const float (&o)[4]);
+template <> __device__ inline void stp<float>(float* row, int lane, const float (&o)[4]) {
+  *reinterpret_cast<float2*>(row + 2 * lane) = float2{o[0], o[1]};
+  *reinterpret_cast<float2*>(row + 128 + 2 * lane) = float2{o[2], o[3]};
+}
+template <> __device__ inline void stp<bf16>(bf16* row, int lane, const float (&o)[4]) {
+  bf16x2_t a, b;
+  a[0] = (bf16)o[0]; a[1] = (bf16)o[1]; b[0] = (bf16)o[2]; b[1] = (bf16)o[3];
+  *reinterpret_cast<bf16x2_t*>(row + 2 * lane) = a;
+  *reinterpret_cast<bf16x2_t*>(row + 128 + 2 * lane) = b;
+}
+// rotate one lane's share of a row: x' = x c - partner s (first half), x' = x c + partner s (second half); dir = -1
+// undoes it (the gradient's way back).  c, s are rounded to T and so is the result when `round` (apply_rotary_pos_emb
+// computes in the activation dtype, modeling_llama.py:130-160).
+template <typename T>
+__device__ inline void rope4(float (&x)[4], const float (&c)[2], const float (&s)[2], float dir, bool round) {
+#pragma unroll
+  for (int e = 0; e < 2; ++e) {
+    const float x1 = x[e], x2 = x[e + 2], sn = dir * s[e];
+    const float r1 = x1 * c[e] - x2 * sn, r2 = x2 * c[e] + x1 * sn;
+    x[e] = round ? rnd<T>(r1) : r1;
+    x[e + 2] = round ? rnd<T>(r2) : r2;
+  }
+}
+
+template <typename T>
+__device__ inline void rope_row(float (&x)[4], const float* rope_c, const float* rope_s, int t, int lane, float dir,
+                                bool round) {
+  const float rc[2] = {rope_c[t * 128 + 2 * lane], rope_c[t * 128 + 2 * lane + 1]};
+  const float rs[2] = {rope_s[t * 128 + 2 * lane], rope_s[t * 128 + 2 * lane + 1]};
+  rope4<T>(x, rc, rs, dir, round);
+}
+
+// One wave per (sequence, head).  K and V of the <= 8 tokens stay in registers (lane l: 4 elements per row, see ldp);
+// the query rows stream through one at a time, which keeps the forward at ~125 and the backward at ~160 VGPRs
+// (3-4 waves per SIMD in flight instead of 1: these kernels only move bytes).
 template <typename T>
 __global__ __launch_bounds__(256) void tokattn_fwd_kernel(const T* __restrict__ qkv, T* __restrict__ o, int64_t NH, int Tn,
-                                                          int H, float scale) {
+                                                          int H, float scale, const float* __restrict__ cos_t,
+                                                          const float* __restrict__ sin_t) {
   const int lane = threadIdx.x & 63;
   const int64_t D = (int64_t)H * 256, D3 = 3 * D;
+  // RoPE on load (cos_t != nullptr): q, k come unrotated straight from the projection; position = token index
+  __shared__ float rope_c[TK * 128], rope_s[TK * 128];  // rounded to T once
+  const bool rot = cos_t != nullptr;
+  if (rot) {
+    for (int i = threadIdx.x; i < Tn * 128; i += 256) {
+      rope_c[i] = rnd<T>(cos_t[i]);
+      rope_s[i] = rnd<T>(sin_t[i]);
+    }
+    __syncthreads();
+  }
   for (int64_t w = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); w < NH; w += (int64_t)gridDim.x * 4) {
     const int64_t n = w / H;
     const int h = (int)(w - n * H);
-    const T* base = qkv + n * Tn * D3 + (int64_t)h * 256 + lane * 4;
-    float q[TK][4], k[TK][4], v[TK][4];
+    const T* base = qkv + n * Tn * D3 + (int64_t)h * 256;
+    float k[TK][4], v[TK][4];
 #pragma unroll
     for (int t = 0; t < TK; ++t) {
       if (t < Tn) {
-        ld4<T>(base + t * D3, q[t]);
-        ld4<T>(base + t * D3 + D, k[t]);
-        ld4<T>(base + t * D3 + 2 * D, v[t]);
+        ldp<T>(base + t * D3 + D, lane, k[t]);
+        ldp<T>(base + t * D3 + 2 * D, lane, v[t]);
+        if (rot) rope_row<T>(k[t], rope_c, rope_s, t, lane, 1.f, true);
       }
     }
 #pragma unroll
     for (int i = 0; i < TK; ++i) {
       if (i >= Tn) break;
+      float q[4];
+      ldp<T>(base + i * D3, lane, q);
+      if (rot) rope_row<T>(q, rope_c, rope_s, i, lane, 1.f, true);
       float s[TK];
       float mx = -INFINITY;
 #pragma unroll
       for (int j = 0; j <= i; ++j) {
-        float p = q[i][0] * k[j][0] + q[i][1] * k[j][1] + q[i][2] * k[j][2] + q[i][3] * k[j][3];
+        float p = q[0] * k[j][0] + q[1] * k[j][1] + q[2] * k[j][2] + q[3] * k[j][3];
         s[j] = wave_sum_fast(p) * scale;
         mx = fmaxf(mx, s[j]);
       }
@@ -81,43 +144,58 @@ __global__ __launch_bounds__(256) void tokattn_fwd_kernel(const T* __restrict__ 
 #pragma unroll
         for (int e = 0; e < 4; ++e) acc[e] += p * v[j][e];
       }
-      st4<T>(o + (n * Tn + i) * D + (int64_t)h * 256 + lane * 4, acc);
+      stp<T>(o + (n * Tn + i) * D + (int64_t)h * 256, lane, acc);
     }
   }
 }
 
 template <typename T>
 __global__ __launch_bounds__(256) void tokattn_bwd_kernel(const T* __restrict__ qkv, const T* __restrict__ dout,
-                                                          T* __restrict__ dqkv, int64_t NH, int Tn, int H, float scale) {
+                                                          T* __restrict__ dqkv, int64_t NH, int Tn, int H, float scale,
+                                                          const float* __restrict__ cos_t, const float* __restrict__ sin_t) {
   const int lane = threadIdx.x & 63;
   const int64_t D = (int64_t)H * 256, D3 = 3 * D;
+  // RoPE on load and its transpose on the way out (cos_t != nullptr): qkv is the unrotated projection output and dqkv
+  // the gradient with respect to it
+  __shared__ float rope_c[TK * 128], rope_s[TK * 128];
+  const bool rot = cos_t != nullptr;
+  if (rot) {
+    for (int i = threadIdx.x; i < Tn * 128; i += 256) {
+      rope_c[i] = rnd<T>(cos_t[i]);
+      rope_s[i] = rnd<T>(sin_t[i]);
+    }
+    __syncthreads();
+  }
   for (int64_t w = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); w < NH; w += (int64_t)gridDim.x * 4) {
     const int64_t n = w / H;
     const int h = (int)(w - n * H);
-    const int64_t off = (int64_t)h * 256 + lane * 4;
+    const int64_t off = (int64_t)h * 256;
     const T* base = qkv + n * Tn * D3 + off;
-    float q[TK][4], k[TK][4], v[TK][4], dO[TK][4];
-    float dq[TK][4], dk[TK][4], dv[TK][4];
+    T* ob = dqkv + n * Tn * D3 + off;
+    float k[TK][4], v[TK][4], dk[TK][4], dv[TK][4];
 #pragma unroll
     for (int t = 0; t < TK; ++t) {
 #pragma unroll
-      for (int e = 0; e < 4; ++e) dq[t][e] = dk[t][e] = dv[t][e] = 0.f;
+      for (int e = 0; e < 4; ++e) dk[t][e] = dv[t][e] = 0.f;
       if (t < Tn) {
-        ld4<T>(base + t * D3, q[t]);
-        ld4<T>(base + t * D3 + D, k[t]);
-        ld4<T>(base + t * D3 + 2 * D, v[t]);
-        ld4<T>(dout + (n * Tn + t) * D + off, dO[t]);
+        ldp<T>(base + t * D3 + D, lane, k[t]);
+        ldp<T>(base + t * D3 + 2 * D, lane, v[t]);
+        if (rot) rope_row<T>(k[t], rope_c, rope_s, t, lane, 1.f, true);
       }
     }
 #pragma unroll
     for (int i = 0; i < TK; ++i) {
       if (i >= Tn) break;
+      float q[4], dO[4], dq[4] = {0.f, 0.f, 0.f, 0.f};
+      ldp<T>(base + i * D3, lane, q);
+      ldp<T>(dout + (n * Tn + i) * D + off, lane, dO);
+      if (rot) rope_row<T>(q, rope_c, rope_s, i, lane, 1.f, true);
       float p[TK], dp[TK];
       float mx = -INFINITY;
 #pragma unroll
       for (int j = 0; j <= i; ++j) {
-        float a = q[i][0] * k[j][0] + q[i][1] * k[j][1] + q[i][2] * k[j][2] + q[i][3] * k[j][3];
-        float b = dO[i][0] * v[j][0] + dO[i][1] * v[j][1] + dO[i][2] * v[j][2] + dO[i][3] * v[j][3];
+        float a = q[0] * k[j][0] + q[1] * k[j][1] + q[2] * k[j][2] + q[3] * k[j][3];
+        float b = dO[0] * v[j][0] + dO[1] * v[j][1] + dO[2] * v[j][2] + dO[3] * v[j][3];
         p[j] = wave_sum_fast(a) * scale;
         dp[j] = wave_sum_fast(b);
         mx = fmaxf(mx, p[j]);
@@ -140,42 +218,45 @@ __global__ __launch_bounds__(256) void tokattn_bwd_kernel(const T* __restrict__ 
         const float ds = p[j] * (dp[j] - dsum) * scale;
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-          dq[i][e] += ds * k[j][e];
-          dk[j][e] += ds * q[i][e];
-          dv[j][e] += p[j] * dO[i][e];
+          dq[e] += ds * k[j][e];
+          dk[j][e] += ds * q[e];
+          dv[j][e] += p[j] * dO[e];
         }
       }
+      if (rot) rope_row<T>(dq, rope_c, rope_s, i, lane, -1.f, false);
+      stp<T>(ob + i * D3, lane, dq);
     }
-    T* ob = dqkv + n * Tn * D3 + off;
 #pragma unroll
     for (int t = 0; t < TK; ++t) {
       if (t < Tn) {
-        st4<T>(ob + t * D3, dq[t]);
-        st4<T>(ob + t * D3 + D, dk[t]);
-        st4<T>(ob + t * D3 + 2 * D, dv[t]);
+        if (rot) rope_row<T>(dk[t], rope_c, rope_s, t, lane, -1.f, false);
+        stp<T>(ob + t * D3 + D, lane, dk[t]);
+        stp<T>(ob + t * D3 + 2 * D, lane, dv[t]);
       }
     }
   }
 }
 
-extern "C" int mh_tokattn_fwd(const void* qkv, void* o, int64_t N, int Tn, int H, float scale, int dtype, void* stream) {
+extern "C" int mh_tokattn_fwd(const void* qkv, void* o, int64_t N, int Tn, int H, float scale, const float* cos_t,
+                              const float* sin_t, int dtype, void* stream) {
   MH_REQUIRE(N > 0 && Tn >= 1 && Tn <= TK && H >= 1, "tokattn_fwd: bad shape N=%ld T=%d H=%d", (long)N, Tn, H);
   const int64_t NH = N * H;
   int64_t g = (NH + 3) / 4;
   if (g > 32768) g = 32768;
-  DISPATCH_T(dtype, (tokattn_fwd_kernel<T><<<(int)g, 256, 0, (hipStream_t)stream>>>((const T*)qkv, (T*)o, NH, Tn, H, scale)));
+  DISPATCH_T(dtype, (tokattn_fwd_kernel<T><<<(int)g, 256, 0, (hipStream_t)stream>>>((const T*)qkv, (T*)o, NH, Tn, H, scale,
+                                                                                    cos_t, sin_t)));
   MH_LAUNCH_CHECK();
   return MH_OK;
 }
 
 extern "C" int mh_tokattn_bwd(const void* qkv, const void* dout, void* dqkv, int64_t N, int Tn, int H, float scale,
-                              int dtype, void* stream) {
+                              const float* cos_t, const float* sin_t, int dtype, void* stream) {
   MH_REQUIRE(N > 0 && Tn >= 1 && Tn <= TK && H >= 1, "tokattn_bwd: bad shape");
   const int64_t NH = N * H;
   int64_t g = (NH + 3) / 4;
   if (g > 32768) g = 32768;
   DISPATCH_T(dtype, (tokattn_bwd_kernel<T><<<(int)g, 256, 0, (hipStream_t)stream>>>((const T*)qkv, (const T*)dout, (T*)dqkv,
-                                                                                    NH, Tn, H, scale)));
+                                                                                    NH, Tn, H, scale, cos_t, sin_t)));
   MH_LAUNCH_CHECK();
   return MH_OK;
 }

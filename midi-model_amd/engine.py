@@ -112,12 +112,18 @@ def stack_forward(spec: StackSpec, W: StackTensors, x: torch.Tensor, nseq: int, 
         ops.rmsnorm_fwd(x, lw.n1, h1, rstd1, spec.eps)
         qkv = _empty((M, 3 * D), x)
         ops.gemm_nt(h1, lw.wqkv, qkv)
-        ops.rope_(qkv, rope.cos, rope.sin, slen, 0, H, spec.hd, +1)
+        # token-level stack: RoPE is applied inside the attention kernels (q,k of a (sequence, head) are in registers
+        # there anyway), so qkv stays unrotated -- except for a prefill, whose K rows go to the cache rotated
+        rope_in_attn = spec.kind != "event" and kv_out is None
+        if not rope_in_attn:
+            ops.rope_(qkv, rope.cos, rope.sin, slen, 0, H, spec.hd, +1)
         o = _empty((M, D), x)
         lse = None
         if spec.kind == "event":
             lse = _empty((nseq * H * ops.round_up(slen, 64),), x, torch.float32)
             ops.attn_fwd(qkv, o, lse, nseq, slen, H, spec.scale)
+        elif rope_in_attn:
+            ops.tokattn_fwd(qkv, o, nseq, slen, H, spec.scale, rope.cos, rope.sin)
         else:
             ops.tokattn_fwd(qkv, o, nseq, slen, H, spec.scale)
         if kv_out is not None:
@@ -175,9 +181,9 @@ def stack_backward(spec: StackSpec, W: StackTensors, G: StackTensors, ctx, dy: t
         dqkv = _empty((M, 3 * D), dy)
         if spec.kind == "event":
             ops.attn_bwd(qkv, o, do, lse, dqkv, nseq, slen, H, spec.scale)
-        else:
-            ops.tokattn_bwd(qkv, do, dqkv, nseq, slen, H, spec.scale)
-        ops.rope_(dqkv, rope.cos, rope.sin, slen, 0, H, spec.hd, -1)
+            ops.rope_(dqkv, rope.cos, rope.sin, slen, 0, H, spec.hd, -1)
+        else:  # (saved qkv is unrotated: the forward ran with save=True, never as a prefill)
+            ops.tokattn_bwd(qkv, do, dqkv, nseq, slen, H, spec.scale, rope.cos, rope.sin)
         dh1 = do
         ops.gemm_nt(dqkv, lw.wqkv, dh1, tb=True)        # d h1 = dqkv @ wqkv
         linear_wgrad(dqkv, h1, lg.wqkv, accumulate)

@@ -259,13 +259,14 @@ def attn_bwd(qkv, o, dout, lse, dqkv, B: int, S: int, H: int, scale: float):
     return dqkv
 
 
-def tokattn_fwd(qkv, o, N: int, T: int, H: int, scale: float):
-    lib().call("mh_tokattn_fwd", _p(qkv), _p(o), N, T, H, scale, dt(qkv), _stream())
+def tokattn_fwd(qkv, o, N: int, T: int, H: int, scale: float, cos_t=None, sin_t=None):
+    """cos_t/sin_t: RoPE fused in (qkv unrotated); see mh_tokattn_fwd"""
+    lib().call("mh_tokattn_fwd", _p(qkv), _p(o), N, T, H, scale, _p(cos_t), _p(sin_t), dt(qkv), _stream())
     return o
 
 
-def tokattn_bwd(qkv, dout, dqkv, N: int, T: int, H: int, scale: float):
-    lib().call("mh_tokattn_bwd", _p(qkv), _p(dout), _p(dqkv), N, T, H, scale, dt(qkv), _stream())
+def tokattn_bwd(qkv, dout, dqkv, N: int, T: int, H: int, scale: float, cos_t=None, sin_t=None):
+    lib().call("mh_tokattn_bwd", _p(qkv), _p(dout), _p(dqkv), N, T, H, scale, _p(cos_t), _p(sin_t), dt(qkv), _stream())
     return dqkv
 
 

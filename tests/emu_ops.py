@@ -192,20 +192,26 @@ def attn_bwd(qkv, o, dout, lse, dqkv, B, S, H, scale):
     return dqkv
 
 
-def tokattn_fwd(qkv, o, N, T, H, scale):
+def tokattn_fwd(qkv, o, N, T, H, scale, cos_t=None, sin_t=None):
+    if cos_t is not None:
+        qkv = rope_(qkv.clone(), cos_t, sin_t, T, 0, H, 256, +1)
     q, k, v = _split(qkv, N, T, H, 256)
     p = torch.softmax(_causal_scores(q, k, scale), -1)
     o.copy_((p @ v).transpose(1, 2).reshape(N * T, H * 256).to(o.dtype))
     return o
 
 
-def tokattn_bwd(qkv, dout, dqkv, N, T, H, scale):
+def tokattn_bwd(qkv, dout, dqkv, N, T, H, scale, cos_t=None, sin_t=None):
+    if cos_t is not None:
+        qkv = rope_(qkv.clone(), cos_t, sin_t, T, 0, H, 256, +1)
     q, k, v = _split(qkv, N, T, H, 256)
     do = dout.float().view(N, T, H, 256).transpose(1, 2)
     dq, dk, dv = _attn_grads(q, k, v, do, scale)
     D = H * 256
     for i, t in enumerate((dq, dk, dv)):
         dqkv[:, i * D:(i + 1) * D] = t.transpose(1, 2).reshape(N * T, D).to(dqkv.dtype)
+    if cos_t is not None:
+        rope_(dqkv, cos_t, sin_t, T, 0, H, 256, -1)
     return dqkv
 
 

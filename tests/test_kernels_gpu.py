@@ -284,6 +284,15 @@ def test_tokattn(ops, dtype, N, T, H):
     ops.tokattn_bwd(qkv.cuda(), do.cuda(), dq, N, T, H, scale)
     cmp(o, o_ref, dtype, what="tokattn o")
     cmp(dq, dq_ref, dtype, k=2, what="tokattn dqkv")
+    # RoPE fused in: unrotated q,k in, gradient with respect to the unrotated q,k out
+    from midi_model_amd.engine import RopeTable
+    tab = RopeTable(256, 10000.0, "cuda", 8)
+    emu.tokattn_fwd(qkv, o_ref, N, T, H, scale, tab.cos.cpu(), tab.sin.cpu())
+    emu.tokattn_bwd(qkv, do, dq_ref, N, T, H, scale, tab.cos.cpu(), tab.sin.cpu())
+    ops.tokattn_fwd(qkv.cuda(), o, N, T, H, scale, tab.cos, tab.sin)
+    ops.tokattn_bwd(qkv.cuda(), do.cuda(), dq, N, T, H, scale, tab.cos, tab.sin)
+    cmp(o, o_ref, dtype, what="tokattn+rope o")
+    cmp(dq, dq_ref, dtype, k=3, what="tokattn+rope dqkv")
 
 
 # ----------------------------------------------------------------------------------------------- SwiGLU
