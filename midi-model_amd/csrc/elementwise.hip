@@ -257,11 +257,55 @@ __global__ __launch_bounds__(256) void rmsnorm_fwd_kernel(const T* __restrict__ 
   }
 }
 
+// Row length D = NCH * 64 * (16 bytes of T): the row lives in registers (one 16-byte load per chunk and lane, all in
+// flight together), so x is read exactly once.  Same arithmetic as rmsnorm_fwd_kernel.
+template <typename T, int NCH>
+__global__ __launch_bounds__(256) void rmsnorm_fwd_reg_kernel(const T* __restrict__ x, const T* __restrict__ w,
+                                                              T* __restrict__ y, float* __restrict__ rstd, int64_t M, int D,
+                                                              float eps) {
+  constexpr int N = Pack<T>::N;
+  const int lane = threadIdx.x & 63;
+  Pack<T> ww[NCH];
+#pragma unroll
+  for (int k = 0; k < NCH; ++k) ww[k] = ld16(w + (k * 64 + lane) * N);
+  for (int64_t m = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); m < M; m += (int64_t)gridDim.x * 4) {
+    const T* xr = x + m * D;
+    Pack<T> v[NCH];
+#pragma unroll
+    for (int k = 0; k < NCH; ++k) v[k] = ld16(xr + (k * 64 + lane) * N);
+    float ss = 0.f;
+#pragma unroll
+    for (int k = 0; k < NCH; ++k)
+#pragma unroll
+      for (int e = 0; e < N; ++e) ss += v[k].get(e) * v[k].get(e);
+    ss = wave_sum(ss);
+    const float r = rsqrtf(ss / (float)D + eps);
+    if (lane == 0 && rstd != nullptr) rstd[m] = r;
+#pragma unroll
+    for (int k = 0; k < NCH; ++k) {
+      Pack<T> o;
+#pragma unroll
+      for (int e = 0; e < N; ++e) o.set(e, ww[k].get(e) * rnd<T>(v[k].get(e) * r));
+      st16(y + m * D + (k * 64 + lane) * N, o);
+    }
+  }
+}
+
 extern "C" int mh_rmsnorm_fwd(const void* x, const void* w, void* y, float* rstd, int64_t M, int D, float eps,
                               int dtype, void* stream) {
   MH_REQUIRE(M > 0 && D % 8 == 0, "rmsnorm_fwd: bad shape M=%ld D=%d", (long)M, D);
-  DISPATCH_T(dtype, (rmsnorm_fwd_kernel<T><<<grid_for(M, 4, 65536), 256, 0, (hipStream_t)stream>>>(
-                        (const T*)x, (const T*)w, (T*)y, rstd, M, D, eps)));
+  const int nch = D / (dtype == MH_BF16 ? 512 : 256);  // 16-byte chunks per lane
+  const bool reg = nch * (dtype == MH_BF16 ? 512 : 256) == D && (nch == 1 || nch == 2 || nch == 4);
+#define MH_RMSF(NCH_)                                                                                     \
+  DISPATCH_T(dtype, (rmsnorm_fwd_reg_kernel<T, NCH_><<<grid_for(M, 4, 65536), 256, 0, (hipStream_t)stream>>>( \
+                        (const T*)x, (const T*)w, (T*)y, rstd, M, D, eps)))
+  if (reg && nch == 1) MH_RMSF(1);
+  else if (reg && nch == 2) MH_RMSF(2);
+  else if (reg && nch == 4) MH_RMSF(4);
+  else
+    DISPATCH_T(dtype, (rmsnorm_fwd_kernel<T><<<grid_for(M, 4, 65536), 256, 0, (hipStream_t)stream>>>(
+                          (const T*)x, (const T*)w, (T*)y, rstd, M, D, eps)));
+#undef MH_RMSF
   MH_LAUNCH_CHECK();
   return MH_OK;
 }
@@ -318,13 +362,80 @@ __global__ __launch_bounds__(256) void rmsnorm_bwd_kernel(const T* __restrict__ 
     dw_partial[(int64_t)blockIdx.x * D + c] = dw_acc[c] + dw_acc[D + c] + dw_acc[2 * D + c] + dw_acc[3 * D + c];
 }
 
+// Register-resident variant (D = NCH * 64 * 16 bytes): every operand is read once, and the weight gradient of the columns a
+// lane owns accumulates in registers over all the rows its wave walks; LDS only for the final 4-wave reduction.
+template <typename T, int NCH>
+__global__ __launch_bounds__(256) void rmsnorm_bwd_reg_kernel(const T* __restrict__ x, const T* __restrict__ w,
+                                                              const float* __restrict__ rstd, const T* __restrict__ dy,
+                                                              const T* dres, T* dx, float* __restrict__ dw_partial,
+                                                              int64_t M, int D) {
+  constexpr int N = Pack<T>::N;
+  extern __shared__ __attribute__((aligned(16))) float dw_acc[];  // [4][D]
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  Pack<T> ww[NCH];
+  float dwr[NCH][N];
+#pragma unroll
+  for (int k = 0; k < NCH; ++k) {
+    ww[k] = ld16(w + (k * 64 + lane) * N);
+#pragma unroll
+    for (int e = 0; e < N; ++e) dwr[k][e] = 0.f;
+  }
+  for (int64_t m = (int64_t)blockIdx.x * 4 + wv; m < M; m += (int64_t)gridDim.x * 4) {
+    const float r = rstd[m];
+    Pack<T> xv[NCH], gv[NCH], rv[NCH];
+#pragma unroll
+    for (int k = 0; k < NCH; ++k) {
+      const int64_t c = m * D + (k * 64 + lane) * N;
+      xv[k] = ld16(x + c);
+      gv[k] = ld16(dy + c);
+      if (dres != nullptr) rv[k] = ld16(dres + c);
+    }
+    float dot = 0.f;
+#pragma unroll
+    for (int k = 0; k < NCH; ++k)
+#pragma unroll
+      for (int e = 0; e < N; ++e) dot += gv[k].get(e) * ww[k].get(e) * (xv[k].get(e) * r);
+    dot = wave_sum(dot) / (float)D;
+#pragma unroll
+    for (int k = 0; k < NCH; ++k) {
+      Pack<T> o;
+#pragma unroll
+      for (int e = 0; e < N; ++e) {
+        const float xh = xv[k].get(e) * r;
+        float d = r * (gv[k].get(e) * ww[k].get(e) - xh * dot);
+        if (dres != nullptr) d += rv[k].get(e);
+        o.set(e, d);
+        dwr[k][e] += gv[k].get(e) * rnd<T>(xh);
+      }
+      st16(dx + m * D + (k * 64 + lane) * N, o);
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < NCH; ++k)
+#pragma unroll
+    for (int e = 0; e < N; ++e) dw_acc[wv * D + (k * 64 + lane) * N + e] = dwr[k][e];
+  __syncthreads();
+  for (int c = threadIdx.x; c < D; c += 256)
+    dw_partial[(int64_t)blockIdx.x * D + c] = dw_acc[c] + dw_acc[D + c] + dw_acc[2 * D + c] + dw_acc[3 * D + c];
+}
+
 extern "C" int mh_rmsnorm_bwd(const void* x, const void* w, const float* rstd, const void* dy, const void* dres,
                               void* dx, float* dw_partial, int64_t M, int D, int dtype, void* stream) {
   MH_REQUIRE(M > 0 && D % 8 == 0 && D <= 8192, "rmsnorm_bwd: bad shape M=%ld D=%d", (long)M, D);
   const int blocks = mh_rmsnorm_bwd_blocks(M);
   const size_t shm = (size_t)4 * D * sizeof(float);
-  DISPATCH_T(dtype, (rmsnorm_bwd_kernel<T><<<blocks, 256, shm, (hipStream_t)stream>>>(
-                        (const T*)x, (const T*)w, rstd, (const T*)dy, (const T*)dres, (T*)dx, dw_partial, M, D)));
+  const int nch = D / (dtype == MH_BF16 ? 512 : 256);  // 16-byte chunks per lane
+  const bool reg = nch * (dtype == MH_BF16 ? 512 : 256) == D && (nch == 1 || nch == 2 || nch == 4);
+#define MH_RMSB(NCH_)                                                                                        \
+  DISPATCH_T(dtype, (rmsnorm_bwd_reg_kernel<T, NCH_><<<blocks, 256, shm, (hipStream_t)stream>>>(              \
+                        (const T*)x, (const T*)w, rstd, (const T*)dy, (const T*)dres, (T*)dx, dw_partial, M, D)))
+  if (reg && nch == 1) MH_RMSB(1);
+  else if (reg && nch == 2) MH_RMSB(2);
+  else if (reg && nch == 4) MH_RMSB(4);
+  else
+    DISPATCH_T(dtype, (rmsnorm_bwd_kernel<T><<<blocks, 256, shm, (hipStream_t)stream>>>(
+                          (const T*)x, (const T*)w, rstd, (const T*)dy, (const T*)dres, (T*)dx, dw_partial, M, D)));
+#undef MH_RMSB
   MH_LAUNCH_CHECK();
   return MH_OK;
 }

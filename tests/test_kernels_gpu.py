@@ -185,7 +185,7 @@ def test_embeddings(ops, dtype):
 
 # --------------------------------------------------------------------------------------------- RMSNorm
 @pytest.mark.parametrize("dtype", DTYPES)
-@pytest.mark.parametrize("M,D", [(1, 256), (37, 1024), (1000, 1024), (5000, 256)])
+@pytest.mark.parametrize("M,D", [(1, 256), (37, 1024), (1000, 1024), (5000, 256), (64, 2048), (10, 768), (300, 512)])
 def test_rmsnorm(ops, dtype, M, D):
     x, w, dy, dres = rnd((M, D), dtype, 13, 2.0), (1 + 0.1 * rnd((D,), torch.float32, 14)).to(dtype), rnd((M, D), dtype, 15), rnd((M, D), dtype, 16)
     y, rstd = torch.empty((M, D), dtype=dtype), torch.empty(M)
