@@ -68,12 +68,106 @@ __global__ __launch_bounds__(256) void cross_entropy_kernel(const T* logits, int
   }
 }
 
+// bf16 rows of 16-byte-aligned stride up to NCH * 512 elements: the row is loaded once with 16-byte loads and stays in
+// registers for both passes (statistics, gradient); same arithmetic as cross_entropy_kernel up to summation order.
+template <int NCH>
+__global__ __launch_bounds__(256) void cross_entropy_vec_kernel(const bf16* logits, int64_t ldl, const int64_t* __restrict__ target,
+                                                                float* __restrict__ row_loss, bf16* dlogits,
+                                                                const float* __restrict__ scale_dev,
+                                                                int64_t* __restrict__ argmax_out, int64_t R, int V,
+                                                                int64_t ignore) {
+  const int lane = threadIdx.x & 63;
+  const float scale = (dlogits != nullptr && scale_dev != nullptr) ? scale_dev[0] : 1.f;
+  const int nchunk = (int)(ldl / 8);
+  for (int64_t r = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); r < R; r += (int64_t)gridDim.x * 4) {
+    const bf16* row = logits + r * ldl;
+    bf16x8 v[NCH];
+#pragma unroll
+    for (int k = 0; k < NCH; ++k) {
+      const int ch = k * 64 + lane;
+      if (ch < nchunk) v[k] = *reinterpret_cast<const bf16x8*>(row + ch * 8);
+    }
+    float mx = -INFINITY;
+    int amax = 0x7fffffff;
+#pragma unroll
+    for (int k = 0; k < NCH; ++k)
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const int c = (k * 64 + lane) * 8 + e;
+        const float x = (float)v[k][e];
+        if (c < V && x > mx) {  // ascending c within the lane: the first maximum stays
+          mx = x;
+          amax = c;
+        }
+      }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      const float omx = __shfl_xor(mx, o, 64);
+      const int oam = __shfl_xor(amax, o, 64);
+      if (omx > mx || (omx == mx && oam < amax)) {
+        mx = omx;
+        amax = oam;
+      }
+    }
+    float sum = 0.f;
+#pragma unroll
+    for (int k = 0; k < NCH; ++k)
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const int c = (k * 64 + lane) * 8 + e;
+        if (c < V) sum += __expf((float)v[k][e] - mx);
+      }
+    sum = wave_sum(sum);
+    const float lse = mx + __logf(sum);
+    const int64_t tgt = target[r];
+    const bool keep = (tgt != ignore);
+    if (lane == 0) {
+      row_loss[r] = keep ? (lse - (float)row[tgt]) : 0.f;
+      if (argmax_out != nullptr) argmax_out[r] = amax;
+    }
+    if (dlogits != nullptr) {
+      bf16* drow = dlogits + r * ldl;
+#pragma unroll
+      for (int k = 0; k < NCH; ++k) {
+        const int ch = k * 64 + lane;
+        if (ch < nchunk) {
+          bf16x8 g8;
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            const int c = ch * 8 + e;
+            float g = 0.f;
+            if (keep && c < V) {
+              g = __expf((float)v[k][e] - lse);
+              if (c == (int)tgt) g -= 1.f;
+              g *= scale;
+            }
+            g8[e] = (bf16)g;
+          }
+          *reinterpret_cast<bf16x8*>(drow + ch * 8) = g8;
+        }
+      }
+    }
+  }
+}
+
 extern "C" int mh_cross_entropy(const void* logits, int64_t ldl, const int64_t* target, float* row_loss, void* dlogits,
                                 const float* scale_dev, int64_t* argmax_out, int64_t R, int V, int64_t ignore,
                                 int dtype, void* stream) {
   MH_REQUIRE(R > 0 && V > 0 && ldl >= V, "cross_entropy: bad shape R=%ld V=%d ldl=%ld", (long)R, V, (long)ldl);
   int64_t g = (R + 3) / 4;
   if (g > 65536) g = 65536;
+  const bool vec = dtype == MH_BF16 && ldl % 8 == 0 && ldl <= 4096 && ((uintptr_t)logits & 15) == 0 &&
+                   (dlogits == nullptr || ((uintptr_t)dlogits & 15) == 0);
+  if (vec && ldl > 3584) {
+    cross_entropy_vec_kernel<8><<<(int)g, 256, 0, (hipStream_t)stream>>>((const bf16*)logits, ldl, target, row_loss,
+                                                                         (bf16*)dlogits, scale_dev, argmax_out, R, V, ignore);
+  } else if (vec && ldl > 2048) {
+    cross_entropy_vec_kernel<7><<<(int)g, 256, 0, (hipStream_t)stream>>>((const bf16*)logits, ldl, target, row_loss,
+                                                                         (bf16*)dlogits, scale_dev, argmax_out, R, V, ignore);
+  } else if (vec) {
+    cross_entropy_vec_kernel<4><<<(int)g, 256, 0, (hipStream_t)stream>>>((const bf16*)logits, ldl, target, row_loss,
+                                                                         (bf16*)dlogits, scale_dev, argmax_out, R, V, ignore);
+  } else
   DISPATCH_T(dtype, (cross_entropy_kernel<T><<<(int)g, 256, 0, (hipStream_t)stream>>>(
                         (const T*)logits, ldl, target, row_loss, (T*)dlogits, scale_dev, argmax_out, R, V, ignore)));
   MH_LAUNCH_CHECK();
