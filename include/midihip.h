@@ -95,6 +95,12 @@ int mh_cast_from_f32(const float* src, void* dst, int64_t n, int accumulate, int
 int mh_copy_rows(const void* src, int64_t src_ld, void* dst, int64_t dst_ld, int64_t M, int D, int accumulate,
                  int dtype, void* stream);
 
+/* Batch assembly (MidiDataset.__getitem__ slicing + collate_fn, train.py:69-90) from a corpus resident in device memory:
+ * tokens int16 [n_events, T]; window b = events [win_start[b], win_start[b] + win_len[b]) (the caller keeps windows
+ * inside the corpus); out int64 [B, L, T], positions past a window's length filled with pad_id.                */
+int mh_collate_windows(const int16_t* tokens, int64_t n_events, const int64_t* win_start, const int64_t* win_len,
+                       int64_t* out, int64_t B, int64_t L, int T, int64_t pad_id, void* stream);
+
 /* ---- RMSNorm (TF:models/llama/modeling_llama.py:62-67) ---------------------------------------------
  * y = w * T(x * rsqrt(mean(x^2)+eps));  rstd[M] (fp32) is saved for the backward.                   */
 int mh_rmsnorm_fwd(const void* x, const void* w, void* y, float* rstd, int64_t M, int D, float eps, int dtype,

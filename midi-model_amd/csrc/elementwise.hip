@@ -595,3 +595,30 @@ extern "C" int mh_swiglu_bwd(const void* gu, const void* da, void* dgu, int64_t 
   MH_LAUNCH_CHECK();
   return MH_OK;
 }
+
+// ---------------------------------------------------------------------------------------------------
+// Batch assembly on the device (MidiDataset.__getitem__ slicing + collate_fn, train.py:69-90): the pre-tokenised
+// corpus lives in HBM as int16 octets [N, T]; a batch is B windows (first event, length) of it, widened to int64 and
+// padded to the longest window with pad_id.  One launch, one thread per output token.
+// ---------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void collate_windows_kernel(const int16_t* __restrict__ tokens,
+                                                              const int64_t* __restrict__ win_start,
+                                                              const int64_t* __restrict__ win_len, int64_t* __restrict__ out,
+                                                              int64_t B, int64_t L, int T, int64_t pad_id) {
+  const int64_t total = B * L * T;
+  for (int64_t it = (int64_t)blockIdx.x * 256 + threadIdx.x; it < total; it += (int64_t)gridDim.x * 256) {
+    const int j = (int)(it % T);
+    const int64_t r = it / T;
+    const int64_t t = r % L, b = r / L;
+    out[it] = (t < win_len[b]) ? (int64_t)tokens[(win_start[b] + t) * T + j] : pad_id;
+  }
+}
+
+extern "C" int mh_collate_windows(const int16_t* tokens, int64_t n_events, const int64_t* win_start, const int64_t* win_len,
+                                  int64_t* out, int64_t B, int64_t L, int T, int64_t pad_id, void* stream) {
+  MH_REQUIRE(B > 0 && L > 0 && T > 0 && n_events > 0, "collate_windows: bad shape B=%ld L=%ld T=%d", (long)B, (long)L, T);
+  collate_windows_kernel<<<grid_for(B * L * T, 256, 16384), 256, 0, (hipStream_t)stream>>>(tokens, win_start, win_len, out, B, L, T,
+                                                                                       pad_id);
+  MH_LAUNCH_CHECK();
+  return MH_OK;
+}

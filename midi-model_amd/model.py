@@ -234,7 +234,52 @@ class MIDIModel(nn.Module):
 
     # ------------------------------------------------------------------------------ reference methods
     def load_merge_lora(self, model_id):
-        raise NotImplementedError("LoRA merge (midi_model.py:109-114) needs `peft`; out of scope of the HIP path")
+        """midi_model.py:109-114 without peft: read a saved LoRA adapter (``adapter_config.json`` +
+        ``adapter_model.safetensors`` / ``.bin`` in the directory ``model_id``) and merge it into the weights in place,
+        W += scale * B @ A with scale = lora_alpha / r (or / sqrt(r) for rsLoRA), which is what
+        ``LoraModel.merge_and_unload`` computes for ``nn.Linear`` targets (train.py:439-449 trains r=64, alpha=128 on
+        q,k,v,o,gate,up,down).  Returns self.  The merge is a pure weight transform; nothing else changes."""
+        cfg_path = os.path.join(model_id, "adapter_config.json")
+        if not os.path.isdir(model_id) or not os.path.exists(cfg_path):
+            raise FileNotFoundError(f"{model_id}: not a local LoRA adapter directory (hub ids need network access)")
+        with open(cfg_path) as f:
+            cfg = json.load(f)
+        if cfg.get("peft_type", "LORA") != "LORA":
+            raise ValueError(f"unsupported peft_type {cfg.get('peft_type')}")
+        r, alpha = int(cfg["r"]), float(cfg.get("lora_alpha", cfg["r"]))
+        scale = alpha / math.sqrt(r) if cfg.get("use_rslora") else alpha / r
+        st_path = os.path.join(model_id, "adapter_model.safetensors")
+        if os.path.exists(st_path):
+            from safetensors.torch import load_file
+            sd = load_file(st_path)
+        else:
+            sd = torch.load(os.path.join(model_id, "adapter_model.bin"), map_location="cpu")
+        params = dict(self.named_parameters())
+        merged = 0
+        with torch.no_grad():
+            for key, a in sd.items():
+                if not key.endswith("lora_A.weight"):
+                    continue
+                stem = key[: -len(".lora_A.weight")]
+                b = sd[stem + ".lora_B.weight"]
+                name = stem
+                for prefix in ("base_model.model.", "base_model."):
+                    if name.startswith(prefix):
+                        name = name[len(prefix):]
+                        break
+                w = params.get(name + ".weight")
+                if w is None:
+                    raise KeyError(f"adapter targets {name}.weight, which this model does not have")
+                delta = (b.float() @ a.float()) * scale  # [out, r] @ [r, in]
+                if cfg.get("fan_in_fan_out"):
+                    delta = delta.t()
+                if delta.shape != w.shape:
+                    raise ValueError(f"{name}: adapter delta {tuple(delta.shape)} vs weight {tuple(w.shape)}")
+                w.add_(delta.to(device=w.device, dtype=w.dtype))
+                merged += 1
+        if merged == 0:
+            raise ValueError(f"{model_id}: no lora_A/lora_B pairs found")
+        return self
 
     def forward(self, x: torch.Tensor, cache=None) -> torch.Tensor:
         """x (B, S, 8) int64 -> hidden (B, S, n_embd)   [midi_model.py:137-150]

@@ -156,6 +156,16 @@ def transpose(x: torch.Tensor, out: Optional[torch.Tensor] = None, pad_to: int =
     return out
 
 
+def collate_windows(tokens_i16: torch.Tensor, win_start: torch.Tensor, win_len: torch.Tensor, out: torch.Tensor, pad_id: int):
+    """out[B, L, T] int64 <- windows of the device-resident int16 corpus tokens_i16[N, T], padded with pad_id"""
+    B, L, T = out.shape
+    assert tokens_i16.dtype == torch.int16 and tokens_i16.is_contiguous() and tokens_i16.shape[1] == T
+    assert win_start.dtype == torch.int64 and win_len.dtype == torch.int64 and out.dtype == torch.int64 and out.is_contiguous()
+    lib().call("mh_collate_windows", _p(tokens_i16), tokens_i16.shape[0], _p(win_start), _p(win_len), _p(out), B, L, T, pad_id,
+               _stream())
+    return out
+
+
 # ---------------------------------------------------------------------------------------- embeddings
 def embed_sum_fwd(tok: torch.Tensor, table: torch.Tensor, out: torch.Tensor) -> torch.Tensor:
     M, T = tok.shape

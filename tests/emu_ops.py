@@ -66,6 +66,14 @@ def transpose(x, out=None, pad_to=8):
     return out
 
 
+def collate_windows(tokens_i16, win_start, win_len, out, pad_id):
+    out.fill_(pad_id)
+    for b in range(out.shape[0]):
+        n = int(win_len[b])
+        out[b, :n] = tokens_i16[int(win_start[b]): int(win_start[b]) + n].long()
+    return out
+
+
 def embed_sum_fwd(tok, table, out):
     out.copy_(table[tok].float().sum(1).to(out.dtype))
     return out

@@ -2,6 +2,8 @@
 the fused training step + optimiser, the KV-cached decode loop and generate(), all driven through the
 test-only fake backend (tests/emu_ops.py) and checked against the reference-generated golden vectors.
 The same checks run on the real HIP kernels in test_model_gpu.py."""
+import json
+
 import numpy as np
 import pytest
 import torch
@@ -226,3 +228,62 @@ def test_forward_token_decode_path(tiny, orc):
 def test_lr_schedule():
     assert lr_lambda(0, 1000, 1e6) == 0.0 and lr_lambda(500, 1000, 1e6) == 0.5
     assert lr_lambda(1000, 1000, 1e6) == 1.0 and lr_lambda(10 ** 6, 1000, 1e6) == 0.0
+
+
+def test_device_corpus_batches_follow_reference_collate(tok):
+    """TokenCorpus + WindowSampler against MidiDataset.__getitem__ / collate_fn (train.py:69-90) restated on the host:
+    same windows (same `random` stream), widened to int64, padded to the longest with pad_id"""
+    import random
+    from midi_model_amd.data import TokenCorpus, WindowSampler, synthetic_events
+    lens = [50, 9, 300, 128, 64]
+    pieces = [synthetic_events(tok, 1, n, seed=100 + i)[0].numpy().astype(np.int16) for i, n in enumerate(lens)]
+    with emu_ops.install():
+        corpus = TokenCorpus(pieces, device="cpu")
+        for rand_start in (True, False):
+            sampler = WindowSampler(corpus, max_len=64, rand_start=rand_start, seed=7)
+            idx = [2, 0, 1, 4, 3, 2]
+            got = sampler.batch(idx, pad_id=tok.pad_id)
+            rng = random.Random(7)
+            ref = []
+            for i in idx:  # train.py:73-83
+                mid = pieces[i]
+                if rand_start:
+                    start = rng.randrange(0, max(1, mid.shape[0] - 64))
+                    start = rng.choice([0, start])
+                else:
+                    max_start = max(1, mid.shape[0] - 64)
+                    start = (i * (max_start // 8)) % max_start
+                ref.append(torch.from_numpy(mid[start:start + 64].astype(np.int64)))
+            L = max(len(m) for m in ref)  # train.py:84-90
+            want = torch.stack([torch.nn.functional.pad(m, (0, 0, 0, L - m.shape[0]), value=tok.pad_id) for m in ref])
+            assert got.dtype == torch.int64 and torch.equal(got, want)
+
+
+def test_load_merge_lora(tmp_path, tiny):
+    """a saved LoRA adapter merges as W += (alpha / r) * B @ A into exactly the targeted weights (midi_model.py:109-114)"""
+    from safetensors.torch import save_file
+    shp, sd, _ = tiny
+    with emu_ops.install():
+        model = mm.MIDIModel(tiny_config())
+        model.load_state_dict(sd)
+        before = {k: v.clone() for k, v in model.state_dict().items()}
+        g = torch.Generator().manual_seed(0)
+        targets = ["net.layers.0.self_attn.q_proj", "net.layers.1.mlp.down_proj", "net_token.layers.0.mlp.gate_proj"]
+        ad, want = {}, {}
+        for t in targets:
+            w = before[t + ".weight"]
+            a, b = torch.randn((4, w.shape[1]), generator=g) * 0.1, torch.randn((w.shape[0], 4), generator=g) * 0.1
+            ad[f"base_model.model.{t}.lora_A.weight"], ad[f"base_model.model.{t}.lora_B.weight"] = a, b
+            want[t + ".weight"] = w + (8.0 / 4) * (b @ a)
+        d = tmp_path / "adapter"
+        d.mkdir()
+        save_file(ad, str(d / "adapter_model.safetensors"))
+        (d / "adapter_config.json").write_text(json.dumps({"peft_type": "LORA", "r": 4, "lora_alpha": 8,
+                                                           "target_modules": ["q_proj", "down_proj", "gate_proj"]}))
+        assert model.load_merge_lora(str(d)) is model
+        after = model.state_dict()
+        for k, v in after.items():
+            ref = want.get(k, before[k])
+            assert torch.allclose(v, ref, atol=1e-6), k
+        with pytest.raises(FileNotFoundError):
+            model.load_merge_lora("skytnt/some-hub-id")

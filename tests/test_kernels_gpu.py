@@ -446,3 +446,15 @@ def test_sample_top_p_k_fused(ops, dtype, top_p, top_k):
         assert (buf[:, 3].cpu() == want).all(), (pos, (buf[:, 3].cpu() != want).nonzero().flatten().tolist())
         assert torch.equal(ob, buf[:, 3]) and (pos != 0 or torch.equal(oc, buf[:, 3]))
     assert (buf[:, :3] == -7).all() and (buf[:, 4:] == -7).all()
+
+
+def test_collate_windows(ops):
+    """device-side batch assembly (mh_collate_windows) against the host restatement"""
+    g = torch.Generator().manual_seed(5)
+    tokens = torch.randint(-3000, 3000, (5000, 8), generator=g).to(torch.int16)
+    start = torch.tensor([0, 4990, 17, 2500, 100], dtype=torch.int64)
+    length = torch.tensor([64, 10, 1, 300, 299], dtype=torch.int64)
+    want = emu.collate_windows(tokens, start, length, torch.empty((5, 300, 8), dtype=torch.int64), 0)
+    out = torch.full((5, 300, 8), -1, dtype=torch.int64, device="cuda")
+    ops.collate_windows(tokens.cuda(), start.cuda(), length.cuda(), out, 0)
+    assert torch.equal(out.cpu(), want)
