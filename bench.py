@@ -132,7 +132,7 @@ def bench_generate(args):
         steps_per_event = tok_steps / (n_new * args.steps)
         by = decode_bytes_per_event(B, (1 + n_new) / 2.0, steps_per_event)
         out_d = {
-            "metric": "MIDI events/sec, KV-cached generate(), tv2o-medium", "value": events / dt, "unit": "events/s",
+            "metric": f"MIDI events/sec, KV-cached generate(), {args.config}", "value": events / dt, "unit": "events/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
             "config": {"workload": f"{args.config} {args.dtype} generate(): batch {B} per GPU, BOS prompt, {n_new} new events, "
@@ -228,14 +228,17 @@ def main():
     if rank == 0:
         events = world * B * S * args.steps
         value = events / dt
-        fl_event = train_flops_per_event(S)
+        nc, tc = cfg.net_config, cfg.net_token_config
+        fl_event = train_flops_per_event(S, net_L=nc.num_hidden_layers, tok_L=tc.num_hidden_layers, D=nc.hidden_size,
+                                         I=nc.intermediate_size, It=tc.intermediate_size, V=model.tokenizer.vocab_size)
         out = {
-            "metric": "MIDI events/sec, training step (fwd+bwd+clip+AdamW), tv2o-medium, seq=2048",
+            "metric": f"MIDI events/sec, training step (fwd+bwd+clip+AdamW), {args.config}, seq={S}",
             "value": value, "unit": "events/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": args.dtype, "data": "synthetic",
             "config": {"workload": f"{args.config} {args.dtype} training step, per-GPU batch {B} x {S} events x 8 tokens "
-                                   f"(BASELINE.json configs[1]); random-init weights, synthetic events",
+                                   f"({'BASELINE.json configs[1]' if (args.config, B, S) == ('tv2o-medium', 16, 2048) else 'non-headline configuration'}); "
+                                   f"random-init weights, synthetic events",
                        "global_batch": world * B, "seq_len": S, "parallelism": f"dp{world}", "accumulate_grad_batches": 1,
                        "optimizer": "AdamW bf16-true + global-norm clip 1.0" if args.dtype == "bf16" else "AdamW fp32 + clip"},
             "loss": loss_v,
