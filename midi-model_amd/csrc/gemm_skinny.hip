@@ -168,9 +168,8 @@ extern "C" int mh_gemm_skinny(const void* A, int64_t lda, const void* W, int64_t
           (const bf16*)A, lda, (const bf16*)W, ldw, (bf16*)C, ldc, (const bf16*)R, ldr, (int)M, (int)N, (int)K, norm_eps); \
   } while (0)
   if (mode == MH_SKINNY_GATEUP) MH_SK(1, 2, 4, (N + 15) / 16);
-  else if (N > 2048) MH_SK(0, 2, 4, (N + 31) / 32);
-  else if (K >= 2048) MH_SK(0, 1, 8, (N + 15) / 16);
-  else MH_SK(0, 1, 4, (N + 15) / 16);
+  else if (N > 4096) MH_SK(0, 2, 4, (N + 31) / 32);
+  else MH_SK(0, 1, 8, (N + 15) / 16);  // 16 columns x 8 waves: <= 4 chunks per wave at K = 1024, all in flight
 #undef MH_SK
   MH_LAUNCH_CHECK();
   return MH_OK;
