@@ -5,14 +5,14 @@
 //     L2, and ablating either the loads or the MFMAs only removes 30 % of the time -> both sides matter;
 //   * every global_load_lds instruction costs its wave ~100+ issue cycles, so the loads per MFMA must drop;
 //   * a workgroup whose two waves per SIMD run in lockstep never overlaps LDS reads with MFMAs (256x128 pipelined
-//     kernel: slower than two independent 128x128 blocks), while the ping-pong schedule of gemm_pipe.hip does.
+//     kernel: slower than two independent 128x128 blocks), while a ping-pong schedule does.
 // This kernel therefore uses
 //   * a 256x256 tile (128 FLOP per staged byte), 8 waves = 2 groups (M halves) x 4 (N quarters), wave tile 128x64:
 //     per 32-deep K-step a wave issues 4 LDS-DMA + 12 ds_read_b128 for 32 MFMAs (16x16x32);
 //   * K-step 32 (64-byte LDS rows) so a step's fragments are 48 VGPRs and four 32 KiB stages fit (128 KiB):
 //     three K-steps of LDS-DMA stay in flight, waited with counted vmcnt only;
 //   * the ping-pong schedule: waves w and w+4 share a SIMD and alternate LOAD(t) / MFMA(t) segments one segment
-//     apart, one workgroup barrier per segment (see gemm_pipe.hip for the ordering argument);
+//     apart, one workgroup barrier per segment (ordering argument at the barriers below);
 //   * 64-byte-row LDS layout: chunk c of row r sits at r*64 + ((c ^ X[(r>>2)&3]) << 4), X = {0,3,2,1}: the four
 //     16-lane groups of a ds_read_b128 fragment read (rows i, chunk g) each hit 16 distinct 16-byte slots of the
 //     256-byte bank row; contraction-major operands keep the 32-byte-granule swizzle and ds_read_b64_tr_b16.
