@@ -145,6 +145,11 @@ def test_tiny_fp32_generate_token_ids(tiny, golden, tok):
     assert out.shape == (4, 24, 8)
     assert not np.isin(out[:, 1:, 0], [tok.event_ids["patch_change"], tok.event_ids["control_change"]]).any()
     assert not np.isin(out, banned).any()
+    # top_k above the fused sampler's limit: the reference's own op chain (torch.sort / cumsum / multinomial) inside the graphs
+    a = model.generate(None, batch_size=2, max_len=10, top_k=100, ban_eos=True, generator=gen.manual_seed(8))
+    b = model.generate(None, batch_size=2, max_len=10, top_k=100, ban_eos=True, generator=gen.manual_seed(8))
+    assert a.shape == (2, 10, 8) and (a == b).all()
+    assert all(tok.tokens2event(r.tolist()) != [] for i in range(2) for r in a[i, 1:])
     # bf16 + graphs: same API, well-formed events
     mb = build(mm.MIDIModel, tiny_config(), sd, dtype=torch.bfloat16)
     out = mb.generate(None, batch_size=2, max_len=10, ban_eos=True, generator=gen.manual_seed(7))
