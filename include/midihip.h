@@ -62,11 +62,14 @@ int mh_gemm_splitk_reduce(const void* workspace, void* C, int64_t ldc, const voi
  *   MH_SKINNY_PLAIN   C[M,N] = A[M,K] * W[N,K]^T (+ R)
  *   MH_SKINNY_GATEUP  W = [gate; up] (2N rows): C[M,N] = round(silu(round(A gate^T))) * round(A up^T)   (LlamaMLP)
  * K a multiple of 256.  norm_eps > 0: every row of the product is scaled by rsqrt(mean_k A[m,k]^2 + norm_eps) before
- * the epilogue -- with the RMSNorm weight folded into W by the caller this is LlamaRMSNorm (:62-67) + projection.    */
+ * the epilogue -- with the RMSNorm weight folded into W by the caller this is LlamaRMSNorm (:62-67) + projection.
+ * row_ids / res_ids (optional, int64 [M]): row m of A / of R is row ids[m] of the given table (nn.Embedding lookup of
+ * the token just sampled, midi_model.py:126-131, without a launch of its own).                                   */
 #define MH_SKINNY_PLAIN 0
 #define MH_SKINNY_GATEUP 1
 int mh_gemm_skinny(const void* A, int64_t lda, const void* W, int64_t ldw, void* C, int64_t ldc, const void* R,
-                   int64_t ldr, int mode, float norm_eps, int64_t M, int64_t N, int64_t K, int dtype, void* stream);
+                   int64_t ldr, int mode, float norm_eps, const int64_t* row_ids, const int64_t* res_ids, int64_t M,
+                   int64_t N, int64_t K, int dtype, void* stream);
 /* out[C,R] = in[R,C]^T (operand re-layout for dgrad/wgrad). */
 int mh_transpose(const void* in, int64_t ldi, void* out, int64_t ldo, int64_t rows, int64_t cols, int dtype,
                  void* stream);
@@ -209,7 +212,8 @@ int mh_masked_softmax(const void* logits, int64_t ldl, const int32_t* lo, const 
  * renormalise, and return for every row the id maximising p_j / q[b, j], where q [B, V] holds Exp(1) draws (only the
  * first top_k of a row are read) taken by the caller from the caller's generator (torch.Tensor.exponential_), which is
  * what keeps a seeded generator's stream identical to the reference's.  The id goes to out[b * out_stride] and, when
- * non-null, to out_b[b] and out_c[b] (all int64).  1 <= top_k <= 64.  ban_mask (optional, [V] bytes): ids with a
+ * non-null, to out_b[b] and out_c[b] (all int64); the fill_rest entries after out[b * out_stride] are set to fill_id
+ * (position 0 opens a fresh event row padded with pad_id).  1 <= top_k <= 64.  ban_mask (optional, [V] bytes): ids with a
  * non-zero byte are removed from every mask (app.py:30-31,85-86 disable_channels).  The caller states the spans of the masks:
  * first_mask is zero outside [first_lo, first_hi), no table range AT THIS POSITION is longer than max_range; both at most
  * 2048 ids.                                                                                                 */
@@ -218,7 +222,7 @@ int mh_sample_top_p_k(const void* logits, int64_t ldl, const uint8_t* first_mask
                       const int32_t* lo_tab, const int32_t* hi_tab, int tab_stride, int max_range, const int64_t* ev,
                       int pos, const float* q, int64_t* out,
                       int64_t out_stride, int64_t* out_b, int64_t* out_c, int64_t B, int V, float temp, float top_p,
-                      int top_k, int dtype, void* stream);
+                      int top_k, int fill_rest, int64_t fill_id, int dtype, void* stream);
 
 #ifdef __cplusplus
 }

@@ -14,6 +14,9 @@
 // (W' = W * w_norm, decode.py) this is LlamaRMSNorm + projection in one launch: rstd * (x . (w_norm * W)) instead of
 // (w_norm * round(x * rstd)) . W -- the same product up to where the bf16 roundings fall.
 //
+// Optional row indirection: row m of A is row row_ids[m] of a table (the token embedding looked up by the ids just
+// sampled), likewise the residual with res_ids -- the embedding lookup of a token step costs no launch of its own.
+//
 // Epilogues:
 //   MH_SKINNY_PLAIN   C = acc (+ R)
 //   MH_SKINNY_GATEUP  W = [gate rows; up rows] (2N x K); a workgroup takes 16 gate and the 16 matching up columns and
@@ -30,7 +33,8 @@ template <int MODE, int NBT, int NW, bool RSTD>
 __global__ __launch_bounds__(NW * 64) void gemm_skinny_kernel(const bf16* __restrict__ A, int64_t lda,
                                                           const bf16* __restrict__ W, int64_t ldw, bf16* __restrict__ C,
                                                           int64_t ldc, const bf16* __restrict__ R, int64_t ldr, int M, int N,
-                                                          int K, float norm_eps) {
+                                                          int K, float norm_eps, const int64_t* __restrict__ row_ids,
+                                                          const int64_t* __restrict__ res_ids) {
   constexpr int NB = NBT * 16;
   __shared__ float red[NW][64][NB + 1];
   __shared__ float ssq[RSTD ? NW : 1][64];
@@ -43,7 +47,8 @@ __global__ __launch_bounds__(NW * 64) void gemm_skinny_kernel(const bf16* __rest
 #pragma unroll
   for (int mb = 0; mb < 4; ++mb) {
     const int m = mb * 16 + fi;
-    arow[mb] = A + (int64_t)(m < M ? m : M - 1) * lda + fg * 8;
+    const int64_t mr = (m < M) ? m : M - 1;
+    arow[mb] = A + (row_ids != nullptr ? row_ids[mr] : mr) * lda + fg * 8;  // row_ids: A rows gathered from a table
   }
 #pragma unroll
   for (int nb = 0; nb < NBT; ++nb) {
@@ -138,7 +143,7 @@ __global__ __launch_bounds__(NW * 64) void gemm_skinny_kernel(const bf16* __rest
       const int n = blockIdx.x * NB + c0 + j;
       if (n < N) {
         float v = total(c0 + j);
-        if (R != nullptr) v += (float)R[(int64_t)m * ldr + n];
+        if (R != nullptr) v += (float)R[(res_ids != nullptr ? res_ids[m] : (int64_t)m) * ldr + n];
         C[(int64_t)m * ldc + n] = (bf16)v;
       }
     }
@@ -148,8 +153,8 @@ __global__ __launch_bounds__(NW * 64) void gemm_skinny_kernel(const bf16* __rest
 }  // namespace
 
 extern "C" int mh_gemm_skinny(const void* A, int64_t lda, const void* W, int64_t ldw, void* C, int64_t ldc, const void* R,
-                              int64_t ldr, int mode, float norm_eps, int64_t M, int64_t N, int64_t K, int dtype,
-                              void* stream) {
+                              int64_t ldr, int mode, float norm_eps, const int64_t* row_ids, const int64_t* res_ids, int64_t M,
+                              int64_t N, int64_t K, int dtype, void* stream) {
   MH_REQUIRE(dtype == MH_BF16, "gemm_skinny: bf16 only (the fp32 verification mode uses mh_gemm)");
   MH_REQUIRE(M > 0 && M <= 64 && N > 0 && N < (1 << 24), "gemm_skinny: needs 1 <= M <= 64 rows (M=%ld N=%ld)", (long)M, (long)N);
   MH_REQUIRE(mode == MH_SKINNY_PLAIN || mode == MH_SKINNY_GATEUP, "gemm_skinny: mode %d", mode);
@@ -162,10 +167,12 @@ extern "C" int mh_gemm_skinny(const void* A, int64_t lda, const void* W, int64_t
   do {                                                                                                                    \
     if (norm_eps > 0.f)                                                                                                   \
       gemm_skinny_kernel<MODE_, NBT_, NW_, true><<<(int)(GRID_), NW_ * 64, 0, st>>>(                                      \
-          (const bf16*)A, lda, (const bf16*)W, ldw, (bf16*)C, ldc, (const bf16*)R, ldr, (int)M, (int)N, (int)K, norm_eps); \
+          (const bf16*)A, lda, (const bf16*)W, ldw, (bf16*)C, ldc, (const bf16*)R, ldr, (int)M, (int)N, (int)K, norm_eps, \
+          row_ids, res_ids);                                                                                              \
     else                                                                                                                  \
       gemm_skinny_kernel<MODE_, NBT_, NW_, false><<<(int)(GRID_), NW_ * 64, 0, st>>>(                                     \
-          (const bf16*)A, lda, (const bf16*)W, ldw, (bf16*)C, ldc, (const bf16*)R, ldr, (int)M, (int)N, (int)K, norm_eps); \
+          (const bf16*)A, lda, (const bf16*)W, ldw, (bf16*)C, ldc, (const bf16*)R, ldr, (int)M, (int)N, (int)K, norm_eps, \
+          row_ids, res_ids);                                                                                              \
   } while (0)
   if (mode == MH_SKINNY_GATEUP) MH_SK(1, 2, 4, (N + 15) / 16);
   else if (N > 4096) MH_SK(0, 2, 4, (N + 31) / 32);

@@ -398,7 +398,8 @@ __global__ __launch_bounds__(256) void sample_top_p_k_kernel(const T* __restrict
                                                              int first_hi, const float* __restrict__ q,
                                                              int64_t* __restrict__ out, int64_t out_stride,
                                                              int64_t* __restrict__ out_b, int64_t* __restrict__ out_c,
-                                                             int64_t B, int V, float temp, float top_p, int top_k) {
+                                                             int64_t B, int V, float temp, float top_p, int top_k,
+                                                             int fill_rest, int64_t fill_id) {
   __shared__ float sel_v[1][SAMPLE_MAX_K];
   __shared__ int sel_i[1][SAMPLE_MAX_K];
   __shared__ float part_m[4], part_s[4];
@@ -490,6 +491,7 @@ __global__ __launch_bounds__(256) void sample_top_p_k_kernel(const T* __restrict
     }
     const int64_t id = (int64_t)sel_i[wv][bj];
     out[b * out_stride] = id;
+    for (int j = 1; j <= fill_rest; ++j) out[b * out_stride + j] = fill_id;  // position 0 opens a fresh event row
     if (out_b != nullptr) out_b[b] = id;
     if (out_c != nullptr) out_c[b] = id;
   }
@@ -500,8 +502,10 @@ extern "C" int mh_sample_top_p_k(const void* logits, int64_t ldl, const uint8_t*
                                  const int32_t* lo_tab, const int32_t* hi_tab, int tab_stride, int max_range,
                                  const int64_t* ev, int pos, const float* q,
                                  int64_t* out, int64_t out_stride, int64_t* out_b, int64_t* out_c, int64_t B, int V,
-                                 float temp, float top_p, int top_k, int dtype, void* stream) {
-  MH_REQUIRE(B > 0 && V > 0 && temp > 0.f && pos >= 0 && pos < tab_stride, "sample_top_p_k: bad args");
+                                 float temp, float top_p, int top_k, int fill_rest, int64_t fill_id, int dtype,
+                                 void* stream) {
+  MH_REQUIRE(B > 0 && V > 0 && temp > 0.f && pos >= 0 && pos < tab_stride && fill_rest >= 0 && fill_rest < out_stride,
+             "sample_top_p_k: bad args");
   MH_REQUIRE(pos == 0 || (ev != nullptr && lo_tab != nullptr && hi_tab != nullptr), "sample_top_p_k: position %d needs the event ids and range tables", pos);
   MH_REQUIRE(top_k >= 1 && top_k <= SAMPLE_MAX_K && top_k <= V, "sample_top_p_k: top_k=%d outside [1, %d]", top_k,
              SAMPLE_MAX_K);
@@ -512,7 +516,7 @@ extern "C" int mh_sample_top_p_k(const void* logits, int64_t ldl, const uint8_t*
 #define MH_SAMPLE(TMAX_)                                                                                                  \
   DISPATCH_T(dtype, (sample_top_p_k_kernel<T, TMAX_><<<(int)B, 256, 0, (hipStream_t)stream>>>(               \
                         (const T*)logits, ldl, first_mask, ban_mask, lo_tab, hi_tab, tab_stride, ev, pos, first_lo, first_hi, q, out, \
-                        out_stride, out_b, out_c, B, V, temp, top_p, top_k)))
+                        out_stride, out_b, out_c, B, V, temp, top_p, top_k, fill_rest, fill_id)))
   if (span <= 128) MH_SAMPLE(2);
   else if (span <= 512) MH_SAMPLE(8);
   else MH_SAMPLE(32);

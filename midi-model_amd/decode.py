@@ -97,19 +97,23 @@ class DecodeSession:
     def _tok_body(self, i: int, generator=None):
         m = self.model
         tspec, Wt = m._specs["net_token"], m._W["net_token"]
-        x = self.hidden if i == 0 else Wt.embed.index_select(0, self.samples_in)
         self.kv2.len = i
         lm_w = m.lm_head.weight.data
         if self.lm_fold is not None:  # the stack's final RMSNorm rides on the lm_head projection
-            h = engine.stack_decode(tspec, Wt, x, self.rope2, self.kv2, folded=self.fold2, final_norm=False)
+            if i == 0:
+                h = engine.stack_decode(tspec, Wt, self.hidden, self.rope2, self.kv2, folded=self.fold2, final_norm=False)
+            else:  # the embedding of the token just sampled is looked up inside the first projections
+                h = engine.stack_decode(tspec, Wt, Wt.embed, self.rope2, self.kv2, folded=self.fold2, final_norm=False,
+                                        x_ids=self.samples_in)
             ops.gemm_skinny(h, self.lm_fold, self.logits[:, : self.V], norm_eps=tspec.eps)
         else:
+            x = self.hidden if i == 0 else Wt.embed.index_select(0, self.samples_in)
             h = engine.stack_decode(tspec, Wt, x, self.rope2, self.kv2)
             if ops.skinny_ok(h, tspec.D):
                 ops.gemm_skinny(h, lm_w, self.logits[:, : self.V])
             else:
                 ops.gemm_nt(h, lm_w, self.logits[:, : self.V])
-        if i == 0:
+        if i == 0 and not self.fused_sampler:
             self.seq.fill_(self.pad_id)
         if self.fused_sampler:
             # one launch instead of sample_top_p_k's ~25: the Exp(1) noise torch.multinomial would draw internally
@@ -118,7 +122,7 @@ class DecodeSession:
             ops.sample_top_p_k(self.logits, self.first_mask, self.lo_tab, self.hi_tab, self.ev, i, self.q, self.seq[:, i],
                                self.V, self.temp, self.top_p, self.top_k, out_b=self.samples_in,
                                out_c=self.ev if i == 0 else None, first_span=self.first_span, max_range=self.max_range[i],
-                               ban_mask=self.ban)
+                               ban_mask=self.ban, fill_rest=self.T - 1 if i == 0 else 0, fill_id=self.pad_id)
             return
         if i == 0:
             lo, hi = self.neg1, self.neg1

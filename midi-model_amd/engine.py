@@ -244,7 +244,7 @@ def fold_norm_weights(W: StackTensors):
 
 
 def stack_decode(spec: StackSpec, W: StackTensors, x: torch.Tensor, rope: RopeTable, kv: KVState, pos_dev=None,
-                 folded=None, final_norm: bool = True):
+                 folded=None, final_norm: bool = True, x_ids=None):
     """x [B, D]: one new position per sequence at index kv.len (q_len == 1 => no causal mask,
     TF:integrations/sdpa_attention.py:120).
 
@@ -253,24 +253,28 @@ def stack_decode(spec: StackSpec, W: StackTensors, x: torch.Tensor, rope: RopeTa
     bf16 with at most 64 sequences runs the projections on mh_gemm_skinny: 7 launches per layer (K/V append fused
     into the attention, gate|up and SwiGLU fused), 5 with ``folded`` (fold_norm_weights: the two RMSNorms ride on the
     q|k|v and gate|up projections); otherwise the general GEMM is used (9 launches + split-K reductions).
-    ``final_norm=False`` returns the residual stream before the stack's last RMSNorm (decode.py folds it into lm_head)."""
+    ``final_norm=False`` returns the residual stream before the stack's last RMSNorm (decode.py folds it into lm_head).
+    ``x_ids`` (folded form only): ``x`` is an embedding table and row b of the input is x[x_ids[b]] -- the lookup happens
+    inside the first layer's projections."""
     _check_heads(spec)
-    B, D = x.shape
+    B, D = (x_ids.shape[0], x.shape[1]) if x_ids is not None else x.shape
+    assert x_ids is None or folded is not None
     H, I, hd = spec.H, spec.I, spec.hd
     pos = kv.len if pos_dev is None else 0
     if pos_dev is None:
         kv.reserve(pos + 1)
         rope.ensure(pos + 1)
-    fused = ops.skinny_ok(x, D) and ops.skinny_ok(x, I)
+    fused = (x_ids is not None) or (ops.skinny_ok(x, D) and ops.skinny_ok(x, I))
     for li, lw in enumerate(W.layers):
         if fused and folded is not None:
             wqkv_n, wgu_n = folded[li]
+            ids = x_ids if li == 0 else None  # layer 0 may read its input rows straight from the embedding table
             qkv = _empty((B, 3 * D), x)
-            ops.gemm_skinny(x, wqkv_n, qkv, norm_eps=spec.eps)
+            ops.gemm_skinny(x, wqkv_n, qkv, norm_eps=spec.eps, row_ids=ids)
             o = _empty((B, D), x)
             ops.attn_decode_append(qkv, rope.cos, rope.sin, kv.k[li], kv.v[li], o, B, H, hd, kv.cap, pos, spec.scale, pos_dev)
             x2 = _empty((B, D), x)
-            ops.gemm_skinny(o, lw.wo, x2, res=x)
+            ops.gemm_skinny(o, lw.wo, x2, res=x, res_ids=ids)
             a = _empty((B, I), x)
             ops.gemm_skinny(x2, wgu_n, a, mode=ops.SKINNY_GATEUP, norm_eps=spec.eps)
             x3 = _empty((B, D), x)

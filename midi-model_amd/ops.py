@@ -124,15 +124,21 @@ SKINNY_PLAIN, SKINNY_GATEUP = 0, 1
 
 
 def gemm_skinny(a: torch.Tensor, w: torch.Tensor, out: torch.Tensor, *, mode: int = SKINNY_PLAIN,
-                res: Optional[torch.Tensor] = None, norm_eps: float = 0.0) -> torch.Tensor:
+                res: Optional[torch.Tensor] = None, norm_eps: float = 0.0, row_ids: Optional[torch.Tensor] = None,
+                res_ids: Optional[torch.Tensor] = None) -> torch.Tensor:
     """decode-step projection, M <= 64 rows, bf16 (mh_gemm_skinny): out[M,N] = a @ w[N,K]^T (+ res), or with
     SKINNY_GATEUP w = [gate; up] ([2N,K]) and out[M,N] = silu(a @ gate^T) * (a @ up^T).  norm_eps > 0 scales row m of
-    the product by rsqrt(mean(a[m]^2) + norm_eps) first (RMSNorm with its weight folded into w)."""
+    the product by rsqrt(mean(a[m]^2) + norm_eps) first (RMSNorm with its weight folded into w).  row_ids / res_ids
+    (int64 [M]): `a` / `res` are tables and row m is their row ids[m] (embedding lookup folded in)."""
     M, N = out.shape
     K = w.shape[1]
-    assert a.shape == (M, K) and w.shape[0] == (2 * N if mode == SKINNY_GATEUP else N), (a.shape, w.shape, out.shape, mode)
+    assert a.shape[1] == K and (row_ids is not None or a.shape[0] == M), (a.shape, out.shape)
+    assert w.shape[0] == (2 * N if mode == SKINNY_GATEUP else N), (a.shape, w.shape, out.shape, mode)
+    for t in (row_ids, res_ids):
+        assert t is None or (t.dtype == torch.int64 and t.is_contiguous() and t.numel() == M)
     lib().call("mh_gemm_skinny", _p(a), _rowmajor(a), _p(w), _rowmajor(w), _p(out), _rowmajor(out), _p(res),
-               _rowmajor(res) if res is not None else 0, mode, norm_eps, M, N, K, dt(out), _stream())
+               _rowmajor(res) if res is not None else 0, mode, norm_eps, _p(row_ids), _p(res_ids), M, N, K, dt(out),
+               _stream())
     return out
 
 
@@ -358,7 +364,8 @@ def mask_spans(first_mask: torch.Tensor, lo_tab: torch.Tensor, hi_tab: torch.Ten
 
 
 def sample_top_p_k(logits, first_mask, lo_tab, hi_tab, ev, pos: int, q, out, V: int, temp: float, top_p: float,
-                   top_k: int, out_b=None, out_c=None, first_span=(0, 0), max_range: int = 0, ban_mask=None):
+                   top_k: int, out_b=None, out_c=None, first_span=(0, 0), max_range: int = 0, ban_mask=None,
+                   fill_rest: int = 0, fill_id: int = 0):
     """fused grammar-masked softmax + top-p/top-k + draw of token position `pos`; q [B, V] fp32 Exp(1) noise; the id goes
     to `out` (a strided int64 view [B]) and to the contiguous int64 [B] tensors out_b / out_c when given.  first_span =
     [lo, hi) outside of which first_mask is zero; max_range = the longest [lo_tab, hi_tab) range at this position
@@ -371,7 +378,7 @@ def sample_top_p_k(logits, first_mask, lo_tab, hi_tab, ev, pos: int, q, out, V: 
     lib().call("mh_sample_top_p_k", _p(logits), _rowmajor(logits), _p(first_mask), _p(ban_mask), int(first_span[0]),
                int(first_span[1]),
                _p(lo_tab), _p(hi_tab), lo_tab.shape[1], int(max_range), _p(ev), pos, _p(q), _p(out), out.stride(0),
-               _p(out_b), _p(out_c), B, V, temp, top_p, top_k, dt(logits), _stream())
+               _p(out_b), _p(out_c), B, V, temp, top_p, top_k, fill_rest, fill_id, dt(logits), _stream())
     return out
 
 

@@ -44,7 +44,11 @@ def skinny_ok(x, K):
     return x.dtype == torch.bfloat16 and x.shape[0] <= 64 and K % 256 == 0
 
 
-def gemm_skinny(a, w, out, *, mode=0, res=None, norm_eps=0.0):
+def gemm_skinny(a, w, out, *, mode=0, res=None, norm_eps=0.0, row_ids=None, res_ids=None):
+    if row_ids is not None:
+        a = a[row_ids]
+    if res is not None and res_ids is not None:
+        res = res[res_ids]
     r = a.float() @ w.float().T
     if norm_eps > 0:
         r = r * torch.rsqrt(a.float().pow(2).mean(-1, keepdim=True) + norm_eps)
@@ -335,7 +339,7 @@ def mask_spans(first_mask, lo_tab, hi_tab):
 
 
 def sample_top_p_k(logits, first_mask, lo_tab, hi_tab, ev, pos, q, out, V, temp, top_p, top_k, out_b=None, out_c=None,
-                   first_span=(0, 0), max_range=0, ban_mask=None):
+                   first_span=(0, 0), max_range=0, ban_mask=None, fill_rest=0, fill_id=0):
     B = logits.shape[0]
     if pos == 0:
         lo = hi = torch.full((B,), -1, dtype=torch.int32)
@@ -353,6 +357,9 @@ def sample_top_p_k(logits, first_mask, lo_tab, hi_tab, ev, pos, q, out, V, temp,
     j = torch.argmax(ps / q, -1)
     ids = pi.gather(-1, j[:, None])[:, 0]
     out.copy_(ids)
+    if fill_rest:  # `out` is column `pos` of a [B, T] buffer: the following columns get the pad id
+        flat = out.as_strided((out.shape[0], fill_rest + 1), (out.stride(0), 1), out.storage_offset())
+        flat[:, 1:] = fill_id
     for t in (out_b, out_c):
         if t is not None:
             t.copy_(ids)

@@ -99,6 +99,14 @@ def test_gemm_skinny(ops, mode, M, N, K):
     out = torch.empty((M, N), dtype=dtype, device="cuda")
     ops.gemm_skinny(a.cuda(), w.cuda(), out, mode=mode, res=None if r is None else r.cuda(), norm_eps=1e-6)
     cmp(out, want, dtype, k=max(1.0, K / 512), what=f"gemm_skinny rstd mode={mode} {M}x{N}x{K}")
+    # embedding lookup folded in: rows of A (and of the residual) picked from tables by id
+    g = torch.Generator().manual_seed(3)
+    table, rtable = rnd((50, K), dtype, 15), (None if mode == 1 else rnd((50, N), dtype, 16))
+    ids = torch.randint(0, 50, (M,), generator=g)
+    want = emu.gemm_skinny(table, w, torch.empty((M, N), dtype=dtype), mode=mode, res=rtable, norm_eps=1e-6, row_ids=ids, res_ids=ids)
+    ops.gemm_skinny(table.cuda(), w.cuda(), out, mode=mode, res=None if rtable is None else rtable.cuda(), norm_eps=1e-6,
+                    row_ids=ids.cuda(), res_ids=None if rtable is None else ids.cuda())
+    cmp(out, want, dtype, k=max(1.0, K / 512), what=f"gemm_skinny gathered rows mode={mode} {M}x{N}x{K}")
     with pytest.raises(RuntimeError):
         ops.gemm_skinny(torch.zeros((65, K), dtype=dtype, device="cuda"), w.cuda(), torch.zeros((65, N), dtype=dtype, device="cuda"), mode=mode)
 
@@ -442,10 +450,12 @@ def test_sample_top_p_k_fused(ops, dtype, top_p, top_k):
         ob, oc = torch.zeros((B,), dtype=torch.int64, device="cuda"), torch.zeros((B,), dtype=torch.int64, device="cuda")
         span, mr = ops.mask_spans(fm, lo_tab, hi_tab)
         ops.sample_top_p_k(logits.cuda(), fm.cuda(), lo_tab.cuda(), hi_tab.cuda(), ev.cuda(), pos, q.cuda(), buf[:, 3], V,
-                           0.9, top_p, top_k, out_b=ob, out_c=oc if pos == 0 else None, first_span=span, max_range=mr[pos])
+                           0.9, top_p, top_k, out_b=ob, out_c=oc if pos == 0 else None, first_span=span, max_range=mr[pos],
+                           fill_rest=2 if pos == 0 else 0, fill_id=99)
         assert (buf[:, 3].cpu() == want).all(), (pos, (buf[:, 3].cpu() != want).nonzero().flatten().tolist())
         assert torch.equal(ob, buf[:, 3]) and (pos != 0 or torch.equal(oc, buf[:, 3]))
-    assert (buf[:, :3] == -7).all() and (buf[:, 4:] == -7).all()
+        assert (buf[:, 4:6] == (99 if pos == 0 else -7)).all()
+    assert (buf[:, :3] == -7).all() and (buf[:, 6:] == -7).all()
 
 
 def test_collate_windows(ops):
