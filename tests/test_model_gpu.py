@@ -275,3 +275,23 @@ def test_bf16_gradients_track_fp32(orc, tok):
     cos = torch.nn.functional.cosine_similarity(gs[0][1], gs[1][1], dim=0).item()
     print(f"fp32 vs bf16 gradient cosine {cos:.5f}")
     assert cos > 0.98
+
+
+def test_device_corpus_feeds_training_step(tiny, tok):
+    """the step before the path (data.TokenCorpus / WindowSampler, one-kernel batch assembly on the device) feeding the
+    training step: ragged pieces -> padded (B, L, 8) int64 batch -> finite loss, pad targets ignored"""
+    from midi_model_amd.data import TokenCorpus, WindowSampler, synthetic_events
+    from midi_model_amd.train import TrainMIDIModel
+    shp, sd, _ = tiny
+    pieces = [synthetic_events(tok, 1, n, seed=200 + i)[0].numpy().astype(np.int16) for i, n in enumerate([40, 17, 64, 33])]
+    corpus = TokenCorpus(pieces, device="cuda")
+    sampler = WindowSampler(corpus, max_len=32, rand_start=True, seed=1)
+    batch = sampler.batch([0, 1, 2, 3], pad_id=tok.pad_id)
+    assert batch.is_cuda and batch.dtype == torch.int64 and batch.shape == (4, 32, 8)
+    assert (batch[1, 17:] == tok.pad_id).all() and (batch[1, :17].cpu() == torch.from_numpy(pieces[1].astype(np.int64))).all()
+    model = build(TrainMIDIModel, tiny_config(), sd, accumulate_grad_batches=1)
+    loss = model.training_step(batch)
+    assert torch.isfinite(loss).all()
+    short = model.training_step(batch[1:2, :17])  # the unpadded piece alone
+    both = model.training_step(torch.cat([batch[1:2], batch[1:2]], 0))  # the same piece twice, padded rows ignored
+    assert abs(float(short) - float(both)) < 1e-4 * abs(float(short)) + 1e-5
