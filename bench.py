@@ -65,7 +65,7 @@ def cpu_baseline(sample_S: int, seed: int = 0):
     dt = time.perf_counter() - t0
     return {"value": sample_S / dt, "unit": "events/s", "cores": cores, "kind": "port",
             "sample": f"1 training step (fwd+bwd+clip+AdamW) of the CPU oracle, fp32, batch 1 x {sample_S} events, {dt:.1f} s",
-            "loss": float(loss)}
+            "loss": float(loss.detach())}
 
 
 def decode_bytes_per_event(B: int, n_cached: float, token_steps: float, L=12, D=1024, I=4096, Lt=3, It=1024, V=3406) -> float:
@@ -158,7 +158,8 @@ def main():
     ap.add_argument("--seq", type=int, default=2048, help="events per sequence seen by the model")
     ap.add_argument("--config", default="tv2o-medium")
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
-    ap.add_argument("--cpu-sample-seq", type=int, default=512)
+    ap.add_argument("--cpu-sample-seq", type=int, default=2048,
+                    help="events in the CPU baseline sample (one sequence of the workload: ~10-20 s of host time)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-gemm-events", action="store_true")
     ap.add_argument("--mode", default="train", choices=["train", "generate"],
