@@ -68,6 +68,28 @@ def cpu_baseline(sample_S: int, seed: int = 0):
             "loss": float(loss.detach())}
 
 
+def cpu_baseline_generate(batch: int, n_events: int, seed: int = 0):
+    """The oracle's KV-cached generate() (fp32, host cores): `batch` sequences x `n_events` new events, EOS masked."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("midi_oracle", os.path.join(ROOT, "oracle", "midi_oracle.py"))
+    orc = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(orc)
+    import midi_model_amd as mm
+    cores = min(os.cpu_count() or 1, 32)
+    torch.set_num_threads(cores)
+    tok = mm.MIDITokenizerV2()
+    shp = orc.Shape(vocab=tok.vocab_size)
+    with torch.no_grad():
+        sd = orc.make_state_dict(shp, seed=seed)
+        t0 = time.perf_counter()
+        out = orc.generate(sd, shp, tok, None, batch_size=batch, max_len=1 + n_events, generator=torch.Generator().manual_seed(seed),
+                           ban_eos=True)
+        dt = time.perf_counter() - t0
+    assert out.shape[1] == 1 + n_events
+    return {"value": batch * n_events / dt, "unit": "events/s", "cores": cores, "kind": "port",
+            "sample": f"CPU oracle generate(), fp32, batch {batch} x {n_events} new events, {dt:.1f} s"}
+
+
 def decode_bytes_per_event(B: int, n_cached: float, token_steps: float, L=12, D=1024, I=4096, Lt=3, It=1024, V=3406) -> float:
     """SURVEY.md 8(d) algorithmic bytes of one generated event at batch B with n cached events, bf16: the net's
     non-embedding weights once, its K/V cache once, and net_token + lm_head weights once per token step."""
@@ -144,6 +166,12 @@ def bench_generate(args):
                          "achieved": by / per_event_s / 1e9, "peak": 8000.0, "unit": "GB/s",
                          "frac": by / per_event_s / 8.0e12, "traffic": None, "algorithmic_bytes_per_event_step": by},
         }
+        if world == 1 and not args.no_cpu_baseline:
+            try:
+                out_d["cpu_baseline"] = cpu_baseline_generate(B, 32)  # B=64 for 32 events
+            except Exception as e:  # the baseline is a report, never a reason to lose the GPU number
+                out_d["cpu_baseline"] = {"value": None, "unit": "events/s", "cores": os.cpu_count(), "kind": "port",
+                                         "sample": f"failed: {e!r}"}
         print(json.dumps(out_d))
     if world > 1:
         dist.destroy_process_group()
