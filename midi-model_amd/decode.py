@@ -18,12 +18,18 @@ is keyed by (parameter buffer, batch, capacity, temperature, top_p, top_k); ``MI
 from __future__ import annotations
 
 import os
+import threading
 from typing import List, Optional
 
 import torch
 
 from . import engine, ops
 from .engine import KVState, RopeTable
+
+
+# One capture at a time per process, and in thread-local error mode: generators of other threads (app.py runs up to 10 on
+# one model) keep launching and allocating while a new session is being captured.
+_CAPTURE_LOCK = threading.Lock()
 
 
 def graphs_enabled(device: torch.device) -> bool:
@@ -137,6 +143,10 @@ class DecodeSession:
         self.samples_in.copy_(self.seq[:, i])
 
     def _capture(self):
+        with _CAPTURE_LOCK:
+            self._capture_locked()
+
+    def _capture_locked(self):
         # one eager pass on a side stream first: lazy initialisation (kernel attributes, allocator pools) must not
         # happen inside a capture
         cur = torch.cuda.current_stream()
@@ -150,12 +160,12 @@ class DecodeSession:
         torch.cuda.synchronize()
         pool = torch.cuda.graph_pool_handle()
         self.g_net = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.g_net, pool=pool):
+        with torch.cuda.graph(self.g_net, pool=pool, capture_error_mode="thread_local"):
             self._net_body()
         for i in range(self.T):
             g = torch.cuda.CUDAGraph()
             g.register_generator_state(self.gen)  # philox seed/offset are read at replay time, offsets advance per replay
-            with torch.cuda.graph(g, pool=pool):
+            with torch.cuda.graph(g, pool=pool, capture_error_mode="thread_local"):
                 self._tok_body(i, self.gen)
             self.g_tok[i] = g
         self.reset()

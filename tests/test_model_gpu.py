@@ -295,3 +295,31 @@ def test_device_corpus_feeds_training_step(tiny, tok):
     short = model.training_step(batch[1:2, :17])  # the unpadded piece alone
     both = model.training_step(torch.cat([batch[1:2], batch[1:2]], 0))  # the same piece twice, padded rows ignored
     assert abs(float(short) - float(both)) < 1e-4 * abs(float(short)) + 1e-5
+
+
+def test_concurrent_generators_on_one_model(tiny, tok):
+    """app.py runs up to 10 generators on one model (app.py:496): two threads on their own streams, each creating (and
+    capturing) its own decode session at the same time, must both produce the stream a lone call produces"""
+    import threading
+    shp, sd, _ = tiny
+    model = build(mm.MIDIModel, tiny_config(), sd, dtype=torch.bfloat16)
+    want = [model.generate(None, batch_size=2 + i, max_len=12, ban_eos=True,
+                           generator=torch.Generator(device="cuda").manual_seed(40 + i)) for i in range(2)]
+    model._sessions.idle.clear()  # force both threads to build and capture new sessions
+    got, errs = [None, None], []
+
+    def work(i):
+        try:
+            with torch.cuda.stream(torch.cuda.Stream()):
+                got[i] = model.generate(None, batch_size=2 + i, max_len=12, ban_eos=True,
+                                        generator=torch.Generator(device="cuda").manual_seed(40 + i))
+                torch.cuda.current_stream().synchronize()
+        except Exception as e:  # noqa: BLE001
+            errs.append(e)
+
+    ths = [threading.Thread(target=work, args=(i,)) for i in range(2)]
+    [t.start() for t in ths]
+    [t.join() for t in ths]
+    assert not errs, errs
+    for i in range(2):
+        assert (got[i] == want[i]).all()
