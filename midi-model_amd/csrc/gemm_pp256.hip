@@ -114,7 +114,8 @@ __global__ __launch_bounds__(512, 2) void gemm_pp256_kernel(const bf16* __restri
                                                             int64_t k_per_split, float* __restrict__ ws) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   // ABL != 0 builds are micro-benchmarks with wrong results (tools/bench_gemm.py): 1 = no LDS-DMA after the pipeline
-  // fill, 2 = no fragment reads, 4 = no MFMA, 8 = row-major pieces fetch whole 128-byte lines (8 rows x 128 B)
+  // fill, 2 = no fragment reads, 4 = no MFMA, 8 = row-major pieces fetch whole 128-byte lines (8 rows x 128 B),
+  // 32 = no output stores
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int grp = wave >> 2;      // M half (and ping-pong group: waves w, w+4 share a SIMD)
@@ -235,6 +236,78 @@ __global__ __launch_bounds__(512, 2) void gemm_pp256_kernel(const bf16* __restri
   // epilogue: lane (fi, fg) of fragment (fn, fm) holds C[m][n..n+3], m = m0 + grp*128 + fm*16 + fi
   const bool partial = (gridDim.z > 1);
   float* wsz = partial ? ws + (int64_t)zslice * M * N : nullptr;
+  if constexpr ((ABL & 32) != 0) {  // micro-benchmark: no output
+    if (acc[0][0][0] != 1.2345e38f) return;
+  }
+  // Whole-line stores: the wave turns its 128 x 64 fp32 tile through its own 16 KiB of the (now idle) stage ring, 64 rows
+  // at a time, so that 8 lanes write one 128-byte line of C (and read one of R) instead of 16 rows x 32 bytes per
+  // instruction: the [32768 x 3072 x 1024] projection went from 222 to 194 us (profiles/r01_run15, r01_run16; with no
+  // stores at all it takes 168).  Row r of the half lives at r * 256 B, 16-byte chunk c at slot c ^ (r & 15): fragment
+  // writes (16 rows x 4 chunks) and row reads (8 rows x 16 chunks) are bank-conflict free.  LDS operations of one wave
+  // execute in order, so no barrier is needed.  C is not read again by this kernel: its stores are marked non-temporal
+  // (1-2 % on the K = 1024 shapes).  Split-K partials keep the direct fragment stores below (16 rows x 64 B per instruction
+  // is already half lines; turning them through LDS measured 5 % slower inside the training step).
+  // Rounding the tile to bf16 before the turn (half the LDS traffic when there is no residual) measured no faster.
+  const bool use_r = (R != nullptr && beta != 0.f);
+  const bool line_ok = !partial && (ldc & 7) == 0 && ((uintptr_t)C & 15) == 0 &&
+                       (!use_r || ((ldr & 7) == 0 && ((uintptr_t)R & 15) == 0));
+  if (line_ok) {
+    char* wreg = smem + wave * 16384;
+    const int lrow = lane >> 3, c = lane & 7;
+    const int64_t n = n0 + wn * 64 + c * 8;
+    const bool n_full = (n + 8 <= N);
+    // the residual lines of the whole tile are requested before the first turn
+    bf16x8 rv[2][8];
+    if (use_r) {
+#pragma unroll
+      for (int half = 0; half < 2; ++half)
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          const int64_t m = m0 + grp * 128 + half * 64 + i * 8 + lrow;
+          if (m < M && n_full) rv[half][i] = *reinterpret_cast<const bf16x8*>(R + m * ldr + n);
+        }
+    }
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+#pragma unroll
+      for (int fmh = 0; fmh < 4; ++fmh)
+#pragma unroll
+        for (int fn = 0; fn < 4; ++fn) {
+          const int row = fmh * 16 + fi, ch = fn * 4 + fg;
+          *reinterpret_cast<f32x4*>(wreg + row * 256 + ((ch ^ (row & 15)) << 4)) = acc[fn][half * 4 + fmh];
+        }
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {  // 8 rows x 128 B per instruction
+        const int row = i * 8 + lrow;
+        const f32x4 lo = *reinterpret_cast<const f32x4*>(wreg + row * 256 + (((2 * c) ^ (row & 15)) << 4));
+        const f32x4 hi = *reinterpret_cast<const f32x4*>(wreg + row * 256 + (((2 * c + 1) ^ (row & 15)) << 4));
+        const int64_t m = m0 + grp * 128 + half * 64 + row;
+        if (m >= M || n >= N) continue;
+        float v[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+        if (!n_full) {  // ragged last chunk of a row (N = 3406 logits)
+          for (int e = 0; n + e < N; ++e) {
+            float x = alpha * v[e];
+            if (use_r) x += beta * (float)R[m * ldr + n + e];
+            C[m * ldc + n + e] = (bf16)x;
+          }
+          continue;
+        }
+        if (use_r) {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) v[e] = alpha * v[e] + beta * (float)rv[half][i][e];
+        } else {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) v[e] = alpha * v[e];
+        }
+        bf16x8 o;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o[e] = (bf16)v[e];
+        __builtin_nontemporal_store(o, reinterpret_cast<bf16x8*>(C + m * ldc + n));
+      }
+    }
+    return;
+  }
+  // split-K partials and unaligned outputs: straight from the fragments
   const bool vec_ok = partial ? ((N & 3) == 0)
                               : ((ldc & 3) == 0 && ((uintptr_t)C & 15) == 0 &&
                                  (R == nullptr || ((ldr & 3) == 0 && ((uintptr_t)R & 15) == 0)));
@@ -319,7 +392,7 @@ int mh_gemm_pp256_bf16(const void* A, int64_t lda, int ta, const void* B, int64_
   case X_:        \
     if (ta) MH_PP(true, true, X_); \
     MH_PP(false, false, X_);
-    switch (g_mh_gemm_ablate) { MH_AB(1) MH_AB(3) MH_AB(4) MH_AB(5) MH_AB(8) MH_AB(12) default: break; }
+    switch (g_mh_gemm_ablate) { MH_AB(1) MH_AB(3) MH_AB(4) MH_AB(5) MH_AB(8) MH_AB(12) MH_AB(32) default: break; }
 #undef MH_AB
   }
   if (ta && tb) MH_PP(true, true, 0);
