@@ -89,9 +89,9 @@ int mh_embed_scatter_bwd(const int64_t* tok, int64_t ldtok, int T, const void* d
                          int j0, float* dtable_f32, int64_t M, int64_t V, int D, int64_t pad_id, int dtype,
                          void* stream);
 /* Segment form (production): occurrences pre-sorted by token id.  dtable_f32[v,:] += sum_{i in [seg_start[v],
- * seg_start[v+1])} dout[src_rows[i]*ld ...]; id `pad_id` is skipped.  `nsplit` blocks share one id's list.   */
+ * seg_start[v+1])} dout[src_rows[i]*ld ...]; id `pad_id` is skipped.  n_occ = seg_start[V] = length of src_rows. */
 int mh_embed_segment_bwd(const int64_t* src_rows, const int64_t* seg_start, const void* dout, int64_t ld,
-                         float* dtable_f32, int64_t V, int D, int nsplit, int64_t pad_id, int dtype, void* stream);
+                         float* dtable_f32, int64_t V, int D, int64_t n_occ, int64_t pad_id, int dtype, void* stream);
 /* dst[i] (dtype) = (accumulate ? dst[i] : 0) + src_f32[i] */
 int mh_cast_from_f32(const float* src, void* dst, int64_t n, int accumulate, int dtype, void* stream);
 /* strided row copy: dst[m,:] = src[m*src_ld ...] (+ optional accumulate) — takes d(hidden) out of d(token seq). */

@@ -115,70 +115,115 @@ extern "C" int mh_embed_scatter_bwd(const int64_t* tok, int64_t ldtok, int T_, c
 }
 
 // Segment form of the same gradient (the production path): the token occurrences are pre-sorted by token id
-// (src[i] = row of `dout` that occurrence i reads, seg[v]..seg[v+1] = the occurrences of id v), so a block owns
-// one id (and one of `nsplit` slices of its occurrences), sums its rows in registers with coalesced 16-byte
-// loads and touches the fp32 table once — at most nsplit atomics per element instead of one per occurrence
-// (the scatter form serialises ~29k atomics on the row of the ubiquitous "note" id).
-template <typename T>
+// (src[i] = row of `dout` that occurrence i reads, seg[v]..seg[v+1] = the occurrences of id v).  The sorted list is cut
+// into equal pieces of 32 occurrences per wave, whatever ids they belong to: a wave looks up its 32 (row, id) pairs with
+// one coalesced load and a binary search in `seg`, then streams the rows four at a time with 16-byte loads, summing in
+// registers while the id stays the same and adding the run to the fp32 table when it changes (one atomic per element per
+// run; the scatter form needs one per occurrence and serialises ~29k of them on the row of the ubiquitous "note" id).
+// Equal pieces matter: with one block per id the 29.5k rows of "note" were a serial chain of dependent index -> row
+// loads and the launch took 1.05 ms for 0.5 GB (profiles/r01_run9), ten times the HBM time.
+// Roofline: HBM; algorithmic bytes = n_occ * D * sizeof(T) (every occurrence's row once).
+template <typename T, int NCH>
 __global__ __launch_bounds__(256) void embed_segment_bwd_kernel(const int64_t* __restrict__ src, const int64_t* __restrict__ seg,
                                                                 const T* __restrict__ dout, int64_t ld,
-                                                                float* __restrict__ dtab, int D, int64_t pad_id) {
+                                                                float* __restrict__ dtab, int V, int D, int64_t n_occ,
+                                                                int pad_id) {
   constexpr int N = Pack<T>::N;
-  constexpr int MAXCH = 8;
-  __shared__ float red[4][64 * N];
-  const int64_t v = blockIdx.x;
-  if (v == pad_id) return;
-  const int64_t a0 = seg[v], a1 = seg[v + 1];
-  const int64_t cnt = a1 - a0;
-  if (cnt <= 0) return;
-  const int64_t per = (cnt + gridDim.y - 1) / gridDim.y;
-  const int64_t b0 = a0 + (int64_t)blockIdx.y * per;
-  int64_t b1 = b0 + per;
-  if (b1 > a1) b1 = a1;
-  if (b0 >= b1) return;
+  constexpr int RW = 32, G = 4;  // occurrences per wave, rows in flight
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-  const int nch = (D + 64 * N - 1) / (64 * N);
-  float acc[MAXCH][N];
+  const int64_t p0 = ((int64_t)blockIdx.x * 4 + wv) * RW;
+  if (p0 >= n_occ) return;
+  const int cnt = (n_occ - p0 < RW) ? (int)(n_occ - p0) : RW;
+  int row_lo = 0, row_hi = 0, my_id = -1;
+  if (lane < cnt) {
+    const int64_t p = p0 + lane;
+    const int64_t r = src[p];
+    row_lo = (int)(uint32_t)r;
+    row_hi = (int)(r >> 32);
+    int lo = 0, hi = V;  // seg[lo] <= p < seg[hi]: the largest v with seg[v] <= p owns occurrence p
+    while (hi - lo > 1) {
+      const int mid = (lo + hi) >> 1;
+      if (seg[mid] <= p) lo = mid; else hi = mid;
+    }
+    my_id = lo;
+  }
+  float acc[NCH][N];
 #pragma unroll
-  for (int ch = 0; ch < MAXCH; ++ch)
+  for (int ch = 0; ch < NCH; ++ch)
 #pragma unroll
     for (int e = 0; e < N; ++e) acc[ch][e] = 0.f;
-  for (int64_t i = b0 + wv; i < b1; i += 4) {
-    const T* row = dout + src[i] * ld;
+  int cur = -1;
+  auto flush = [&]() {
+    float* dst = dtab + (int64_t)cur * D;
 #pragma unroll
-    for (int ch = 0; ch < MAXCH; ++ch) {
+    for (int ch = 0; ch < NCH; ++ch) {
       const int c = (ch * 64 + lane) * N;
-      if (ch < nch && c < D) {
-        Pack<T> p = ld16(row + c);
-#pragma unroll
-        for (int e = 0; e < N; ++e) acc[ch][e] += p.get(e);
-      }
-    }
-  }
-  float* dst = dtab + v * D;
-  for (int ch = 0; ch < nch; ++ch) {
-    __syncthreads();
-#pragma unroll
-    for (int e = 0; e < N; ++e) red[wv][lane * N + e] = acc[ch][e];
-    __syncthreads();
-    for (int t = threadIdx.x; t < 64 * N; t += 256) {
-      const int c = ch * 64 * N + t;
       if (c < D) {
-        const float s = red[0][t] + red[1][t] + red[2][t] + red[3][t];
-        if (gridDim.y > 1) atomicAdd(dst + c, s); else dst[c] += s;
+#pragma unroll
+        for (int e = 0; e < N; ++e) {
+          atomicAdd(dst + c + e, acc[ch][e]);
+          acc[ch][e] = 0.f;
+        }
+      }
+    }
+  };
+#pragma unroll
+  for (int j0 = 0; j0 < RW; j0 += G) {
+    if (j0 < cnt) {  // (wave-uniform)
+      Pack<T> buf[G][NCH];
+      int idj[G];
+#pragma unroll
+      for (int g = 0; g < G; ++g) {
+        idj[g] = __builtin_amdgcn_readlane(my_id, j0 + g);  // -1 past the end of the list
+        const int64_t row = ((int64_t)__builtin_amdgcn_readlane(row_hi, j0 + g) << 32) |
+                            (uint32_t)__builtin_amdgcn_readlane(row_lo, j0 + g);
+        if (idj[g] >= 0 && idj[g] != pad_id) {
+#pragma unroll
+          for (int ch = 0; ch < NCH; ++ch) {
+            const int c = (ch * 64 + lane) * N;
+            if (c < D) buf[g][ch] = ld16(dout + row * ld + c);
+          }
+        }
+      }
+#pragma unroll
+      for (int g = 0; g < G; ++g) {
+        if (idj[g] < 0 || idj[g] == pad_id) continue;
+        if (idj[g] != cur) {
+          if (cur >= 0) flush();
+          cur = idj[g];
+        }
+#pragma unroll
+        for (int ch = 0; ch < NCH; ++ch) {
+          const int c = (ch * 64 + lane) * N;
+          if (c < D) {
+#pragma unroll
+            for (int e = 0; e < N; ++e) acc[ch][e] += buf[g][ch].get(e);
+          }
+        }
       }
     }
   }
+  if (cur >= 0) flush();
 }
 
 extern "C" int mh_embed_segment_bwd(const int64_t* src_rows, const int64_t* seg_start, const void* dout, int64_t ld,
-                                    float* dtable_f32, int64_t V, int D, int nsplit, int64_t pad_id, int dtype,
+                                    float* dtable_f32, int64_t V, int D, int64_t n_occ, int64_t pad_id, int dtype,
                                     void* stream) {
-  MH_REQUIRE(V > 0 && V < (1 << 30) && D % 8 == 0 && D <= 4096 && nsplit >= 1 && nsplit <= 65535, "embed_segment_bwd: bad args");
+  MH_REQUIRE(V > 0 && V < (1 << 30) && D % 8 == 0 && D <= 4096 && n_occ >= 0, "embed_segment_bwd: bad args");
   MH_REQUIRE(dtype != MH_F32 || D <= 2048, "embed_segment_bwd: fp32 supports D <= 2048");
-  dim3 grid((unsigned)V, (unsigned)nsplit);
-  DISPATCH_T(dtype, (embed_segment_bwd_kernel<T><<<grid, 256, 0, (hipStream_t)stream>>>(src_rows, seg_start, (const T*)dout, ld,
-                                                                                        dtable_f32, D, pad_id)));
+  if (n_occ == 0) return MH_OK;
+  const int64_t nblk = (n_occ + 127) / 128;
+  MH_REQUIRE(nblk < (1ll << 31), "embed_segment_bwd: too many occurrences");
+  const int per = 64 * (dtype == MH_F32 ? 4 : 8);
+  const int nch = (D + per - 1) / per;
+#define MH_SEG(NCH_)                                                                                                      \
+  DISPATCH_T(dtype, (embed_segment_bwd_kernel<T, NCH_><<<(unsigned)nblk, 256, 0, (hipStream_t)stream>>>(                   \
+                        src_rows, seg_start, (const T*)dout, ld, dtable_f32, (int)V, D, n_occ, (int)pad_id)))
+  if (nch <= 1) MH_SEG(1);
+  else if (nch <= 2) MH_SEG(2);
+  else if (nch <= 4) MH_SEG(4);
+  else MH_SEG(8);
+#undef MH_SEG
   MH_LAUNCH_CHECK();
   return MH_OK;
 }

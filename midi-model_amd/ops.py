@@ -207,11 +207,11 @@ def token_segments(tok_flat: torch.Tensor, V: int):
 
 
 def embed_segment_bwd(src_rows: torch.Tensor, seg_start: torch.Tensor, dout: torch.Tensor, ld: int,
-                      dtable_f32: torch.Tensor, pad_id: int, nsplit: int = 16) -> None:
+                      dtable_f32: torch.Tensor, pad_id: int) -> None:
     V, D = dtable_f32.shape
     assert src_rows.dtype == torch.int64 and seg_start.dtype == torch.int64 and seg_start.numel() == V + 1
     assert src_rows.is_contiguous() and dtable_f32.dtype == torch.float32
-    lib().call("mh_embed_segment_bwd", _p(src_rows), _p(seg_start), _p(dout), ld, _p(dtable_f32), V, D, nsplit, pad_id,
+    lib().call("mh_embed_segment_bwd", _p(src_rows), _p(seg_start), _p(dout), ld, _p(dtable_f32), V, D, src_rows.numel(), pad_id,
                dt(dout), _stream())
 
 

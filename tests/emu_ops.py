@@ -107,7 +107,7 @@ def token_segments(tok_flat, V):
     return order, seg.contiguous()
 
 
-def embed_segment_bwd(src_rows, seg_start, dout, ld, dtable_f32, pad_id, nsplit=16):
+def embed_segment_bwd(src_rows, seg_start, dout, ld, dtable_f32, pad_id):
     V, D = dtable_f32.shape
     rows = torch.as_strided(dout, (int(src_rows.max()) + 1 if src_rows.numel() else 0, D), (ld, 1), dout.storage_offset()).float()
     ids = torch.repeat_interleave(torch.arange(V), seg_start[1:] - seg_start[:-1])

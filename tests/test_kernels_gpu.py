@@ -142,8 +142,9 @@ def test_transpose(ops, dtype, R, C):
 
 # ------------------------------------------------------------------------------------------ embeddings
 @pytest.mark.parametrize("dtype", DTYPES)
-def test_embeddings(ops, dtype):
-    V, D, M, T = 3406, 256, 77, 8
+@pytest.mark.parametrize("D,M", [(256, 77), (1024, 700), (2048, 150)])
+def test_embeddings(ops, dtype, D, M):
+    V, T = 3406, 8
     g = torch.Generator().manual_seed(7)
     table = rnd((V, D), dtype, 8)
     tok = torch.randint(0, V, (M, T), generator=g)
@@ -167,17 +168,20 @@ def test_embeddings(ops, dtype):
     ops.embed_scatter_bwd(tok[:, :7].cuda(), 7, d2.cuda(), T, 1, 1, acc, 0)
     emu.embed_scatter_bwd(tok[:, :7], 7, d2, T, 1, 1, ref, 0)
     cmp(acc, ref, torch.float32, k=10, what="scatter (token)")
-    # segment form (sorted occurrences) == scatter form, incl. a heavily repeated id and nsplit > 1
+    # segment form (sorted occurrences) == scatter form, incl. a heavily repeated id; also on a ragged prefix of the rows
     hot = tok[:, :7].clone()
     hot[: M // 2, 0] = 3
-    order, seg = ops.token_segments(hot.reshape(-1).cuda(), V)
-    src = (order // 7) * T + order % 7 + 1
-    for ns in (1, 16):
+    for rows in (M, max(1, M - 3)):
+        order, seg = ops.token_segments(hot[:rows].reshape(-1).cuda(), V)
+        src = (order // 7) * T + order % 7 + 1
         acc.zero_(); ref.zero_()
-        ops.embed_segment_bwd(src.contiguous(), seg, d2.cuda(), D, acc, 0, nsplit=ns)
-        emu.embed_scatter_bwd(hot, 7, d2, T, 1, 1, ref, 0)
-        cmp(acc, ref, torch.float32, k=20, what=f"segment bwd nsplit={ns}")
+        ops.embed_segment_bwd(src.contiguous(), seg, d2.cuda(), D, acc, 0)
+        emu.embed_scatter_bwd(hot[:rows], 7, d2[:rows], T, 1, 1, ref, 0)
+        cmp(acc, ref, torch.float32, k=20, what=f"segment bwd rows={rows}")
         assert acc[0].abs().max() == 0
+        ref2 = torch.zeros((V, D))
+        emu.embed_segment_bwd(src.cpu(), seg.cpu(), d2, D, ref2, 0)
+        cmp(ref2, ref, torch.float32, k=20, what="segment bwd (emu)")
     acc.zero_(); ref.zero_()
     ops.embed_scatter_bwd(tok[:, :7].cuda(), 7, d2.cuda(), T, 1, 1, acc, 0)
     emu.embed_scatter_bwd(tok[:, :7], 7, d2, T, 1, 1, ref, 0)
