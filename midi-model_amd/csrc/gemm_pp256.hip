@@ -23,7 +23,9 @@
 
 namespace {
 
-__device__ __attribute__((aligned(16))) char g_zero16[16];  // source of out-of-range chunks
+// source of out-of-range chunks; reaches the kernel as an argument (taking the symbol's address inside the K loop cost a
+// scalar load and an lgkmcnt(0) wait -- for every outstanding fragment read as well -- in front of each step's LDS-DMA)
+__device__ __attribute__((aligned(16))) char g_zero16[16];
 
 constexpr int QBM = 256, QBN = 256, QBK = 32;
 constexpr int OP_BYTES = 256 * 64;             // one operand's K-step: 256 rows x 64 B (or 32 k-rows x 512 B)
@@ -56,14 +58,6 @@ __device__ inline void stage_init_n(StageCtx& c, const bf16* __restrict__ base, 
     c.klim[it] = (grow < nrows) ? (int)kend - ch * 8 : INT_MIN;
   }
 }
-__device__ inline void stage_n(const StageCtx& c, int k0, char* tile, int wave) {
-#pragma unroll
-  for (int it = 0; it < NI; ++it) {
-    const void* src = (k0 < c.klim[it]) ? (const void*)(c.p[it] + k0) : (const void*)g_zero16;
-    glds16(src, tile + (wave + NWAVE * it) * 1024);
-  }
-}
-
 // contraction-major operand X[k][r]: K-step tile 32 k-rows x 512 B; one LDS-DMA instruction = 2 k-rows
 __device__ inline void stage_init_t(StageCtx& c, const bf16* __restrict__ base, int64_t ld, int64_t r0, int64_t nrows,
                                     int64_t kend, int wave, int lane) {
@@ -77,15 +71,6 @@ __device__ inline void stage_init_t(StageCtx& c, const bf16* __restrict__ base, 
     c.klim[it] = (r < nrows) ? (int)kend - krow : INT_MIN;
   }
 }
-__device__ inline void stage_t(const StageCtx& c, int k0, int64_t ld, char* tile, int wave) {
-  const int64_t koff = (int64_t)k0 * ld;
-#pragma unroll
-  for (int it = 0; it < NI; ++it) {
-    const void* src = (k0 < c.klim[it]) ? (const void*)(c.p[it] + koff) : (const void*)g_zero16;
-    glds16(src, tile + (wave + NWAVE * it) * 1024);
-  }
-}
-
 template <bool TR>
 __device__ inline bf16x8 frag(const char* tile, int row0, int fi, int fg) {
   if constexpr (!TR) {
@@ -111,7 +96,8 @@ __global__ __launch_bounds__(512, 2) void gemm_pp256_kernel(const bf16* __restri
                                                             const bf16* __restrict__ B, int64_t ldb, bf16* C, int64_t ldc,
                                                             const bf16* R, int64_t ldr, int64_t M, int64_t N, int64_t K,
                                                             float alpha, float beta, int tiles_n, int nwg,
-                                                            int64_t k_per_split, float* __restrict__ ws) {
+                                                            int64_t k_per_split, float* __restrict__ ws,
+                                                            const void* __restrict__ zero16) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   // ABL != 0 builds are micro-benchmarks with wrong results (tools/bench_gemm.py): 1 = no LDS-DMA after the pipeline
   // fill, 2 = no fragment reads, 4 = no MFMA, 8 = row-major pieces fetch whole 128-byte lines (8 rows x 128 B),
@@ -159,7 +145,7 @@ __global__ __launch_bounds__(512, 2) void gemm_pp256_kernel(const bf16* __restri
     const bool tr = (j >> 1) ? TB : TA;
     const int64_t ld = (j >> 1) ? ldb : lda;
     const bf16* p = c.p[j & 1] + (tr ? (int64_t)k0 * ld : (int64_t)k0);
-    const void* src = (k0 < c.klim[j & 1]) ? (const void*)p : (const void*)g_zero16;
+    const void* src = (k0 < c.klim[j & 1]) ? (const void*)p : zero16;
     glds16(src, buf);
   };
   // every wave issues exactly 4 LDS-DMA instructions per K-step; three steps stay in flight
@@ -204,6 +190,8 @@ __global__ __launch_bounds__(512, 2) void gemm_pp256_kernel(const bf16* __restri
     else if (t + 1 < nt) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   };
+  // (order inside the segment: issuing the LDS-DMA before the fragment reads is neutral on row-major operands and 40 %
+  // slower on contraction-major ones; waiting for the fragments before issuing it costs 1-2 %; profiles/r01_run18)
   auto load_segment = [&](int t) {
     load_frags(t);
     if (t + 3 < nt && !(ABL & 1)) {
@@ -357,6 +345,11 @@ template <bool TA, bool TB, int ABL>
 int launch_one(const void* A, int64_t lda, const void* B, int64_t ldb, void* C, int64_t ldc, const void* R, int64_t ldr,
                int64_t M, int64_t N, int64_t K, float alpha, float beta, int splitk, void* workspace, hipStream_t st) {
   static bool attr_set = false;
+  static void* zero16 = nullptr;  // 16 zero bytes in device memory: the source of out-of-range LDS-DMA chunks
+  if (zero16 == nullptr && hipGetSymbolAddress(&zero16, HIP_SYMBOL(g_zero16)) != hipSuccess) {
+    mh_set_error("gemm_pp256: hipGetSymbolAddress(g_zero16) failed");
+    return MH_ERR_LAUNCH;
+  }
   if (!attr_set) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_pp256_kernel<TA, TB, ABL>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
@@ -372,7 +365,7 @@ int launch_one(const void* A, int64_t lda, const void* B, int64_t ldb, void* C, 
   dim3 grid(nwg, 1, splitk);
   gemm_pp256_kernel<TA, TB, ABL><<<grid, 512, LDS_BYTES, st>>>((const bf16*)A, lda, (const bf16*)B, ldb, (bf16*)C, ldc,
                                                           (const bf16*)R, ldr, M, N, K, alpha, beta, (int)tiles_n, nwg, kps,
-                                                          (float*)workspace);
+                                                          (float*)workspace, zero16);
   MH_LAUNCH_CHECK();
   return MH_OK;
 }
