@@ -55,6 +55,13 @@ int mh_gemm_nt(const void* A, int64_t lda, const void* B, int64_t ldb, void* C, 
 int mh_gemm(const void* A, int64_t lda, int transA, const void* B, int64_t ldb, int transB, void* C, int64_t ldc,
             const void* R, int64_t ldr, int64_t M, int64_t N, int64_t K, float alpha, float beta, int dtype, int splitk,
             void* workspace, void* stream);
+/* down_proj dgrad with the SwiGLU backward as its epilogue (LlamaMLP backward, modeling_llama.py:174-176):
+ *   d a = A[M,K] * B[K,I] (B contraction-major, as mh_gemm with transB), rounded to the activation dtype, then
+ *   DGU[:, :I] = d a * up * silu'(gate),  DGU[:, I:] = d a * silu(gate)     with GU = gate|up of the forward [M, 2I].
+ * Same results as mh_gemm followed by mh_swiglu_bwd, without d a's round trip through HBM and the extra read of GU's
+ * neighbourhood.  bf16, production GEMM kernel only (option "gemm" != 0), I % 8 == 0; fails loudly otherwise.   */
+int mh_gemm_dswiglu(const void* A, int64_t lda, const void* B, int64_t ldb, const void* GU, int64_t ldgu, void* DGU,
+                    int64_t lddgu, int64_t M, int64_t I, int64_t K, int dtype, void* stream);
 int mh_gemm_splitk_reduce(const void* workspace, void* C, int64_t ldc, const void* R, int64_t ldr, int64_t M,
                           int64_t N, int splitk, float alpha, float beta, int dtype, void* stream);
 /* Skinny projection of the decode step (replaces the per-token nn.Linear calls of LlamaAttention / LlamaMLP /

@@ -327,6 +327,21 @@ extern "C" int mh_gemm(const void* A, int64_t lda, int transA, const void* B, in
   return MH_ERR_ARG;
 }
 
+int mh_gemm_pp256_dswiglu_bf16(const void* A, int64_t lda, const void* B, int64_t ldb, const void* GU, int64_t ldgu,
+                               void* DGU, int64_t lddgu, int64_t M, int64_t I, int64_t K, hipStream_t st);  // gemm_pp256.hip
+
+extern "C" int mh_gemm_dswiglu(const void* A, int64_t lda, const void* B, int64_t ldb, const void* GU, int64_t ldgu,
+                               void* DGU, int64_t lddgu, int64_t M, int64_t I, int64_t K, int dtype, void* stream) {
+  MH_REQUIRE(dtype == MH_BF16 && g_mh_gemm_variant != 0,
+             "gemm_dswiglu: served by the production bf16 kernel only (use mh_gemm + mh_swiglu_bwd otherwise)");
+  MH_REQUIRE(M > 0 && I > 0 && K > 0 && I % 8 == 0, "gemm_dswiglu: bad shape M=%ld I=%ld K=%ld", (long)M, (long)I, (long)K);
+  MH_REQUIRE(lda % 8 == 0 && ldb % 8 == 0 && ldgu % 8 == 0 && lddgu % 8 == 0 && lda >= K && ldb >= I && ldgu >= 2 * I &&
+                 lddgu >= 2 * I,
+             "gemm_dswiglu: leading dimensions must be multiples of 8 elements and cover the rows");
+  MH_REQUIRE((((uintptr_t)A | (uintptr_t)B | (uintptr_t)GU | (uintptr_t)DGU) & 15) == 0, "gemm_dswiglu: 16-byte alignment");
+  return mh_gemm_pp256_dswiglu_bf16(A, lda, B, ldb, GU, ldgu, DGU, lddgu, M, I, K, (hipStream_t)stream);
+}
+
 extern "C" int mh_gemm_nt(const void* A, int64_t lda, const void* B, int64_t ldb, void* C, int64_t ldc,
                           const void* R, int64_t ldr, int64_t M, int64_t N, int64_t K, float alpha, float beta,
                           int dtype, int splitk, void* workspace, void* stream) {

@@ -91,7 +91,7 @@ __device__ inline bf16x8 frag(const char* tile, int row0, int fi, int fg) {
   }
 }
 
-template <bool TA, bool TB, int ABL>
+template <bool TA, bool TB, int ABL, int EPI>
 __global__ __launch_bounds__(512, 2) void gemm_pp256_kernel(const bf16* __restrict__ A, int64_t lda,
                                                             const bf16* __restrict__ B, int64_t ldb, bf16* C, int64_t ldc,
                                                             const bf16* R, int64_t ldr, int64_t M, int64_t N, int64_t K,
@@ -236,6 +236,57 @@ __global__ __launch_bounds__(512, 2) void gemm_pp256_kernel(const bf16* __restri
   // (1-2 % on the K = 1024 shapes).  Split-K partials keep the direct fragment stores below (16 rows x 64 B per instruction
   // is already half lines; turning them through LDS measured 5 % slower inside the training step).
   // Rounding the tile to bf16 before the turn (half the LDS traffic when there is no residual) measured no faster.
+  if constexpr (EPI == 1) {
+    // SwiGLU backward as the epilogue of down_proj's dgrad (mh_gemm_dswiglu): the tile is d a = dx * Wd (M x I); R holds
+    // gate|up of the forward ([M, 2 I]) and C receives d gate | d up.  Same whole-line turn through LDS; the gate and up
+    // lines of a 64-row half are requested before its turn.  d a is rounded to bf16 first, as the unfused pair of
+    // launches (mh_gemm + mh_swiglu_bwd) stores it.
+    char* wreg = smem + wave * 16384;
+    const int lrow = lane >> 3, c = lane & 7;
+    const int64_t n = n0 + wn * 64 + c * 8;
+    const bool n_ok = (n + 8 <= N);
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+      bf16x8 gv[8], uv[8];
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const int64_t m = m0 + grp * 128 + half * 64 + i * 8 + lrow;
+        if (m < M && n_ok) {
+          gv[i] = *reinterpret_cast<const bf16x8*>(R + m * ldr + n);
+          uv[i] = *reinterpret_cast<const bf16x8*>(R + m * ldr + N + n);
+        }
+      }
+#pragma unroll
+      for (int fmh = 0; fmh < 4; ++fmh)
+#pragma unroll
+        for (int fn = 0; fn < 4; ++fn) {
+          const int row = fmh * 16 + fi, ch = fn * 4 + fg;
+          *reinterpret_cast<f32x4*>(wreg + row * 256 + ((ch ^ (row & 15)) << 4)) = acc[fn][half * 4 + fmh];
+        }
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const int row = i * 8 + lrow;
+        const f32x4 lo = *reinterpret_cast<const f32x4*>(wreg + row * 256 + (((2 * c) ^ (row & 15)) << 4));
+        const f32x4 hi = *reinterpret_cast<const f32x4*>(wreg + row * 256 + (((2 * c + 1) ^ (row & 15)) << 4));
+        const int64_t m = m0 + grp * 128 + half * 64 + row;
+        if (m >= M || !n_ok) continue;
+        const float v[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+        bf16x8 og, ou;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const float dv = (float)(bf16)(alpha * v[e]);
+          const float g = (float)gv[i][e], u = (float)uv[i][e];
+          const float sig = 1.f / (1.f + __expf(-g));
+          const float silu = g * sig;
+          og[e] = (bf16)(dv * u * (sig * (1.f + g * (1.f - sig))));
+          ou[e] = (bf16)(dv * silu);
+        }
+        __builtin_nontemporal_store(og, reinterpret_cast<bf16x8*>(C + m * ldc + n));
+        __builtin_nontemporal_store(ou, reinterpret_cast<bf16x8*>(C + m * ldc + N + n));
+      }
+    }
+    return;
+  }
   const bool use_r = (R != nullptr && beta != 0.f);
   const bool line_ok = !partial && (ldc & 7) == 0 && ((uintptr_t)C & 15) == 0 &&
                        (!use_r || ((ldr & 7) == 0 && ((uintptr_t)R & 15) == 0));
@@ -341,7 +392,7 @@ __global__ __launch_bounds__(512, 2) void gemm_pp256_kernel(const bf16* __restri
   }
 }
 
-template <bool TA, bool TB, int ABL>
+template <bool TA, bool TB, int ABL, int EPI = 0>
 int launch_one(const void* A, int64_t lda, const void* B, int64_t ldb, void* C, int64_t ldc, const void* R, int64_t ldr,
                int64_t M, int64_t N, int64_t K, float alpha, float beta, int splitk, void* workspace, hipStream_t st) {
   static bool attr_set = false;
@@ -351,7 +402,7 @@ int launch_one(const void* A, int64_t lda, const void* B, int64_t ldb, void* C, 
     return MH_ERR_LAUNCH;
   }
   if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_pp256_kernel<TA, TB, ABL>),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_pp256_kernel<TA, TB, ABL, EPI>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
     if (e != hipSuccess) {
       mh_set_error("gemm_pp256: cannot raise dynamic LDS to %d bytes: %s", LDS_BYTES, hipGetErrorString(e));
@@ -363,7 +414,7 @@ int launch_one(const void* A, int64_t lda, const void* B, int64_t ldb, void* C, 
   const int nwg = (int)(tiles_m * tiles_n);
   const int64_t kps = ((K + splitk - 1) / splitk + QBK - 1) / QBK * QBK;
   dim3 grid(nwg, 1, splitk);
-  gemm_pp256_kernel<TA, TB, ABL><<<grid, 512, LDS_BYTES, st>>>((const bf16*)A, lda, (const bf16*)B, ldb, (bf16*)C, ldc,
+  gemm_pp256_kernel<TA, TB, ABL, EPI><<<grid, 512, LDS_BYTES, st>>>((const bf16*)A, lda, (const bf16*)B, ldb, (bf16*)C, ldc,
                                                           (const bf16*)R, ldr, M, N, K, alpha, beta, (int)tiles_n, nwg, kps,
                                                           (float*)workspace, zero16);
   MH_LAUNCH_CHECK();
@@ -393,4 +444,10 @@ int mh_gemm_pp256_bf16(const void* A, int64_t lda, int ta, const void* B, int64_
   if (tb) MH_PP(false, true, 0);
   MH_PP(false, false, 0);
 #undef MH_PP
+}
+
+// d gate | d up = SwiGLU'(gate|up) applied to A * B^T (A row-major [M,K], B contraction-major [K,I]); gemm.hip validates
+int mh_gemm_pp256_dswiglu_bf16(const void* A, int64_t lda, const void* B, int64_t ldb, const void* GU, int64_t ldgu,
+                               void* DGU, int64_t lddgu, int64_t M, int64_t I, int64_t K, hipStream_t st) {
+  return launch_one<false, true, 0, 1>(A, lda, B, ldb, DGU, lddgu, GU, ldgu, M, I, K, 1.f, 0.f, 1, nullptr, st);
 }

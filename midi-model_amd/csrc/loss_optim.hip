@@ -190,7 +190,15 @@ __device__ inline float block_sum_1024(float v, float* sh) {
 __global__ __launch_bounds__(1024) void sum_f32_kernel(const float* __restrict__ x, int64_t n, float* __restrict__ out) {
   __shared__ float sh[16];
   float s = 0.f;
-  for (int64_t i = threadIdx.x; i < n; i += 1024) s += x[i];
+  int64_t i = threadIdx.x;
+  for (; i + 7 * 1024 < n; i += 8 * 1024) {  // eight loads in flight, added in index order (one block: a latency chain)
+    float v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) v[u] = x[i + u * 1024];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) s += v[u];
+  }
+  for (; i < n; i += 1024) s += x[i];
   s = block_sum_1024(s, sh);
   if (threadIdx.x == 0) out[0] = s;
 }
@@ -206,7 +214,15 @@ __global__ __launch_bounds__(1024) void count_valid_kernel(const int64_t* __rest
                                                            float* __restrict__ count, float* __restrict__ inv) {
   __shared__ float sh[16];
   float s = 0.f;
-  for (int64_t i = threadIdx.x; i < n; i += 1024) s += (t[i] != ignore) ? 1.f : 0.f;
+  int64_t i = threadIdx.x;
+  for (; i + 7 * 1024 < n; i += 8 * 1024) {
+    int64_t v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) v[u] = t[i + u * 1024];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) s += (v[u] != ignore) ? 1.f : 0.f;
+  }
+  for (; i < n; i += 1024) s += (t[i] != ignore) ? 1.f : 0.f;
   s = block_sum_1024(s, sh);
   if (threadIdx.x == 0) {
     count[0] = s;

@@ -162,12 +162,15 @@ def stack_backward(spec: StackSpec, W: StackTensors, G: StackTensors, ctx, dy: t
         lw, lg = W.layers[li], G.layers[li]
         x, rstd1, h1, qkv, o, lse, x2, rstd2, h2, gu, a = saved[li]
         # ---- MLP ----
-        da = _empty((M, I), dy)
-        ops.gemm_nt(dx, lw.wd, da, tb=True)             # d a = dx @ wd      (wd [D, I] read contraction-major)
-        linear_wgrad(dx, a, lg.wd, accumulate)
         dgu = _empty((M, 2 * I), dy)
-        ops.swiglu_bwd(gu, da, dgu)
-        del da
+        if ops.dswiglu_ok(dx, I):                       # d a = dx @ wd with the SwiGLU backward as its epilogue
+            ops.gemm_dswiglu(dx, lw.wd, gu, dgu)
+        else:
+            da = _empty((M, I), dy)
+            ops.gemm_nt(dx, lw.wd, da, tb=True)         # d a = dx @ wd      (wd [D, I] read contraction-major)
+            ops.swiglu_bwd(gu, da, dgu)
+            del da
+        linear_wgrad(dx, a, lg.wd, accumulate)
         dh2 = _empty((M, D), dy)
         ops.gemm_nt(dgu, lw.wgu, dh2, tb=True)          # d h2 = dgu @ wgu
         linear_wgrad(dgu, h2, lg.wgu, accumulate)

@@ -54,6 +54,15 @@ def set_option(name: str, value: int) -> None:
         _gemm_variant = int(value)
 
 
+def get_option(name: str) -> int:
+    global _gemm_variant
+    if name == "gemm":
+        if _gemm_variant is None:
+            _gemm_variant = lib().cdll.mh_get_option(b"gemm")
+        return _gemm_variant
+    return lib().cdll.mh_get_option(name.encode())
+
+
 def _pick_splitk(M: int, N: int, K: int) -> int:
     """Split the contraction when the output has too few tiles to fill 256 CUs (the weight-gradient shapes):
     aim at >= 512 workgroups, keep >= 512 contraction elements per slice."""
@@ -118,6 +127,29 @@ def gemm_nt(a: torch.Tensor, b: torch.Tensor, out: torch.Tensor, *, K: Optional[
         lib().call("mh_gemm_splitk_reduce", _p(ws), _p(out), _rowmajor(out), _p(res),
                    _rowmajor(res) if res is not None else 0, M, N, splitk, alpha, beta, dt(out), _stream())
     return out
+
+
+def dswiglu_ok(dx: torch.Tensor, I: int) -> bool:
+    """whether mh_gemm_dswiglu serves down_proj's dgrad + SwiGLU backward (else mh_gemm, then mh_swiglu_bwd)"""
+    return dx.dtype == torch.bfloat16 and I % 8 == 0 and get_option("gemm") != 0
+
+
+def gemm_dswiglu(dx: torch.Tensor, wd: torch.Tensor, gu: torch.Tensor, dgu: torch.Tensor) -> torch.Tensor:
+    """dgu = SwiGLU'(gu) applied to (dx @ wd): dx [M, D], wd [D, I] (the down_proj weight, read contraction-major),
+    gu / dgu [M, 2I]"""
+    M, K = dx.shape
+    I = wd.shape[1]
+    assert wd.shape[0] == K and gu.shape == (M, 2 * I) and dgu.shape == (M, 2 * I) and dx.dtype == wd.dtype == gu.dtype
+    prof = gemm_profile
+    if prof is not None:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+    lib().call("mh_gemm_dswiglu", _p(dx), _rowmajor(dx), _p(wd), _rowmajor(wd), _p(gu), _rowmajor(gu), _p(dgu), _rowmajor(dgu),
+               M, I, K, dt(dx), _stream())
+    if prof is not None:
+        e1.record()
+        prof.append((e0, e1, 2.0 * M * I * K, (M, I, K, 1, 0, 1)))
+    return dgu
 
 
 SKINNY_PLAIN, SKINNY_GATEUP = 0, 1

@@ -19,6 +19,10 @@ def set_option(name, value):
     pass
 
 
+def get_option(name):
+    return 1
+
+
 def round_up(x, m):
     return (x + m - 1) // m * m
 
@@ -38,6 +42,16 @@ def gemm_nt(a, b, out, *, K=None, alpha=1.0, beta=0.0, res=None, splitk=0, ta=Fa
 
 
 SKINNY_PLAIN, SKINNY_GATEUP = 0, 1
+
+
+def dswiglu_ok(dx, I):
+    return dx.dtype == torch.bfloat16 and I % 8 == 0
+
+
+def gemm_dswiglu(dx, wd, gu, dgu):
+    da = torch.empty((dx.shape[0], wd.shape[1]), dtype=dx.dtype)
+    gemm_nt(dx, wd, da, tb=True)
+    return swiglu_bwd(gu, da, dgu)
 
 
 def skinny_ok(x, K):

@@ -140,6 +140,25 @@ def test_transpose(ops, dtype, R, C):
     assert torch.equal(out[:, :R].cpu(), x.T) and (out[:, R:] == 0).all()
 
 
+@pytest.mark.parametrize("M,I,K", [(256, 256, 64), (300, 520, 1024), (1000, 4096, 1024), (77, 1024, 264)])
+def test_gemm_dswiglu(ops, M, I, K):
+    """down_proj dgrad with the SwiGLU backward as its epilogue == mh_gemm followed by mh_swiglu_bwd"""
+    dt = torch.bfloat16
+    dx, wd, gu = rnd((M, K), dt, 61, 0.5), rnd((K, I), dt, 62, 0.5), rnd((M, 2 * I), dt, 63, 2.0)
+    assert ops.dswiglu_ok(dx.cuda(), I)
+    fused = torch.full((M, 2 * I), 7.0, dtype=dt, device="cuda")
+    ops.gemm_dswiglu(dx.cuda(), wd.cuda(), gu.cuda(), fused)
+    da = torch.empty((M, I), dtype=dt, device="cuda")
+    ops.gemm_nt(dx.cuda(), wd.cuda(), da, tb=True)
+    two = torch.empty((M, 2 * I), dtype=dt, device="cuda")
+    ops.swiglu_bwd(gu.cuda(), da, two)
+    ref = emu.gemm_dswiglu(dx, wd, gu, torch.empty((M, 2 * I), dtype=dt))
+    cmp(fused, ref, dt, k=K, what="gemm_dswiglu vs emulation")
+    same = (fused == two).float().mean().item()
+    assert same > 0.999, f"fused and two-launch results agree on only {same:.5f} of the elements"
+    cmp(fused, two.cpu(), dt, k=8, what="gemm_dswiglu vs two launches")
+
+
 # ------------------------------------------------------------------------------------------ embeddings
 @pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("D,M", [(256, 77), (1024, 700), (2048, 150)])
