@@ -330,6 +330,22 @@ extern "C" int mh_gemm(const void* A, int64_t lda, int transA, const void* B, in
 int mh_gemm_pp256_dswiglu_bf16(const void* A, int64_t lda, const void* B, int64_t ldb, const void* GU, int64_t ldgu,
                                void* DGU, int64_t lddgu, int64_t M, int64_t I, int64_t K, hipStream_t st);  // gemm_pp256.hip
 
+int mh_gemm_pp256_swiglu_bf16(const void* A, int64_t lda, const void* W, int64_t ldw, void* GU, int64_t ldgu, void* ACT,
+                              int64_t ldact, int64_t M, int64_t I, int64_t K, hipStream_t st);  // gemm_pp256.hip
+
+extern "C" int mh_gemm_swiglu(const void* A, int64_t lda, const void* W, int64_t ldw, void* GU, int64_t ldgu, void* ACT,
+                              int64_t ldact, int64_t M, int64_t I, int64_t K, int dtype, void* stream) {
+  MH_REQUIRE(dtype == MH_BF16 && g_mh_gemm_variant != 0,
+             "gemm_swiglu: served by the production bf16 kernel only (use mh_gemm + mh_swiglu_fwd otherwise)");
+  MH_REQUIRE(M > 0 && I > 0 && K > 0 && I % 128 == 0, "gemm_swiglu: bad shape M=%ld I=%ld K=%ld (I must be a multiple of 128)",
+             (long)M, (long)I, (long)K);
+  MH_REQUIRE(lda % 8 == 0 && ldw % 8 == 0 && ldgu % 8 == 0 && ldact % 8 == 0 && lda >= K && ldw >= K && ldgu >= 2 * I &&
+                 ldact >= I,
+             "gemm_swiglu: leading dimensions must be multiples of 8 elements and cover the rows");
+  MH_REQUIRE((((uintptr_t)A | (uintptr_t)W | (uintptr_t)GU | (uintptr_t)ACT) & 15) == 0, "gemm_swiglu: 16-byte alignment");
+  return mh_gemm_pp256_swiglu_bf16(A, lda, W, ldw, GU, ldgu, ACT, ldact, M, I, K, (hipStream_t)stream);
+}
+
 extern "C" int mh_gemm_dswiglu(const void* A, int64_t lda, const void* B, int64_t ldb, const void* GU, int64_t ldgu,
                                void* DGU, int64_t lddgu, int64_t M, int64_t I, int64_t K, int dtype, void* stream) {
   MH_REQUIRE(dtype == MH_BF16 && g_mh_gemm_variant != 0,

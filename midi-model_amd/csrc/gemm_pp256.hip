@@ -47,13 +47,13 @@ struct StageCtx {
 
 // row-major operand X[r][k]: K-step tile 256 rows x 64 B; one LDS-DMA instruction = 16 rows
 __device__ inline void stage_init_n(StageCtx& c, const bf16* __restrict__ base, int64_t ld, int64_t row0, int64_t nrows,
-                                    int64_t kend, int wave, int lane, bool fullline = false) {
+                                    int64_t kend, int wave, int lane, bool fullline = false, int64_t jump128 = 0) {
   const int rsub = fullline ? (lane >> 3) : (lane >> 2), pc = fullline ? (lane & 7) : (lane & 3);
 #pragma unroll
   for (int it = 0; it < NI; ++it) {
     const int r = (wave + NWAVE * it) * 16 + rsub;
     const int ch = fullline ? pc : (pc ^ xswz(r));
-    const int64_t grow = row0 + r;
+    const int64_t grow = row0 + r + (r >= 128 ? jump128 : 0);  // (jump128: the tile's upper half comes from another row block)
     c.p[it] = base + (grow < nrows ? grow : 0) * ld + ch * 8;
     c.klim[it] = (grow < nrows) ? (int)kend - ch * 8 : INT_MIN;
   }
@@ -119,7 +119,10 @@ __global__ __launch_bounds__(512, 2) void gemm_pp256_kernel(const bf16* __restri
   const int zslice = item / nwg;
   int tm, tn;
   gemm_tile_of(item - zslice * nwg, nwg / tiles_n, tiles_n, 4, tm, tn);
-  const int64_t m0 = (int64_t)tm * QBM, n0 = (int64_t)tn * QBN;
+  // EPI == 2 (gate|up projection with the SwiGLU forward as epilogue, mh_gemm_swiglu): B = [gate rows; up rows] (N = 2 I);
+  // a tile takes 128 gate rows and the 128 matching up rows, so that every lane ends up holding gate and up of the same
+  // output element (wave wn: fragments 0,1 = gate columns wn*32.., fragments 2,3 = the same up columns)
+  const int64_t m0 = (int64_t)tm * QBM, n0 = (int64_t)tn * (EPI == 2 ? 128 : QBN);
 
   const int64_t kbeg = (int64_t)zslice * k_per_split;
   const int64_t kend = (kbeg + k_per_split < K) ? kbeg + k_per_split : K;
@@ -136,7 +139,7 @@ __global__ __launch_bounds__(512, 2) void gemm_pp256_kernel(const bf16* __restri
   if constexpr (TA) stage_init_t(ca, A, lda, m0, M, kend, wave, lane);
   else stage_init_n(ca, A, lda, m0, M, kend, wave, lane, (ABL & 8) != 0);
   if constexpr (TB) stage_init_t(cb, B, ldb, n0, N, kend, wave, lane);
-  else stage_init_n(cb, B, ldb, n0, N, kend, wave, lane, (ABL & 8) != 0);
+  else stage_init_n(cb, B, ldb, n0, N, kend, wave, lane, (ABL & 8) != 0, EPI == 2 ? N / 2 - 128 : 0);
   // LDS-DMA instruction j (0,1: A; 2,3: B) of K-step t; step t lives in stage t & 3
   auto issue_one = [&](int t, int j) {
     char* buf = smem + (t & (NSTAGE - 1)) * STAGE_BYTES + (j >> 1) * OP_BYTES + (wave + NWAVE * (j & 1)) * 1024;
@@ -162,7 +165,8 @@ __global__ __launch_bounds__(512, 2) void gemm_pp256_kernel(const bf16* __restri
     const char* tB = tA + OP_BYTES;
     if ((ABL & 2) && t > 0) return;
 #pragma unroll
-    for (int f = 0; f < 4; ++f) fw[f] = frag<TB>(tB, wn * 64 + f * 16, fi, fg);
+    for (int f = 0; f < 4; ++f)
+      fw[f] = frag<TB>(tB, EPI == 2 ? (f >> 1) * 128 + wn * 32 + (f & 1) * 16 : wn * 64 + f * 16, fi, fg);
 #pragma unroll
     for (int f = 0; f < 8; ++f) fx[f] = frag<TA>(tA, grp * 128 + f * 16, fi, fg);
   };
@@ -283,6 +287,50 @@ __global__ __launch_bounds__(512, 2) void gemm_pp256_kernel(const bf16* __restri
         }
         __builtin_nontemporal_store(og, reinterpret_cast<bf16x8*>(C + m * ldc + n));
         __builtin_nontemporal_store(ou, reinterpret_cast<bf16x8*>(C + m * ldc + N + n));
+      }
+    }
+    return;
+  }
+  if constexpr (EPI == 2) {
+    // C = gate|up [M, 2 I] (kept for the backward), R = the activation a = round(silu(gate)) * up [M, I] (written here:
+    // LlamaMLP.forward, modeling_llama.py:174-176, roundings as mh_swiglu_fwd).  The wave's 64 fp32 columns are 32 gate +
+    // the 32 matching up columns: 4 lanes write 64 contiguous bytes of a row to each of the three outputs.
+    char* wreg = smem + wave * 16384;
+    const int lrow = lane >> 2, c = lane & 3;
+    const int64_t I = N >> 1, col = n0 + wn * 32 + c * 8;
+    bf16* act = const_cast<bf16*>(R);
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+#pragma unroll
+      for (int fmh = 0; fmh < 4; ++fmh)
+#pragma unroll
+        for (int fn = 0; fn < 4; ++fn) {
+          const int row = fmh * 16 + fi, ch = fn * 4 + fg;
+          *reinterpret_cast<f32x4*>(wreg + row * 256 + ((ch ^ (row & 15)) << 4)) = acc[fn][half * 4 + fmh];
+        }
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {  // 16 rows x (64 B gate, 64 B up) per pass
+        const int row = i * 16 + lrow, sw = row & 15;
+        const f32x4 g0 = *reinterpret_cast<const f32x4*>(wreg + row * 256 + (((2 * c) ^ sw) << 4));
+        const f32x4 g1 = *reinterpret_cast<const f32x4*>(wreg + row * 256 + (((2 * c + 1) ^ sw) << 4));
+        const f32x4 u0 = *reinterpret_cast<const f32x4*>(wreg + row * 256 + (((8 + 2 * c) ^ sw) << 4));
+        const f32x4 u1 = *reinterpret_cast<const f32x4*>(wreg + row * 256 + (((9 + 2 * c) ^ sw) << 4));
+        const int64_t m = m0 + grp * 128 + half * 64 + row;
+        if (m >= M || col >= I) continue;
+        const float gf[8] = {g0[0], g0[1], g0[2], g0[3], g1[0], g1[1], g1[2], g1[3]};
+        const float uf[8] = {u0[0], u0[1], u0[2], u0[3], u1[0], u1[1], u1[2], u1[3]};
+        bf16x8 og, ou, oa;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          og[e] = (bf16)(alpha * gf[e]);
+          ou[e] = (bf16)(alpha * uf[e]);
+          const float gv = (float)og[e];
+          const float sv = (float)(bf16)(gv / (1.f + __expf(-gv)));
+          oa[e] = (bf16)(sv * (float)ou[e]);
+        }
+        *reinterpret_cast<bf16x8*>(C + m * ldc + col) = og;      // (read again by the backward only)
+        *reinterpret_cast<bf16x8*>(C + m * ldc + I + col) = ou;
+        *reinterpret_cast<bf16x8*>(act + m * ldr + col) = oa;
       }
     }
     return;
@@ -410,7 +458,7 @@ int launch_one(const void* A, int64_t lda, const void* B, int64_t ldb, void* C, 
     }
     attr_set = true;
   }
-  const int64_t tiles_m = (M + QBM - 1) / QBM, tiles_n = (N + QBN - 1) / QBN;
+  const int64_t tiles_m = (M + QBM - 1) / QBM, tiles_n = (EPI == 2) ? N / 256 : (N + QBN - 1) / QBN;  // (EPI 2: I / 128)
   const int nwg = (int)(tiles_m * tiles_n);
   const int64_t kps = ((K + splitk - 1) / splitk + QBK - 1) / QBK * QBK;
   dim3 grid(nwg, 1, splitk);
@@ -444,6 +492,12 @@ int mh_gemm_pp256_bf16(const void* A, int64_t lda, int ta, const void* B, int64_
   if (tb) MH_PP(false, true, 0);
   MH_PP(false, false, 0);
 #undef MH_PP
+}
+
+// gate|up = A * [Wgate; Wup]^T and a = round(silu(gate)) * up in one launch (both operands row-major); gemm.hip validates
+int mh_gemm_pp256_swiglu_bf16(const void* A, int64_t lda, const void* W, int64_t ldw, void* GU, int64_t ldgu, void* ACT,
+                              int64_t ldact, int64_t M, int64_t I, int64_t K, hipStream_t st) {
+  return launch_one<false, false, 0, 2>(A, lda, W, ldw, GU, ldgu, ACT, ldact, M, 2 * I, K, 1.f, 0.f, 1, nullptr, st);
 }
 
 // d gate | d up = SwiGLU'(gate|up) applied to A * B^T (A row-major [M,K], B contraction-major [K,I]); gemm.hip validates

@@ -134,9 +134,12 @@ def stack_forward(spec: StackSpec, W: StackTensors, x: torch.Tensor, nseq: int, 
         rstd2 = _empty((M,), x, torch.float32)
         ops.rmsnorm_fwd(x2, lw.n2, h2, rstd2, spec.eps)
         gu = _empty((M, 2 * I), x)
-        ops.gemm_nt(h2, lw.wgu, gu)
         a = _empty((M, I), x)
-        ops.swiglu_fwd(gu, a)
+        if ops.swiglu_fused_ok(h2, I):                  # gate|up projection with SwiGLU as its epilogue
+            ops.gemm_swiglu(h2, lw.wgu, gu, a)
+        else:
+            ops.gemm_nt(h2, lw.wgu, gu)
+            ops.swiglu_fwd(gu, a)
         x3 = _empty((M, D), x)
         ops.gemm_nt(a, lw.wd, x3, beta=1.0, res=x2)
         if save:

@@ -6,6 +6,8 @@ from __future__ import annotations
 
 from typing import Optional
 
+import os
+
 import torch
 
 from .lib import MH_BF16, MH_F32, lib
@@ -129,9 +131,34 @@ def gemm_nt(a: torch.Tensor, b: torch.Tensor, out: torch.Tensor, *, K: Optional[
     return out
 
 
+_FUSE_SWIGLU = int(os.environ.get("MH_FUSE_SWIGLU", "3"))  # bit 0: forward, bit 1: backward fusion (A/B measurements)
+
+
+def swiglu_fused_ok(x: torch.Tensor, I: int) -> bool:
+    """whether mh_gemm_swiglu serves the gate|up projection + SwiGLU (else mh_gemm, then mh_swiglu_fwd)"""
+    return x.dtype == torch.bfloat16 and I % 128 == 0 and get_option("gemm") != 0 and (_FUSE_SWIGLU & 1) != 0
+
+
+def gemm_swiglu(x: torch.Tensor, wgu: torch.Tensor, gu: torch.Tensor, a: torch.Tensor) -> torch.Tensor:
+    """gu [M, 2I] = x @ wgu^T (wgu = [gate; up], [2I, K]) and a [M, I] = silu(gate) * up"""
+    M, K = x.shape
+    I = a.shape[1]
+    assert wgu.shape == (2 * I, K) and gu.shape == (M, 2 * I) and a.shape[0] == M and x.dtype == wgu.dtype == gu.dtype == a.dtype
+    prof = gemm_profile
+    if prof is not None:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+    lib().call("mh_gemm_swiglu", _p(x), _rowmajor(x), _p(wgu), _rowmajor(wgu), _p(gu), _rowmajor(gu), _p(a), _rowmajor(a),
+               M, I, K, dt(x), _stream())
+    if prof is not None:
+        e1.record()
+        prof.append((e0, e1, 2.0 * M * 2 * I * K, (M, 2 * I, K, 1, 0, 0)))
+    return a
+
+
 def dswiglu_ok(dx: torch.Tensor, I: int) -> bool:
     """whether mh_gemm_dswiglu serves down_proj's dgrad + SwiGLU backward (else mh_gemm, then mh_swiglu_bwd)"""
-    return dx.dtype == torch.bfloat16 and I % 8 == 0 and get_option("gemm") != 0
+    return dx.dtype == torch.bfloat16 and I % 8 == 0 and get_option("gemm") != 0 and (_FUSE_SWIGLU & 2) != 0
 
 
 def gemm_dswiglu(dx: torch.Tensor, wd: torch.Tensor, gu: torch.Tensor, dgu: torch.Tensor) -> torch.Tensor:

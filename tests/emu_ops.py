@@ -44,6 +44,15 @@ def gemm_nt(a, b, out, *, K=None, alpha=1.0, beta=0.0, res=None, splitk=0, ta=Fa
 SKINNY_PLAIN, SKINNY_GATEUP = 0, 1
 
 
+def swiglu_fused_ok(x, I):
+    return x.dtype == torch.bfloat16 and I % 128 == 0
+
+
+def gemm_swiglu(x, wgu, gu, a):
+    gemm_nt(x, wgu, gu)
+    return swiglu_fwd(gu, a)
+
+
 def dswiglu_ok(dx, I):
     return dx.dtype == torch.bfloat16 and I % 8 == 0
 

@@ -140,6 +140,27 @@ def test_transpose(ops, dtype, R, C):
     assert torch.equal(out[:, :R].cpu(), x.T) and (out[:, R:] == 0).all()
 
 
+@pytest.mark.parametrize("M,I,K", [(256, 128, 64), (300, 640, 1024), (1000, 4096, 1024), (77, 1024, 264)])
+def test_gemm_swiglu(ops, M, I, K):
+    """gate|up projection with the SwiGLU forward as its epilogue == mh_gemm_nt followed by mh_swiglu_fwd"""
+    dt = torch.bfloat16
+    x, w = rnd((M, K), dt, 64, 0.5), rnd((2 * I, K), dt, 65, 0.5)
+    assert ops.swiglu_fused_ok(x.cuda(), I)
+    gu = torch.full((M, 2 * I), 7.0, dtype=dt, device="cuda")
+    a = torch.full((M, I), 7.0, dtype=dt, device="cuda")
+    ops.gemm_swiglu(x.cuda(), w.cuda(), gu, a)
+    gu2 = torch.empty((M, 2 * I), dtype=dt, device="cuda")
+    ops.gemm_nt(x.cuda(), w.cuda(), gu2, splitk=1)  # (same accumulation order as the unsplit fused launch)
+    a2 = torch.empty((M, I), dtype=dt, device="cuda")
+    ops.swiglu_fwd(gu2, a2)
+    assert torch.equal(gu, gu2), "gate|up differs from the plain projection"
+    assert torch.equal(a, a2), "activation differs from mh_swiglu_fwd on the same gate|up"
+    gr, ar = torch.empty((M, 2 * I), dtype=dt), torch.empty((M, I), dtype=dt)
+    emu.gemm_swiglu(x, w, gr, ar)
+    cmp(gu, gr, dt, k=max(1.0, K / 256), what="gemm_swiglu gate|up vs emulation")
+    cmp(a, ar, dt, k=max(2.0, K / 128), what="gemm_swiglu activation vs emulation")
+
+
 @pytest.mark.parametrize("M,I,K", [(256, 256, 64), (300, 520, 1024), (1000, 4096, 1024), (77, 1024, 264)])
 def test_gemm_dswiglu(ops, M, I, K):
     """down_proj dgrad with the SwiGLU backward as its epilogue == mh_gemm followed by mh_swiglu_bwd"""
