@@ -204,12 +204,20 @@ __global__ __launch_bounds__(512, 2) void gemm_pp256_kernel(const bf16* __restri
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   };
+  // Barrier 2t+1 keeps the two groups strictly out of phase (group 0 reads while group 1 multiplies and vice versa); LDS
+  // safety only needs barrier 2t (every wave has seen its own pieces of step t land, and has finished reading step t-1
+  // whose stage the LDS-DMA of step t+3 overwrites).  With a contraction-major operand the load segment carries the
+  // transposing reads (24 per wave when both operands are) and outlasts the 32 MFMAs; letting the groups drift measured
+  // 9-14 % faster for weight gradients and 0-8 % for the dgrad shapes (profiles/r01_run19_gemm_single_barrier_*.txt).
+  // With both operands row-major it is neutral to 3 % slower, so those keep the second barrier.  (ABL bit 64 flips the
+  // choice; results are identical either way.)
+  constexpr bool MIDBAR = ((ABL & 64) != 0) == (TA || TB);
   if (grp == 0) {
     for (int t = 0; t < nt; ++t) {
       wait_step(t);
       bar();  // barrier 2t
       load_segment(t);
-      bar();  // barrier 2t+1
+      if (MIDBAR) bar();  // barrier 2t+1
       mfma_all(t);
     }
     bar();    // barrier 2nt
@@ -218,7 +226,7 @@ __global__ __launch_bounds__(512, 2) void gemm_pp256_kernel(const bf16* __restri
       wait_step(t);
       bar();  // barrier 2t
       if (t > 0) mfma_all(t - 1);
-      bar();  // barrier 2t+1
+      if (MIDBAR) bar();  // barrier 2t+1
       load_segment(t);
     }
     bar();    // barrier 2nt
@@ -486,6 +494,12 @@ int mh_gemm_pp256_bf16(const void* A, int64_t lda, int ta, const void* B, int64_
     MH_PP(false, false, X_);
     switch (g_mh_gemm_ablate) { MH_AB(1) MH_AB(3) MH_AB(4) MH_AB(5) MH_AB(8) MH_AB(12) MH_AB(32) default: break; }
 #undef MH_AB
+  }
+  if (g_mh_gemm_ablate == 64) {  // the other mid-barrier choice (correct results), any operand layout
+    if (ta && tb) MH_PP(true, true, 64);
+    if (ta) MH_PP(true, false, 64);
+    if (tb) MH_PP(false, true, 64);
+    MH_PP(false, false, 64);
   }
   if (ta && tb) MH_PP(true, true, 0);
   if (ta) MH_PP(true, false, 0);

@@ -35,6 +35,8 @@ def main():
         shapes = [(32768, 1024, 512, 0, 0, 0), (32768, 1024, 1024, 0, 0, 12), (32768, 1024, 2048, 0, 0, 0), (32768, 1024, 4096, 0, 0, 12),
                   (32768, 3072, 1024, 0, 0, 12), (262144, 1024, 1024, 0, 0, 6), (32768, 8192, 1024, 0, 0, 12),
                   (8192, 1024, 32768, 1, 1, 12), (1024, 1024, 262144, 1, 1, 6), (1024, 1024, 32768, 1, 1, 12)]
+    if os.environ.get("MH_BENCH_SHAPES") == "mixed":   # one row-major, one contraction-major operand
+        shapes = [sh for sh in SHAPES if sh[3] != sh[4]] + [(8192, 1024, 32768, 1, 0, 0), (3072, 1024, 32768, 1, 0, 0)]
     if os.environ.get("MH_BENCH_SHAPES") == "wgrad":
         shapes = [sh for sh in SHAPES if sh[3] and sh[4]]
     if os.environ.get("MH_BENCH_SHAPES") == "few":
