@@ -51,6 +51,21 @@ template <> __device__ inline void ldp<bf16>(const bf16* row, int lane, float (&
   const bf16x2_t a = *reinterpret_cast<const bf16x2_t*>(row + 2 * lane), b = *reinterpret_cast<const bf16x2_t*>(row + 128 + 2 * lane);
   o[0] = (float)a[0]; o[1] = (float)a[1]; o[2] = (float)b[0]; o[3] = (float)b[1];
 }
+// the same lane share as ldp, kept as loaded (2 dwords for bf16) so that a whole octet's rows can be requested up front
+template <typename T> struct RawRow;
+template <> struct RawRow<float> { float2 a, b; };
+template <> struct RawRow<bf16> { bf16x2_t a, b; };
+template <typename T> __device__ inline RawRow<T> ldraw(const T* row, int lane);
+template <> __device__ inline RawRow<float> ldraw<float>(const float* row, int lane) {
+  return {*reinterpret_cast<const float2*>(row + 2 * lane), *reinterpret_cast<const float2*>(row + 128 + 2 * lane)};
+}
+template <> __device__ inline RawRow<bf16> ldraw<bf16>(const bf16* row, int lane) {
+  return {*reinterpret_cast<const bf16x2_t*>(row + 2 * lane), *reinterpret_cast<const bf16x2_t*>(row + 128 + 2 * lane)};
+}
+__device__ inline void unpack(const RawRow<float>& r, float (&o)[4]) { o[0] = r.a.x; o[1] = r.a.y; o[2] = r.b.x; o[3] = r.b.y; }
+__device__ inline void unpack(const RawRow<bf16>& r, float (&o)[4]) {
+  o[0] = (float)r.a[0]; o[1] = (float)r.a[1]; o[2] = (float)r.b[0]; o[3] = (float)r.b[1];
+}
 template <typename T> __device__ inline void stp(T* row, int lane, const float (&o)[4]);
 template <> __device__ inline void stp<float>(float* row, int lane, const float (&o)[4]) {
   *reinterpret_cast<float2*>(row + 2 * lane) = float2{o[0], o[1]};
@@ -85,9 +100,13 @@ __device__ inline void rope_row(float (&x)[4], const float* rope_c, const float*
 }
 
 // One wave per (sequence, head).  K and V of the <= 8 tokens stay in registers (lane l: 4 elements per row, see ldp);
-// the query rows stream through one at a time, which keeps the forward at ~125 and the backward at ~160 VGPRs
+// the query rows go through one at a time, which keeps the forward at ~125 and the backward at ~160 VGPRs
 // (3-4 waves per SIMD in flight instead of 1: these kernels only move bytes).
-template <typename T>
+// TN = the compile-time sequence length (8, the octet of the training path) or 0 for a run-time Tn <= 8.  With TN known
+// every row of the (sequence, head) -- K, V, Q (and dO) -- is requested before the first one is used; the run-time form
+// branches per row and was a chain of 16 dependent HBM round trips per wave (r01_run20: 604 us forward, 1.3 ms backward
+// for 2.1 / 3.8 GB).
+template <typename T, int TN>
 __global__ __launch_bounds__(256) void tokattn_fwd_kernel(const T* __restrict__ qkv, T* __restrict__ o, int64_t NH, int Tn,
                                                           int H, float scale, const float* __restrict__ cos_t,
                                                           const float* __restrict__ sin_t) {
@@ -108,19 +127,38 @@ __global__ __launch_bounds__(256) void tokattn_fwd_kernel(const T* __restrict__ 
     const int h = (int)(w - n * H);
     const T* base = qkv + n * Tn * D3 + (int64_t)h * 256;
     float k[TK][4], v[TK][4];
+    RawRow<T> qraw[TN ? TN : 1];
+    if constexpr (TN != 0) {
+      RawRow<T> kraw[TN ? TN : 1], vraw[TN ? TN : 1];
 #pragma unroll
-    for (int t = 0; t < TK; ++t) {
-      if (t < Tn) {
-        ldp<T>(base + t * D3 + D, lane, k[t]);
-        ldp<T>(base + t * D3 + 2 * D, lane, v[t]);
+      for (int t = 0; t < TN; ++t) {
+        kraw[t] = ldraw<T>(base + t * D3 + D, lane);
+        vraw[t] = ldraw<T>(base + t * D3 + 2 * D, lane);
+      }
+#pragma unroll
+      for (int t = 0; t < TN; ++t) qraw[t] = ldraw<T>(base + t * D3, lane);
+#pragma unroll
+      for (int t = 0; t < TN; ++t) {
+        unpack(kraw[t], k[t]);
+        unpack(vraw[t], v[t]);
         if (rot) rope_row<T>(k[t], rope_c, rope_s, t, lane, 1.f, true);
+      }
+    } else {
+#pragma unroll
+      for (int t = 0; t < TK; ++t) {
+        if (t < Tn) {
+          ldp<T>(base + t * D3 + D, lane, k[t]);
+          ldp<T>(base + t * D3 + 2 * D, lane, v[t]);
+          if (rot) rope_row<T>(k[t], rope_c, rope_s, t, lane, 1.f, true);
+        }
       }
     }
 #pragma unroll
     for (int i = 0; i < TK; ++i) {
-      if (i >= Tn) break;
+      if (TN ? i >= TN : i >= Tn) break;
       float q[4];
-      ldp<T>(base + i * D3, lane, q);
+      if constexpr (TN != 0) unpack(qraw[i], q);
+      else ldp<T>(base + i * D3, lane, q);
       if (rot) rope_row<T>(q, rope_c, rope_s, i, lane, 1.f, true);
       float s[TK];
       float mx = -INFINITY;
@@ -149,7 +187,7 @@ __global__ __launch_bounds__(256) void tokattn_fwd_kernel(const T* __restrict__ 
   }
 }
 
-template <typename T>
+template <typename T, int TN>
 __global__ __launch_bounds__(256) void tokattn_bwd_kernel(const T* __restrict__ qkv, const T* __restrict__ dout,
                                                           T* __restrict__ dqkv, int64_t NH, int Tn, int H, float scale,
                                                           const float* __restrict__ cos_t, const float* __restrict__ sin_t) {
@@ -173,22 +211,50 @@ __global__ __launch_bounds__(256) void tokattn_bwd_kernel(const T* __restrict__ 
     const T* base = qkv + n * Tn * D3 + off;
     T* ob = dqkv + n * Tn * D3 + off;
     float k[TK][4], v[TK][4], dk[TK][4], dv[TK][4];
+    RawRow<T> qraw[TN ? TN : 1], doraw[TN ? TN : 1];
 #pragma unroll
-    for (int t = 0; t < TK; ++t) {
+    for (int t = 0; t < TK; ++t)
 #pragma unroll
       for (int e = 0; e < 4; ++e) dk[t][e] = dv[t][e] = 0.f;
-      if (t < Tn) {
-        ldp<T>(base + t * D3 + D, lane, k[t]);
-        ldp<T>(base + t * D3 + 2 * D, lane, v[t]);
+    if constexpr (TN != 0) {
+      RawRow<T> kraw[TN ? TN : 1], vraw[TN ? TN : 1];
+#pragma unroll
+      for (int t = 0; t < TN; ++t) {
+        kraw[t] = ldraw<T>(base + t * D3 + D, lane);
+        vraw[t] = ldraw<T>(base + t * D3 + 2 * D, lane);
+      }
+#pragma unroll
+      for (int t = 0; t < TN; ++t) {
+        qraw[t] = ldraw<T>(base + t * D3, lane);
+        doraw[t] = ldraw<T>(dout + (n * Tn + t) * D + off, lane);
+      }
+#pragma unroll
+      for (int t = 0; t < TN; ++t) {
+        unpack(kraw[t], k[t]);
+        unpack(vraw[t], v[t]);
         if (rot) rope_row<T>(k[t], rope_c, rope_s, t, lane, 1.f, true);
+      }
+    } else {
+#pragma unroll
+      for (int t = 0; t < TK; ++t) {
+        if (t < Tn) {
+          ldp<T>(base + t * D3 + D, lane, k[t]);
+          ldp<T>(base + t * D3 + 2 * D, lane, v[t]);
+          if (rot) rope_row<T>(k[t], rope_c, rope_s, t, lane, 1.f, true);
+        }
       }
     }
 #pragma unroll
     for (int i = 0; i < TK; ++i) {
-      if (i >= Tn) break;
+      if (TN ? i >= TN : i >= Tn) break;
       float q[4], dO[4], dq[4] = {0.f, 0.f, 0.f, 0.f};
-      ldp<T>(base + i * D3, lane, q);
-      ldp<T>(dout + (n * Tn + i) * D + off, lane, dO);
+      if constexpr (TN != 0) {
+        unpack(qraw[i], q);
+        unpack(doraw[i], dO);
+      } else {
+        ldp<T>(base + i * D3, lane, q);
+        ldp<T>(dout + (n * Tn + i) * D + off, lane, dO);
+      }
       if (rot) rope_row<T>(q, rope_c, rope_s, i, lane, 1.f, true);
       float p[TK], dp[TK];
       float mx = -INFINITY;
@@ -228,7 +294,7 @@ __global__ __launch_bounds__(256) void tokattn_bwd_kernel(const T* __restrict__ 
     }
 #pragma unroll
     for (int t = 0; t < TK; ++t) {
-      if (t < Tn) {
+      if (TN ? t < TN : t < Tn) {
         if (rot) rope_row<T>(dk[t], rope_c, rope_s, t, lane, -1.f, false);
         stp<T>(ob + t * D3 + D, lane, dk[t]);
         stp<T>(ob + t * D3 + 2 * D, lane, dv[t]);
@@ -243,8 +309,12 @@ extern "C" int mh_tokattn_fwd(const void* qkv, void* o, int64_t N, int Tn, int H
   const int64_t NH = N * H;
   int64_t g = (NH + 3) / 4;
   if (g > 32768) g = 32768;
-  DISPATCH_T(dtype, (tokattn_fwd_kernel<T><<<(int)g, 256, 0, (hipStream_t)stream>>>((const T*)qkv, (T*)o, NH, Tn, H, scale,
-                                                                                    cos_t, sin_t)));
+  if (Tn == TK)
+    DISPATCH_T(dtype, (tokattn_fwd_kernel<T, TK><<<(int)g, 256, 0, (hipStream_t)stream>>>((const T*)qkv, (T*)o, NH, Tn, H, scale,
+                                                                                          cos_t, sin_t)));
+  else
+    DISPATCH_T(dtype, (tokattn_fwd_kernel<T, 0><<<(int)g, 256, 0, (hipStream_t)stream>>>((const T*)qkv, (T*)o, NH, Tn, H, scale,
+                                                                                         cos_t, sin_t)));
   MH_LAUNCH_CHECK();
   return MH_OK;
 }
@@ -255,8 +325,12 @@ extern "C" int mh_tokattn_bwd(const void* qkv, const void* dout, void* dqkv, int
   const int64_t NH = N * H;
   int64_t g = (NH + 3) / 4;
   if (g > 32768) g = 32768;
-  DISPATCH_T(dtype, (tokattn_bwd_kernel<T><<<(int)g, 256, 0, (hipStream_t)stream>>>((const T*)qkv, (const T*)dout, (T*)dqkv,
-                                                                                    NH, Tn, H, scale, cos_t, sin_t)));
+  if (Tn == TK)
+    DISPATCH_T(dtype, (tokattn_bwd_kernel<T, TK><<<(int)g, 256, 0, (hipStream_t)stream>>>(
+                          (const T*)qkv, (const T*)dout, (T*)dqkv, NH, Tn, H, scale, cos_t, sin_t)));
+  else
+    DISPATCH_T(dtype, (tokattn_bwd_kernel<T, 0><<<(int)g, 256, 0, (hipStream_t)stream>>>(
+                          (const T*)qkv, (const T*)dout, (T*)dqkv, NH, Tn, H, scale, cos_t, sin_t)));
   MH_LAUNCH_CHECK();
   return MH_OK;
 }
