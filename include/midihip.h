@@ -142,12 +142,15 @@ int mh_attn_prep_fwd(const void* qkv, void* vt, int64_t B, int64_t S, int H, int
 int mh_attn_fwd(const void* qkv, const void* vt, void* o, float* lse, int64_t B, int64_t S, int H, float scale,
                 int dtype, void* stream);
 /* backward: dqkv[B*S,3*H*64] <- (qkv, o, do, lse).  scratch: delta[B,H,S] fp32; bf16 additionally
- * qt,kt,dot: [B,H,64,Sp] transposed copies (zero padded) filled by mh_attn_prep_bwd.                  */
+ * qt,kt,dot: [B,H,64,Sp] transposed copies (zero padded) filled by mh_attn_prep_bwd.
+ * cos_t/sin_t (optional, fp32 [>=S, 32]): the q and k thirds of dqkv are returned rotated back (the transpose of
+ * apply_rotary_pos_emb at position = row index within the sequence), i.e. the gradient with respect to the
+ * unrotated projection output -- what mh_rope(dqkv, dir = -1) would make of it in a pass of its own.            */
 int mh_attn_prep_bwd(const void* qkv, const void* o, const void* dout, float* delta, void* qt, void* kt, void* dot,
                      int64_t B, int64_t S, int H, int dtype, void* stream);
 int mh_attn_bwd(const void* qkv, const void* dout, const float* lse, const float* delta, const void* qt,
-                const void* kt, const void* dot, void* dqkv, int64_t B, int64_t S, int H, float scale, int dtype,
-                void* stream);
+                const void* kt, const void* dot, void* dqkv, int64_t B, int64_t S, int H, float scale,
+                const float* cos_t, const float* sin_t, int dtype, void* stream);
 /* NOTE: lse and delta are laid out [B,H,Sp] with Sp = S rounded up to a multiple of 64 (entries past S unused).
  * The *_plain variants run the exact-fp32-math thread-per-row kernels for either dtype; tests use them to
  * cross-check the MFMA kernels on the device.                                                              */

@@ -66,6 +66,37 @@ __device__ inline void stage64(const bf16* __restrict__ base, int64_t ld, int64_
   }
 }
 
+// Store one lane's share of a 64-wide gradient row (acc[hb][16]: elements hb*32 + 16*r8 + 8*hi + e), optionally through
+// the transpose of the RoPE rotation at position `pos` (the gradient with respect to the unrotated projection): the
+// partners d and d + 32 are acc[0][.] and acc[1][.] of the same lane.  Roundings as the separate pass it replaces
+// (mh_rope with dir = -1 on the stored bf16 gradient; cos/sin rounded to bf16, modeling_llama.py:126).
+__device__ inline void store_grad_row(bf16* orow, const f32x16 (&acc)[2], float scale, int hi, const float* cos_t,
+                                      const float* sin_t, int pos) {
+#pragma unroll
+  for (int r8 = 0; r8 < 2; ++r8) {
+    bf16x8 v0, v1;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      v0[e] = (bf16)(acc[0][8 * r8 + e] * scale);
+      v1[e] = (bf16)(acc[1][8 * r8 + e] * scale);
+    }
+    if (cos_t != nullptr) {
+      const int i0 = 16 * r8 + 8 * hi;
+      const f32x4 c0 = *reinterpret_cast<const f32x4*>(cos_t + pos * 32 + i0), c1 = *reinterpret_cast<const f32x4*>(cos_t + pos * 32 + i0 + 4);
+      const f32x4 s0 = *reinterpret_cast<const f32x4*>(sin_t + pos * 32 + i0), s1 = *reinterpret_cast<const f32x4*>(sin_t + pos * 32 + i0 + 4);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const float c = (float)(bf16)(e < 4 ? c0[e] : c1[e - 4]), sn = -(float)(bf16)(e < 4 ? s0[e] : s1[e - 4]);
+        const float x1 = (float)v0[e], x2 = (float)v1[e];
+        v0[e] = (bf16)(x1 * c - x2 * sn);
+        v1[e] = (bf16)(x2 * c + x1 * sn);
+      }
+    }
+    *reinterpret_cast<bf16x8*>(orow + 16 * r8 + 8 * hi) = v0;
+    *reinterpret_cast<bf16x8*>(orow + 32 + 16 * r8 + 8 * hi) = v1;
+  }
+}
+
 // Work assignment.  The dispatcher places workgroup b on XCD b % 8 (each XCD has a private 4 MiB L2), so a 1-D
 // grid is decoded as  xcd = b & 7, i = b >> 3, head = (i / ntile) * 8 + xcd, tile = i % ntile : consecutive
 // workgroups of one XCD walk the tiles of ONE (batch, head) pair, whose K/V (or Q/dO) panels then stay in that
@@ -241,7 +272,9 @@ __device__ inline void dq_tile(const char* tK, const char* tV, const char* tKT, 
 __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const bf16* __restrict__ qkv, const bf16* __restrict__ dout,
                                                              const float* __restrict__ lse, const float* __restrict__ delta,
                                                              const bf16* __restrict__ kt_, bf16* __restrict__ dqkv, int S,
-                                                             int Sp, int H, float scale, int BH, int nqt) {
+                                                             int Sp, int H, float scale, int BH, int nqt,
+                                                             const float* __restrict__ cos_t,
+                                                             const float* __restrict__ sin_t) {
   __shared__ __attribute__((aligned(16))) char smem[6 * TILE64];  // [stage][K | V | K^T]
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -304,15 +337,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const bf16* __restr
   }
   if (qrow < S) {
     bf16* orow = dqkv + (b * S + qrow) * D3 + (int64_t)h * HD;
-#pragma unroll
-    for (int hb = 0; hb < 2; ++hb)
-#pragma unroll
-      for (int r8 = 0; r8 < 2; ++r8) {
-        bf16x8 v;
-#pragma unroll
-        for (int e = 0; e < 8; ++e) v[e] = (bf16)(dqacc[hb][8 * r8 + e] * scale);
-        *reinterpret_cast<bf16x8*>(orow + hb * 32 + 16 * r8 + 8 * hi) = v;
-      }
+    store_grad_row(orow, dqacc, scale, hi, cos_t, sin_t, qrow);
   }
 }
 
@@ -374,7 +399,8 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const bf16* __rest
                                                               const float* __restrict__ lse, const float* __restrict__ delta,
                                                               const bf16* __restrict__ qt_, const bf16* __restrict__ dot_,
                                                               bf16* __restrict__ dqkv, int S, int Sp, int H, float scale,
-                                                              int BH, int nkt) {
+                                                              int BH, int nkt, const float* __restrict__ cos_t,
+                                                              const float* __restrict__ sin_t) {
   __shared__ __attribute__((aligned(16))) char smem[8 * TILE64];  // [stage][Q | dO | Q^T | dO^T]
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -439,19 +465,8 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const bf16* __rest
   }
   if (krow < S) {
     bf16* krow_out = dqkv + (b * S + krow) * D3 + D + (int64_t)h * HD;
-#pragma unroll
-    for (int xb = 0; xb < 2; ++xb)
-#pragma unroll
-      for (int r8 = 0; r8 < 2; ++r8) {
-        bf16x8 vk, vv;
-#pragma unroll
-        for (int e = 0; e < 8; ++e) {
-          vk[e] = (bf16)(dkacc[xb][8 * r8 + e] * scale);
-          vv[e] = (bf16)(dvacc[xb][8 * r8 + e]);
-        }
-        *reinterpret_cast<bf16x8*>(krow_out + xb * 32 + 16 * r8 + 8 * hi) = vk;
-        *reinterpret_cast<bf16x8*>(krow_out + D + xb * 32 + 16 * r8 + 8 * hi) = vv;
-      }
+    store_grad_row(krow_out, dkacc, scale, hi, cos_t, sin_t, krow);
+    store_grad_row(krow_out + D, dvacc, 1.f, hi, nullptr, nullptr, 0);
   }
 }
 
@@ -471,17 +486,17 @@ int mh_attn_fwd_mfma(const void* qkv, const void* vt, void* o, float* lse, int64
 
 int mh_attn_bwd_mfma(const void* qkv, const void* dout, const float* lse, const float* delta, const void* qt,
                      const void* kt, const void* dot, void* dqkv, int64_t B, int64_t S, int H, float scale,
-                     hipStream_t st) {
+                     const float* cos_t, const float* sin_t, hipStream_t st) {
   MH_REQUIRE(qt != nullptr && kt != nullptr && dot != nullptr, "attn_bwd(bf16): needs the transposed copies (mh_attn_prep_bwd)");
   MH_REQUIRE(S < (1 << 24), "attn_bwd: sequence too long");
   const int64_t Sp = (S + 63) / 64 * 64;
   const int nt = (int)((S + 127) / 128), BH = (int)(B * H);
   const unsigned grid = (unsigned)(nt * 8 * ((BH + 7) / 8));
   attn_bwd_dq_kernel<<<grid, 256, 0, st>>>((const bf16*)qkv, (const bf16*)dout, lse, delta, (const bf16*)kt,
-                                           (bf16*)dqkv, (int)S, (int)Sp, H, scale, BH, nt);
+                                           (bf16*)dqkv, (int)S, (int)Sp, H, scale, BH, nt, cos_t, sin_t);
   MH_LAUNCH_CHECK();
   attn_bwd_dkv_kernel<<<grid, 256, 0, st>>>((const bf16*)qkv, (const bf16*)dout, lse, delta, (const bf16*)qt,
-                                            (const bf16*)dot, (bf16*)dqkv, (int)S, (int)Sp, H, scale, BH, nt);
+                                            (const bf16*)dot, (bf16*)dqkv, (int)S, (int)Sp, H, scale, BH, nt, cos_t, sin_t);
   MH_LAUNCH_CHECK();
   return MH_OK;
 }

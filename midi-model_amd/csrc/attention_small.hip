@@ -853,7 +853,8 @@ extern "C" int mh_attn_prep_bwd(const void* qkv, const void* o, const void* dout
 int mh_attn_fwd_mfma(const void* qkv, const void* vt, void* o, float* lse, int64_t B, int64_t S, int H, float scale,
                      hipStream_t st);
 int mh_attn_bwd_mfma(const void* qkv, const void* dout, const float* lse, const float* delta, const void* qt,
-                     const void* kt, const void* dot, void* dqkv, int64_t B, int64_t S, int H, float scale, hipStream_t st);
+                     const void* kt, const void* dot, void* dqkv, int64_t B, int64_t S, int H, float scale,
+                     const float* cos_t, const float* sin_t, hipStream_t st);
 
 template <typename T>
 static int attn_plain_fwd(const void* qkv, void* o, float* lse, int64_t B, int64_t S, int H, float scale, hipStream_t st) {
@@ -897,13 +898,21 @@ extern "C" int mh_attn_fwd(const void* qkv, const void* vt, void* o, float* lse,
   return MH_ERR_ARG;
 }
 
+extern "C" int mh_rope(void* qkv, const float* cos_t, const float* sin_t, int64_t M, int64_t S, int64_t pos0, int H, int hd,
+                       int dir, int dtype, void* stream);  // elementwise.hip
+
 extern "C" int mh_attn_bwd(const void* qkv, const void* dout, const float* lse, const float* delta, const void* qt,
                            const void* kt, const void* dot, void* dqkv, int64_t B, int64_t S, int H, float scale,
-                           int dtype, void* stream) {
+                           const float* cos_t, const float* sin_t, int dtype, void* stream) {
   MH_REQUIRE(B > 0 && S > 0 && H > 0 && B * H < 65536, "attn_bwd: bad shape");
-  if (dtype == MH_BF16)
-    return mh_attn_bwd_mfma(qkv, dout, lse, delta, qt, kt, dot, dqkv, B, S, H, scale, (hipStream_t)stream);
-  if (dtype == MH_F32) return attn_plain_bwd<float>(qkv, dout, lse, delta, dqkv, B, S, H, scale, (hipStream_t)stream);
+  MH_REQUIRE((cos_t == nullptr) == (sin_t == nullptr), "attn_bwd: cos and sin tables come together");
+  if (dtype == MH_BF16)  // (the rotation back rides on the dq / dk stores)
+    return mh_attn_bwd_mfma(qkv, dout, lse, delta, qt, kt, dot, dqkv, B, S, H, scale, cos_t, sin_t, (hipStream_t)stream);
+  if (dtype == MH_F32) {
+    int rc = attn_plain_bwd<float>(qkv, dout, lse, delta, dqkv, B, S, H, scale, (hipStream_t)stream);
+    if (rc == MH_OK && cos_t != nullptr) rc = mh_rope(dqkv, cos_t, sin_t, B * S, S, 0, H, 64, -1, dtype, stream);
+    return rc;
+  }
   mh_set_error("attn_bwd: bad dtype");
   return MH_ERR_ARG;
 }

@@ -186,8 +186,7 @@ def stack_backward(spec: StackSpec, W: StackTensors, G: StackTensors, ctx, dy: t
         linear_wgrad(dx2, o, lg.wo, accumulate)
         dqkv = _empty((M, 3 * D), dy)
         if spec.kind == "event":
-            ops.attn_bwd(qkv, o, do, lse, dqkv, nseq, slen, H, spec.scale)
-            ops.rope_(dqkv, rope.cos, rope.sin, slen, 0, H, spec.hd, -1)
+            ops.attn_bwd(qkv, o, do, lse, dqkv, nseq, slen, H, spec.scale, rope.cos, rope.sin)  # (rotated back in the stores)
         else:  # (saved qkv is unrotated: the forward ran with save=True, never as a prefill)
             ops.tokattn_bwd(qkv, do, dqkv, nseq, slen, H, spec.scale, rope.cos, rope.sin)
         dh1 = do

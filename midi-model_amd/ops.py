@@ -320,7 +320,8 @@ def attn_fwd(qkv, o, lse, B: int, S: int, H: int, scale: float):
     return o
 
 
-def attn_bwd(qkv, o, dout, lse, dqkv, B: int, S: int, H: int, scale: float):
+def attn_bwd(qkv, o, dout, lse, dqkv, B: int, S: int, H: int, scale: float, cos_t=None, sin_t=None):
+    """cos_t/sin_t: return the gradient with respect to the UNROTATED q, k (see mh_attn_bwd)"""
     Sp = round_up(S, 64)
     delta = torch.empty((B * H * Sp,), dtype=torch.float32, device=qkv.device)
     qt = kt = dot = None
@@ -330,7 +331,7 @@ def attn_bwd(qkv, o, dout, lse, dqkv, B: int, S: int, H: int, scale: float):
         qt, kt, dot = buf[0], buf[1], buf[2]
     lib().call("mh_attn_prep_bwd", _p(qkv), _p(o), _p(dout), _p(delta), _p(qt), _p(kt), _p(dot), B, S, H, dt(qkv), _stream())
     lib().call("mh_attn_bwd", _p(qkv), _p(dout), _p(lse), _p(delta), _p(qt), _p(kt), _p(dot), _p(dqkv), B, S, H, scale,
-               dt(qkv), _stream())
+               _p(cos_t), _p(sin_t), dt(qkv), _stream())
     return dqkv
 
 

@@ -217,13 +217,15 @@ def _attn_grads(q, k, v, do, scale):
     return ds @ k, ds.transpose(-1, -2) @ q, dv
 
 
-def attn_bwd(qkv, o, dout, lse, dqkv, B, S, H, scale):
+def attn_bwd(qkv, o, dout, lse, dqkv, B, S, H, scale, cos_t=None, sin_t=None):
     q, k, v = _split(qkv, B, S, H, 64)
     do = dout.float().view(B, S, H, 64).transpose(1, 2)
     dq, dk, dv = _attn_grads(q, k, v, do, scale)
     D = H * 64
     for i, t in enumerate((dq, dk, dv)):
         dqkv[:, i * D:(i + 1) * D] = t.transpose(1, 2).reshape(B * S, D).to(dqkv.dtype)
+    if cos_t is not None:
+        rope_(dqkv, cos_t, sin_t, S, 0, H, 64, -1)
     return dqkv
 
 

@@ -293,6 +293,16 @@ def test_attention_fwd_bwd(ops, dtype, B, S, H):
     ops.attn_bwd(qkv.cuda(), o, do.cuda(), lse, dqkv, B, S, H, scale)
     for i, nm in enumerate(("dq", "dk", "dv")):
         cmp(dqkv[:, i * D:(i + 1) * D], dq_ref[:, i * D:(i + 1) * D], dtype, k=3, what=f"attn {nm}")
+    # rotation back fused into the dq / dk stores == a separate mh_rope(dir = -1) pass over the result
+    from midi_model_amd.engine import RopeTable
+    tab = RopeTable(64, 10000.0, "cuda", S)
+    want = ops.rope_(dqkv.clone(), tab.cos, tab.sin, S, 0, H, 64, -1)
+    got = torch.full((B * S, 3 * D), float("nan"), dtype=dtype, device="cuda")
+    ops.attn_bwd(qkv.cuda(), o, do.cuda(), lse, got, B, S, H, scale, tab.cos, tab.sin)
+    assert torch.equal(got[:, 2 * D:], dqkv[:, 2 * D:])
+    cmp(got, want.cpu(), dtype, k=2, what="attn bwd + rotation back")
+    same = (got == want).float().mean().item()
+    assert same > 0.99, f"fused rotation agrees with the separate pass on only {same:.4f} of the elements"
 
 
 def test_attention_mfma_vs_plain_on_device(ops):
