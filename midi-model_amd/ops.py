@@ -131,12 +131,12 @@ def gemm_nt(a: torch.Tensor, b: torch.Tensor, out: torch.Tensor, *, K: Optional[
     return out
 
 
-_FUSE_SWIGLU = int(os.environ.get("MH_FUSE_SWIGLU", "3"))  # bit 0: forward, bit 1: backward fusion (A/B measurements)
+_FUSE = int(os.environ.get("MH_FUSE_EPILOGUES", "3"))  # bit 0: SwiGLU forward, bit 1: SwiGLU backward in the GEMM epilogue (A/B runs)
 
 
 def swiglu_fused_ok(x: torch.Tensor, I: int) -> bool:
     """whether mh_gemm_swiglu serves the gate|up projection + SwiGLU (else mh_gemm, then mh_swiglu_fwd)"""
-    return x.dtype == torch.bfloat16 and I % 128 == 0 and get_option("gemm") != 0 and (_FUSE_SWIGLU & 1) != 0
+    return x.dtype == torch.bfloat16 and I % 128 == 0 and get_option("gemm") != 0 and (_FUSE & 1) != 0
 
 
 def gemm_swiglu(x: torch.Tensor, wgu: torch.Tensor, gu: torch.Tensor, a: torch.Tensor) -> torch.Tensor:
@@ -158,7 +158,7 @@ def gemm_swiglu(x: torch.Tensor, wgu: torch.Tensor, gu: torch.Tensor, a: torch.T
 
 def dswiglu_ok(dx: torch.Tensor, I: int) -> bool:
     """whether mh_gemm_dswiglu serves down_proj's dgrad + SwiGLU backward (else mh_gemm, then mh_swiglu_bwd)"""
-    return dx.dtype == torch.bfloat16 and I % 8 == 0 and get_option("gemm") != 0 and (_FUSE_SWIGLU & 2) != 0
+    return dx.dtype == torch.bfloat16 and I % 8 == 0 and get_option("gemm") != 0 and (_FUSE & 2) != 0
 
 
 def gemm_dswiglu(dx: torch.Tensor, wd: torch.Tensor, gu: torch.Tensor, dgu: torch.Tensor) -> torch.Tensor:
