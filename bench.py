@@ -283,13 +283,18 @@ def main():
             for e0, e1, f, shp in prof:
                 t_, f_, n_ = by_shape.get(shp, (0.0, 0.0, 0))
                 by_shape[shp] = (t_ + e0.elapsed_time(e1), f_ + f, n_ + 1)
-            print("[bench] GEMM launches by shape (M,N,K,splitk,transA,transB): calls, total ms, TFLOP/s", file=sys.stderr)
+            plain = [(e0.elapsed_time(e1), f) for e0, e1, f, shp in prof if len(shp) == 6]  # no elementwise work in the epilogue
+            print("[bench] GEMM launches by shape (M,N,K,splitk,transA,transB[,fused epilogue]): calls, total ms, TFLOP/s", file=sys.stderr)
             for shp, (t_, f_, n_) in sorted(by_shape.items(), key=lambda kv: -kv[1][0]):
                 print(f"[bench]   {shp}: {n_:4d} {t_:9.3f} {f_ / (t_ * 1e-3) / 1e12:8.1f}", file=sys.stderr)
             out["roofline"] = {"bound": "mfma", "kernel": "gemm_pp256_kernel (all projection GEMMs: fwd, dgrad, wgrad, lm_head)",
                                "achieved": ach, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": ach / PEAK_BF16_TFLOPS,
                                "traffic": None, "launches": n, "avg_launch_us": 1e3 * ms / n,
-                               "avg_flops_per_launch": fl / n, "gemm_share_of_step_time": ms * 1e-3 / dt}
+                               "avg_flops_per_launch": fl / n, "gemm_share_of_step_time": ms * 1e-3 / dt,
+                               # the same ratio over the launches whose epilogue carries no SwiGLU forward / backward
+                               "achieved_plain_epilogue": (sum(f for _, f in plain) / (sum(t for t, _ in plain) * 1e-3) / 1e12
+                                                           if plain else None),
+                               "launches_plain_epilogue": len(plain)}
         if world == 1 and not args.no_cpu_baseline:
             try:
                 out["cpu_baseline"] = cpu_baseline(args.cpu_sample_seq)

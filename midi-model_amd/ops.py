@@ -152,7 +152,7 @@ def gemm_swiglu(x: torch.Tensor, wgu: torch.Tensor, gu: torch.Tensor, a: torch.T
                M, I, K, dt(x), _stream())
     if prof is not None:
         e1.record()
-        prof.append((e0, e1, 2.0 * M * 2 * I * K, (M, 2 * I, K, 1, 0, 0)))
+        prof.append((e0, e1, 2.0 * M * 2 * I * K, (M, 2 * I, K, 1, 0, 0, "+swiglu")))
     return a
 
 
@@ -175,7 +175,7 @@ def gemm_dswiglu(dx: torch.Tensor, wd: torch.Tensor, gu: torch.Tensor, dgu: torc
                M, I, K, dt(dx), _stream())
     if prof is not None:
         e1.record()
-        prof.append((e0, e1, 2.0 * M * I * K, (M, I, K, 1, 0, 1)))
+        prof.append((e0, e1, 2.0 * M * I * K, (M, I, K, 1, 0, 1, "+dswiglu")))
     return dgu
 
 
