@@ -118,6 +118,7 @@ class TrainMIDIModel(MIDIModel):
         self._reducer = None
         self.last_grad_norm = None
         self.process_group = None
+        self._lora = None          # LoraAdapter while fine-tuning adapters on a frozen base (add_adapter)
 
     # ----------------------------------------------------------------------------------- optimiser
     def configure_optimizers(self):
@@ -141,6 +142,8 @@ class TrainMIDIModel(MIDIModel):
 
     def optimizer_step(self):
         """clip_grad_norm_(1.0) -> AdamW -> scheduler.step(), all on device (no host sync)."""
+        if self._lora is not None:
+            return self._lora_optimizer_step()
         if self._opt is None:
             self.configure_optimizers()
         if self._reducer is not None:
@@ -166,6 +169,66 @@ class TrainMIDIModel(MIDIModel):
         self.global_step += 1
         self._micro = 0
 
+    # ------------------------------------------------------------------------------------- LoRA
+    def add_adapter(self, lora_config=None, **kwargs):
+        """train.py:439-449: ``model.requires_grad_(False); model.add_adapter(LoraConfig(r=64, lora_alpha=128,
+        target_modules=[q,o,k,v,gate,up,down], lora_dropout=0))``.  Accepts a config object with those attributes (peft's
+        LoraConfig), a dict, or keyword arguments.  From here on training_step / optimizer_step update the adapters only;
+        the base weights stay as loaded (lora.py)."""
+        from .lora import DEFAULT_TARGETS, LoraAdapter
+        self._require_gpu()
+        cfg = dict(r=64, lora_alpha=128, target_modules=DEFAULT_TARGETS, lora_dropout=0.0)
+        src = lora_config if isinstance(lora_config, dict) else (
+            {k: getattr(lora_config, k) for k in cfg if hasattr(lora_config, k)} if lora_config is not None else {})
+        cfg.update({k: v for k, v in src.items() if k in cfg and v is not None})
+        cfg.update({k: v for k, v in kwargs.items() if k in cfg})
+        if self._lora is not None:
+            raise RuntimeError("an adapter is already attached (merge_and_unload() first)")
+        self.requires_grad_(False)
+        self._lora = LoraAdapter(self, cfg["r"], cfg["lora_alpha"], tuple(cfg["target_modules"]), cfg["lora_dropout"],
+                                 kwargs.get("generator"))
+        self._micro = 0
+        return self._lora
+
+    def save_adapter(self, directory: str) -> None:
+        """adapter_config.json + adapter_model.safetensors in peft's layout (readable by MIDIModel.load_merge_lora)"""
+        if self._lora is None:
+            raise RuntimeError("no adapter attached")
+        self._lora.save(directory)
+
+    def merge_and_unload(self):
+        """fold the adapter into the weights (W <- W + scale * B @ A) and drop it; returns self"""
+        if self._lora is not None:
+            self._lora.materialize(self)
+            self._lora = None
+            self.requires_grad_(True)
+        return self
+
+    def _lora_optimizer_step(self):
+        import torch.distributed as dist
+        lo = self._lora
+        lo.compute_grads(self)
+        if dist.is_available() and dist.is_initialized() and dist.get_world_size(self.process_group) > 1:
+            lo.grad.div_(dist.get_world_size(self.process_group))
+            dist.all_reduce(lo.grad, group=self.process_group)
+        o = lo.optimizer_state()
+        if self.gradient_clip_val is not None and self.gradient_clip_val > 0:
+            ops.sumsq(lo.grad, o["partial"], o["sumsq"], False)
+            ops.clip_coef(o["sumsq"], float(self.gradient_clip_val), o["coef"], o["norm"])
+            self.last_grad_norm = o["norm"]
+            coef = o["coef"]
+        else:
+            coef = None
+        lr = self.current_lr()
+        step = self.global_step + 1
+        bc1, bc2 = 1.0 - self.betas[0] ** step, 1.0 - self.betas[1] ** step
+        # (names lora_A / lora_B contain neither "bias" nor "norm": weight decay applies, train.py:121-151)
+        ops.adamw(lo.flat, lo.grad, o["m"], o["v"], lr, self.betas[0], self.betas[1], self.eps, self.weight_decay,
+                  bc1, bc2, coef)
+        lo.dirty = True
+        self.global_step += 1
+        self._micro = 0
+
     def zero_grad(self, set_to_none: bool = False):
         if self._flat_grad is not None:
             self._flat_grad.zero_()
@@ -175,6 +238,8 @@ class TrainMIDIModel(MIDIModel):
     def _loss_and_backward(self, batch: torch.Tensor, backward: bool, want_acc: bool = False):
         """train.py:168-188 (+ its backward).  batch (B, S+1, 8) int64.  Returns (loss[1] fp32 device tensor, acc)."""
         self._require_gpu()
+        if self._lora is not None and self._lora.dirty:
+            self._lora.materialize(self)  # live weights <- base + scale * B @ A
         tok = self.tokenizer
         dev, dty = self.device, self.dtype
         batch = batch.to(device=dev, dtype=torch.long)
@@ -299,6 +364,8 @@ class TrainMIDIModel(MIDIModel):
     def _reducer_for_step(self):
         import torch.distributed as dist
         if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(self.process_group) == 1:
+            return None
+        if self._lora is not None:  # only the adapter gradients are exchanged (in optimizer_step)
             return None
         # exchange only on the micro-batch that completes an accumulation window (DDP no_sync otherwise)
         if (self._micro + 1) % max(1, self.accumulate_grad_batches) != 0:

@@ -287,3 +287,74 @@ def test_load_merge_lora(tmp_path, tiny):
             assert torch.allclose(v, ref, atol=1e-6), k
         with pytest.raises(FileNotFoundError):
             model.load_merge_lora("skytnt/some-hub-id")
+
+
+def test_lora_training_step_matches_autograd(orc, tiny, tok, tmp_path):
+    """train.py:439-449 (task lora): frozen base + rank-r adapters.  The fused step's adapter gradients equal autograd
+    through the oracle on W + (alpha / r) B A; clip + AdamW touch the adapters only; the saved adapter merges back
+    (midi_model.py:109-114) into the same effective weights."""
+    shp, sd, batch = tiny
+    r, alpha = 8, 16.0
+    s = alpha / r
+    with emu_ops.install():
+        model = TrainMIDIModel(tiny_config(), lr=1e-2, warmup=0, max_step=100, accumulate_grad_batches=1, weight_decay=0.01)
+        model.load_state_dict(sd)
+        lo = model.add_adapter({"r": r, "lora_alpha": alpha}, generator=torch.Generator().manual_seed(5))
+        assert len(lo.targets) == 7 * (4 + 1) and not any(p.requires_grad for p in model.parameters())
+        g = torch.Generator().manual_seed(6)
+        for name in lo.B:  # B = 0 would leave dA = 0: give the adapters something to do
+            lo.B[name].copy_(torch.randn(lo.B[name].shape, generator=g) * 0.05)
+        lo.dirty = True
+        A0 = {k: v.clone() for k, v in lo.A.items()}
+        B0 = {k: v.clone() for k, v in lo.B.items()}
+        loss = model.training_step(batch)
+
+        # autograd through the oracle on the effective weights
+        A = {k: v.clone().requires_grad_(True) for k, v in A0.items()}
+        B = {k: v.clone().requires_grad_(True) for k, v in B0.items()}
+        sd_eff = dict(sd)
+        for name in A:
+            sd_eff[name + ".weight"] = sd[name + ".weight"] + s * (B[name] @ A[name])
+        ref_loss, _ = orc.training_loss(sd_eff, shp, batch, tok.pad_id)
+        ref_loss.backward()
+        assert abs(loss.item() - ref_loss.item()) < 3e-5
+        lo.compute_grads(model)
+        for name in A:
+            np.testing.assert_allclose(lo.gA[name].numpy(), A[name].grad.numpy(), rtol=2e-3, atol=2e-7, err_msg=name)
+            np.testing.assert_allclose(lo.gB[name].numpy(), B[name].grad.numpy(), rtol=2e-3, atol=2e-7, err_msg=name)
+
+        # optimiser step: clip_grad_norm_(1.0) + AdamW(lr, (0.9, 0.99), 1e-8, wd) over the adapter parameters only
+        params = [p for d in (A, B) for p in d.values()]
+        opt = torch.optim.AdamW(params, lr=model.current_lr(), betas=(0.9, 0.99), eps=1e-8, weight_decay=0.01)
+        gn = torch.nn.utils.clip_grad_norm_(params, 1.0)
+        opt.step()
+        base_before = {k: v.clone() for k, v in model.state_dict().items()}
+        model.optimizer_step()
+        assert abs(model.last_grad_norm.item() - gn.item()) < 1e-3 * gn.item() and model.global_step == 1
+        for name in A:  # (the first AdamW step is lr * g / (|g| + eps): elements with |g| ~ eps amplify fp32 noise)
+            for got, want in ((lo.A[name], A[name].detach()), (lo.B[name], B[name].detach())):
+                d = (got - want).abs()
+                assert d.max().item() < 1e-2 * 0.1 and (d < 1e-6 + 1e-4 * want.abs()).float().mean().item() > 0.99, name
+
+        # the next step runs on the updated effective weights; everything that is not a target stays as loaded
+        loss2 = model.training_step(batch)
+        after = model.state_dict()
+        targets = {name + ".weight" for name in A}
+        for k, v in after.items():
+            if k in targets:
+                want = sd[k] + s * (lo.B[k[:-7]] @ lo.A[k[:-7]])
+                assert torch.allclose(v, want, atol=1e-6), k
+            else:
+                assert torch.equal(v, sd[k].to(v.dtype)), k
+        assert loss2.item() < loss.item()
+
+        # save -> merge into a fresh base model (midi_model.py:109-114) == the trained effective weights
+        model.save_adapter(str(tmp_path / "adapter"))
+        fresh = mm.MIDIModel(tiny_config())
+        fresh.load_state_dict(sd)
+        fresh.load_merge_lora(str(tmp_path / "adapter"))
+        for k, v in fresh.state_dict().items():
+            assert torch.allclose(v, after[k], atol=1e-6), k
+        assert model.merge_and_unload() is model and model._lora is None
+        with pytest.raises(NotImplementedError):
+            model.add_adapter(r=8, lora_dropout=0.1)

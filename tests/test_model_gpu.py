@@ -323,3 +323,56 @@ def test_concurrent_generators_on_one_model(tiny, tok):
     assert not errs, errs
     for i in range(2):
         assert (got[i] == want[i]).all()
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_lora_training_on_device(orc, tiny, tok, tmp_path, dtype):
+    """train.py:439-449: adapters on a frozen base.  fp32: adapter gradients equal autograd through the oracle on
+    W + (alpha / r) B A.  Both dtypes: a few optimiser steps lower the loss, nothing but the targeted weights moves,
+    and the saved adapter merges (midi_model.py:109-114) into the trained effective weights."""
+    shp, sd, batch = tiny
+    r, alpha = 8, 16.0
+    s = alpha / r
+    model = build(TrainMIDIModel, tiny_config(), sd, dtype, lr=5e-3, warmup=0, max_step=100, accumulate_grad_batches=1)
+    lo = model.add_adapter(r=r, lora_alpha=alpha, generator=torch.Generator().manual_seed(5))
+    g = torch.Generator().manual_seed(6)
+    for name in lo.B:
+        lo.B[name].copy_((torch.randn(lo.B[name].shape, generator=g) * 0.05).to(lo.B[name]))
+    lo.dirty = True
+    A0 = {k: v.float().cpu() for k, v in lo.A.items()}
+    B0 = {k: v.float().cpu() for k, v in lo.B.items()}
+    loss = model.training_step(batch)
+    if dtype == torch.float32:
+        A = {k: v.clone().requires_grad_(True) for k, v in A0.items()}
+        B = {k: v.clone().requires_grad_(True) for k, v in B0.items()}
+        sd_eff = dict(sd)
+        for name in A:
+            sd_eff[name + ".weight"] = sd[name + ".weight"] + s * (B[name] @ A[name])
+        ref_loss, _ = orc.training_loss(sd_eff, shp, batch, tok.pad_id)
+        ref_loss.backward()
+        assert abs(loss.item() - ref_loss.item()) < 1e-4
+        lo.compute_grads(model)
+        for name in A:
+            np.testing.assert_allclose(lo.gA[name].cpu().numpy(), A[name].grad.numpy(), rtol=5e-3, atol=1e-6, err_msg=name)
+            np.testing.assert_allclose(lo.gB[name].cpu().numpy(), B[name].grad.numpy(), rtol=5e-3, atol=1e-6, err_msg=name)
+    losses = [loss.item()]
+    model.optimizer_step()
+    for _ in range(4):
+        losses.append(model.fit_step(batch).item())
+    assert losses[-1] < losses[0] - 0.01, losses
+    model.training_step(batch)  # (materialises the latest adapters)
+    after = {k: v.float().cpu() for k, v in model.state_dict().items()}
+    targets = {name + ".weight" for name in lo.A}
+    tol = 1e-5 if dtype == torch.float32 else 2e-2
+    for k, v in after.items():
+        ref = sd[k].to(dtype).float()
+        if k in targets:
+            ref = ref + s * (lo.B[k[:-7]].float().cpu() @ lo.A[k[:-7]].float().cpu())
+            assert torch.allclose(v, ref, atol=tol), k
+        else:
+            assert torch.equal(v, ref), k
+    model.save_adapter(str(tmp_path / "adapter"))
+    fresh = build(mm.MIDIModel, tiny_config(), sd, dtype)
+    fresh.load_merge_lora(str(tmp_path / "adapter"))
+    for k, v in fresh.state_dict().items():
+        assert torch.allclose(v.float().cpu(), after[k], atol=tol), k
