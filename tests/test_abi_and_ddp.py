@@ -81,9 +81,22 @@ def _worker(rank, world, port, out_dir):
         g_avg = model.grad_buffer().clone()
         model.optimizer_step()
         vloss, vacc = model.validation_step(batches[0])
+        # LoRA on the same ranks (train.py:439-449): only the adapter gradients are exchanged, in optimizer_step
+        lora = TrainMIDIModel(cfg, lr=1e-2, warmup=0, accumulate_grad_batches=1)
+        lora.load_state_dict(sd)
+        lo = lora.add_adapter(r=8, lora_alpha=16, generator=torch.Generator().manual_seed(3))
+        for name in lo.B:
+            lo.B[name].fill_(0.01)
+        lo.dirty = True
+        lora.training_step(batches[0])
+        assert lora._reducer is None
+        lo.compute_grads(lora)
+        lg_local = lo.grad.clone()
+        lora.optimizer_step()
         np.savez(os.path.join(out_dir, f"rank{rank}.npz"), g_local=g_local.numpy(), g_avg=g_avg.numpy(),
                  flat=model._flat.detach().numpy(), n_buckets=n_buckets, vloss=vloss.numpy(), vacc=float(vacc),
-                 losses=np.array([l0.item(), l1.item()]))
+                 losses=np.array([l0.item(), l1.item()]), lora_g_local=lg_local.numpy(), lora_g=lo.grad.numpy(),
+                 lora_flat=lo.flat.numpy())
     dist.destroy_process_group()
 
 
@@ -115,3 +128,8 @@ def test_ddp_world2_gloo(tmp_path, orc):
     np.testing.assert_array_equal(r0["flat"], r1["flat"])
     np.testing.assert_array_equal(r0["vloss"], r1["vloss"])
     assert float(r0["vacc"]) == float(r1["vacc"])
+    # LoRA: local adapter gradients differ, the exchanged ones are their mean, the adapters stay in step
+    assert not np.allclose(r0["lora_g_local"], r1["lora_g_local"])
+    np.testing.assert_array_equal(r0["lora_g"], r1["lora_g"])
+    np.testing.assert_allclose(r0["lora_g"], (r0["lora_g_local"] + r1["lora_g_local"]) / 2, rtol=1e-5, atol=1e-8)
+    np.testing.assert_array_equal(r0["lora_flat"], r1["lora_flat"])
