@@ -116,8 +116,8 @@ extern "C" int mh_embed_scatter_bwd(const int64_t* tok, int64_t ldtok, int T_, c
 
 // Segment form of the same gradient (the production path): the token occurrences are pre-sorted by token id
 // (src[i] = row of `dout` that occurrence i reads, seg[v]..seg[v+1] = the occurrences of id v).  The sorted list is cut
-// into equal pieces of 32 occurrences per wave, whatever ids they belong to: a wave looks up its 32 (row, id) pairs with
-// one coalesced load and a binary search in `seg`, then streams the rows four at a time with 16-byte loads, summing in
+// into equal pieces of 128 occurrences per wave, whatever ids they belong to: a wave looks up 64 (row, id) pairs at a time
+// with one coalesced load and a binary search in `seg`, then streams the rows four at a time with 16-byte loads, summing in
 // registers while the id stays the same and adding the run to the fp32 table when it changes (one atomic per element per
 // run; the scatter form needs one per occurrence and serialises ~29k of them on the row of the ubiquitous "note" id).
 // Equal pieces matter: with one block per id the 29.5k rows of "note" were a serial chain of dependent index -> row
@@ -129,24 +129,10 @@ __global__ __launch_bounds__(256) void embed_segment_bwd_kernel(const int64_t* _
                                                                 float* __restrict__ dtab, int V, int D, int64_t n_occ,
                                                                 int pad_id) {
   constexpr int N = Pack<T>::N;
-  constexpr int RW = 32, G = 4;  // occurrences per wave, rows in flight
+  constexpr int RW = 64, NPASS = 2, G = 4;  // occurrences per pass (one per lane), passes per wave, rows in flight
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-  const int64_t p0 = ((int64_t)blockIdx.x * 4 + wv) * RW;
-  if (p0 >= n_occ) return;
-  const int cnt = (n_occ - p0 < RW) ? (int)(n_occ - p0) : RW;
-  int row_lo = 0, row_hi = 0, my_id = -1;
-  if (lane < cnt) {
-    const int64_t p = p0 + lane;
-    const int64_t r = src[p];
-    row_lo = (int)(uint32_t)r;
-    row_hi = (int)(r >> 32);
-    int lo = 0, hi = V;  // seg[lo] <= p < seg[hi]: the largest v with seg[v] <= p owns occurrence p
-    while (hi - lo > 1) {
-      const int mid = (lo + hi) >> 1;
-      if (seg[mid] <= p) lo = mid; else hi = mid;
-    }
-    my_id = lo;
-  }
+  const int64_t w0 = ((int64_t)blockIdx.x * 4 + wv) * (RW * NPASS);
+  if (w0 >= n_occ) return;
   float acc[NCH][N];
 #pragma unroll
   for (int ch = 0; ch < NCH; ++ch)
@@ -167,6 +153,24 @@ __global__ __launch_bounds__(256) void embed_segment_bwd_kernel(const int64_t* _
       }
     }
   };
+#pragma unroll 1
+  for (int pass = 0; pass < NPASS; ++pass) {
+  const int64_t p0 = w0 + pass * RW;
+  if (p0 >= n_occ) break;
+  const int cnt = (n_occ - p0 < RW) ? (int)(n_occ - p0) : RW;
+  int row_lo = 0, row_hi = 0, my_id = -1;
+  if (lane < cnt) {
+    const int64_t p = p0 + lane;
+    const int64_t r = src[p];
+    row_lo = (int)(uint32_t)r;
+    row_hi = (int)(r >> 32);
+    int lo = 0, hi = V;  // seg[lo] <= p < seg[hi]: the largest v with seg[v] <= p owns occurrence p
+    while (hi - lo > 1) {
+      const int mid = (lo + hi) >> 1;
+      if (seg[mid] <= p) lo = mid; else hi = mid;
+    }
+    my_id = lo;
+  }
 #pragma unroll
   for (int j0 = 0; j0 < RW; j0 += G) {
     if (j0 < cnt) {  // (wave-uniform)
@@ -203,6 +207,7 @@ __global__ __launch_bounds__(256) void embed_segment_bwd_kernel(const int64_t* _
       }
     }
   }
+  }
   if (cur >= 0) flush();
 }
 
@@ -212,7 +217,7 @@ extern "C" int mh_embed_segment_bwd(const int64_t* src_rows, const int64_t* seg_
   MH_REQUIRE(V > 0 && V < (1 << 30) && D % 8 == 0 && D <= 4096 && n_occ >= 0, "embed_segment_bwd: bad args");
   MH_REQUIRE(dtype != MH_F32 || D <= 2048, "embed_segment_bwd: fp32 supports D <= 2048");
   if (n_occ == 0) return MH_OK;
-  const int64_t nblk = (n_occ + 127) / 128;
+  const int64_t nblk = (n_occ + 511) / 512;  // 4 waves x 128 occurrences
   MH_REQUIRE(nblk < (1ll << 31), "embed_segment_bwd: too many occurrences");
   const int per = 64 * (dtype == MH_F32 ? 4 : 8);
   const int nch = (D + per - 1) / per;
