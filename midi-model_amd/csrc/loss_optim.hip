@@ -79,14 +79,23 @@ __global__ __launch_bounds__(256) void cross_entropy_vec_kernel(const bf16* logi
   const int lane = threadIdx.x & 63;
   const float scale = (dlogits != nullptr && scale_dev != nullptr) ? scale_dev[0] : 1.f;
   const int nchunk = (int)(ldl / 8);
-  for (int64_t r = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); r < R; r += (int64_t)gridDim.x * 4) {
+  // the next row of the wave is requested before the current one is worked on (two rows of loads in flight per wave: the
+  // kernel holds ~200 VGPRs, i.e. 8 waves per CU, and one 6.9 KB row each did not cover the HBM latency: 2.4 TB/s)
+  auto load_row = [&](int64_t r, bf16x8 (&dst)[NCH]) {
     const bf16* row = logits + r * ldl;
-    bf16x8 v[NCH];
 #pragma unroll
-    for (int k = 0; k < NCH; ++k) {
+    for (int k = 0; k < NCH; ++k) {  // (chunks past the row re-read chunk 0: unconditional loads, their columns are >= V)
       const int ch = k * 64 + lane;
-      if (ch < nchunk) v[k] = *reinterpret_cast<const bf16x8*>(row + ch * 8);
+      dst[k] = *reinterpret_cast<const bf16x8*>(row + (ch < nchunk ? ch : 0) * 8);
     }
+  };
+  const int64_t rstep = (int64_t)gridDim.x * 4;
+  int64_t r = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  bf16x8 v[NCH], vn[NCH];
+  if (r < R) load_row(r, v);
+  for (; r < R; r += rstep) {
+    const bf16* row = logits + r * ldl;
+    if (r + rstep < R) load_row(r + rstep, vn);
     float mx = -INFINITY;
     int amax = 0x7fffffff;
 #pragma unroll
@@ -147,6 +156,8 @@ __global__ __launch_bounds__(256) void cross_entropy_vec_kernel(const bf16* logi
         }
       }
     }
+#pragma unroll
+    for (int k = 0; k < NCH; ++k) v[k] = vn[k];
   }
 }
 
@@ -158,6 +169,7 @@ extern "C" int mh_cross_entropy(const void* logits, int64_t ldl, const int64_t* 
   if (g > 65536) g = 65536;
   const bool vec = dtype == MH_BF16 && ldl % 8 == 0 && ldl <= 4096 && ((uintptr_t)logits & 15) == 0 &&
                    (dlogits == nullptr || ((uintptr_t)dlogits & 15) == 0);
+  if (vec && g > 512) g = 512;  // two resident blocks per CU, every wave walks ~R / 2048 rows with the next one prefetched
   if (vec && ldl > 3584) {
     cross_entropy_vec_kernel<8><<<(int)g, 256, 0, (hipStream_t)stream>>>((const bf16*)logits, ldl, target, row_loss,
                                                                          (bf16*)dlogits, scale_dev, argmax_out, R, V, ignore);
