@@ -18,7 +18,7 @@ agg = collections.defaultdict(lambda: collections.defaultdict(float))
 cnt = collections.defaultdict(set)
 for n in (0, 1):
     for r in csv.DictReader(open(f"/tmp/pmcb_{n}/pmc_counter_collection.csv")):
-        k = r["Kernel_Name"].split("(")[0][:70]
+        k = r["Kernel_Name"].replace("(anonymous namespace)::", "").replace("void ", "").split("(")[0][:70]
         agg[k][r["Counter_Name"]] += float(r["Counter_Value"])
         cnt[k].add(r["Dispatch_Id"])
 print("# per kernel over bench.py --steps 1 --warmup 1 (2 steps): dispatches, FETCH_SIZE KiB (x2 for 16-B/lane streams on gfx950), WRITE_SIZE KiB, L2 hit rate")
