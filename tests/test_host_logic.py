@@ -358,3 +358,32 @@ def test_lora_training_step_matches_autograd(orc, tiny, tok, tmp_path):
         assert model.merge_and_unload() is model and model._lora is None
         with pytest.raises(NotImplementedError):
             model.add_adapter(r=8, lora_dropout=0.1)
+
+
+def test_sample_seq_training_step(orc, tiny, tok):
+    """train.py:172-175 (--sample-seq): the token-level stack and the loss see the last position + random others; the
+    gradient of the sampled hidden states scatters back to their positions."""
+    import random
+    shp, sd, _ = tiny
+    batch = orc.synthetic_events(tok, 2, 21, seed=31)
+    with emu_ops.install():
+        model = TrainMIDIModel(tiny_config(), sample_seq=True, accumulate_grad_batches=1)
+        model.load_state_dict(sd)
+        random.seed(1234)
+        loss = model.training_step(batch)
+    # the reference's lines, restated on the oracle with the same draw
+    random.seed(1234)
+    x, y = batch[:, :-1], batch[:, 1:]
+    idx = [-1] + random.sample(list(range(y.shape[1] - 2)), min(127, (y.shape[1] - 2) // 2))
+    sdg = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    hidden = orc.midi_forward(sdg, shp, x)[:, idx].reshape(-1, shp.n_embd)
+    ys = y[:, idx].reshape(-1, y.shape[-1])
+    logits = orc.midi_forward_token(sdg, shp, hidden, ys[:, :-1])
+    ref = torch.nn.functional.cross_entropy(logits.reshape(-1, shp.vocab), ys.reshape(-1), reduction="mean",
+                                            ignore_index=tok.pad_id)
+    ref.backward()
+    assert abs(loss.item() - ref.item()) < 3e-5
+    named = dict(model.named_parameters())
+    for k in ("net.embed_tokens.weight", "net.layers.0.self_attn.q_proj.weight", "net.layers.3.mlp.down_proj.weight",
+              "net_token.layers.0.mlp.gate_proj.weight", "net.norm.weight", "lm_head.weight"):
+        np.testing.assert_allclose(named[k].grad.numpy(), sdg[k].grad.numpy(), rtol=3e-3, atol=3e-7, err_msg=k)
