@@ -374,7 +374,8 @@ def test_swiglu(ops, dtype):
 
 # ------------------------------------------------------------------------------------- loss, optimiser
 @pytest.mark.parametrize("dtype", DTYPES)
-@pytest.mark.parametrize("R,V,Vp", [(531, 3406, 3456), (100, 1000, 1024), (64, 500, 508), (33, 4000, 4096)])
+@pytest.mark.parametrize("R,V,Vp", [(531, 3406, 3456), (100, 1000, 1024), (64, 500, 508), (33, 4000, 4096),
+                                    (5003, 3406, 3456)])  # (the last: several rows per wave, next row prefetched)
 def test_cross_entropy(ops, dtype, R, V, Vp):
     g = torch.Generator().manual_seed(26)
     logits = torch.zeros((R, Vp), dtype=dtype)
