@@ -23,7 +23,7 @@ static inline int grid_for(int64_t items, int per_block, int cap = 1 << 20) {
 // one wave per event row: out[m,:] = sum_j table[tok[m,j],:]
 template <typename T>
 __global__ __launch_bounds__(256) void embed_sum_fwd_kernel(const int64_t* __restrict__ tok, const T* __restrict__ table,
-                                                            T* __restrict__ out, int64_t M, int TT, int D) {
+                                                            T* __restrict__ out, int64_t M, int TT, int D, int64_t V) {
   constexpr int N = Pack<T>::N;
   const int lane = threadIdx.x & 63;
   const int64_t wave0 = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -34,6 +34,7 @@ __global__ __launch_bounds__(256) void embed_sum_fwd_kernel(const int64_t* __res
       for (int e = 0; e < N; ++e) acc[e] = 0.f;
       for (int j = 0; j < TT; ++j) {
         const int64_t id = tok[m * TT + j];
+        if ((uint64_t)id >= (uint64_t)V) __builtin_trap();  // torch's embedding raises a device assert here; never read out of bounds
         Pack<T> v = ld16(table + id * D + c);
 #pragma unroll
         for (int e = 0; e < N; ++e) acc[e] += v.get(e);
@@ -50,7 +51,7 @@ extern "C" int mh_embed_sum_fwd(const int64_t* tok, const void* table, void* out
                                 int dtype, void* stream) {
   MH_REQUIRE(M > 0 && T_ > 0 && D % 8 == 0, "embed_sum_fwd: bad shape M=%ld T=%d D=%d", (long)M, T_, D);
   DISPATCH_T(dtype, (embed_sum_fwd_kernel<T><<<grid_for(M, 4, 65536), 256, 0, (hipStream_t)stream>>>(
-                        tok, (const T*)table, (T*)out, M, T_, D)));
+                        tok, (const T*)table, (T*)out, M, T_, D, V)));
   MH_LAUNCH_CHECK();
   return MH_OK;
 }
@@ -59,14 +60,16 @@ extern "C" int mh_embed_sum_fwd(const int64_t* tok, const void* table, void* out
 template <typename T>
 __global__ __launch_bounds__(256) void concat_tok_fwd_kernel(const T* __restrict__ hidden, const int64_t* __restrict__ tok,
                                                              int64_t ldtok, const T* __restrict__ table,
-                                                             T* __restrict__ out, int64_t M, int TT, int D) {
+                                                             T* __restrict__ out, int64_t M, int TT, int D, int64_t V) {
   constexpr int N = Pack<T>::N;
   const int lane = threadIdx.x & 63;
   const int64_t rows = M * TT;
   for (int64_t r = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); r < rows; r += (int64_t)gridDim.x * 4) {
     const int64_t m = r / TT;
     const int j = (int)(r - m * TT);
-    const T* src = (j == 0) ? hidden + m * D : table + tok[m * ldtok + j - 1] * D;
+    const int64_t id = (j == 0) ? 0 : tok[m * ldtok + j - 1];
+    if ((uint64_t)id >= (uint64_t)V) __builtin_trap();  // (as embed_sum_fwd)
+    const T* src = (j == 0) ? hidden + m * D : table + id * D;
     for (int c = lane * N; c < D; c += 64 * N) st16(out + r * D + c, ld16(src + c));
   }
 }
@@ -75,7 +78,7 @@ extern "C" int mh_concat_tok_fwd(const void* hidden, const int64_t* tok, int64_t
                                  int64_t M, int T_, int64_t V, int D, int dtype, void* stream) {
   MH_REQUIRE(M > 0 && T_ > 0 && D % 8 == 0, "concat_tok_fwd: bad shape");
   DISPATCH_T(dtype, (concat_tok_fwd_kernel<T><<<grid_for(M * T_, 4, 65536), 256, 0, (hipStream_t)stream>>>(
-                        (const T*)hidden, tok, ldtok, (const T*)table, (T*)out, M, T_, D)));
+                        (const T*)hidden, tok, ldtok, (const T*)table, (T*)out, M, T_, D, V)));
   MH_LAUNCH_CHECK();
   return MH_OK;
 }

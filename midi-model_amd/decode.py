@@ -74,8 +74,8 @@ class DecodeSession:
                 and os.environ.get("MH_DECODE_FOLD", "1") != "0":
             self.fold1 = engine.fold_norm_weights(model._W["net"])
             self.fold2 = engine.fold_norm_weights(model._W["net_token"])
-            lm_w = model.lm_head.weight.data
-            self.lm_fold = (lm_w.float() * model._W["net_token"].norm.float()[None, :]).to(lm_w.dtype)
+            self.lm_fold = torch.empty_like(model.lm_head.weight.data)
+            self.refresh()
         self.g_net = None
         self.g_tok: List[Optional[torch.cuda.CUDAGraph]] = [None] * self.T
         self.use_graphs = graphs_enabled(dev)
@@ -86,9 +86,20 @@ class DecodeSession:
 
     @staticmethod
     def make_key(model, B, capacity, temp, top_p, top_k):
-        # (_version: the folded weights below are derived from the parameters as they were when the session was built)
-        return (model._flat.data_ptr(), model._flat._version, model._flat.dtype, B, capacity, float(temp), float(top_p),
-                int(top_k))
+        return (model._flat.data_ptr(), model._flat.dtype, B, capacity, float(temp), float(top_p), int(top_k))
+
+    def refresh(self) -> None:
+        """Re-derive the folded weights (norm weight x projection) IN PLACE from the live parameters.  The training
+        kernels write the flat parameter buffer through raw pointers (AdamW, LoRA materialisation), which no tensor version
+        counter sees, so a pooled session refreshes every time it is handed out (model._checkout_session): ~0.3 GB of
+        elementwise traffic per generate() call, and the captured graphs keep their addresses."""
+        if self.fold1 is None:
+            return
+        m = self.model
+        engine.fold_norm_weights(m._W["net"], out=self.fold1)
+        engine.fold_norm_weights(m._W["net_token"], out=self.fold2)
+        lm_w = m.lm_head.weight.data
+        self.lm_fold.copy_(lm_w.float() * m._W["net_token"].norm.float()[None, :])
 
     # ---- the step bodies (run eagerly, or once under capture) ---------------------------------------------
     def _net_body(self):

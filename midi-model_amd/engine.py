@@ -238,13 +238,15 @@ def stack_prefill(spec: StackSpec, W: StackTensors, x: torch.Tensor, nseq: int, 
     return y
 
 
-def fold_norm_weights(W: StackTensors):
+def fold_norm_weights(W: StackTensors, out=None):
     """[(wqkv * n1, wgu * n2) per layer]: the RMSNorm weights folded into the projections that follow them, for the
-    decode path's one-launch norm + projection (mh_gemm_skinny with norm_eps).  Derived data: rebuild when W changes."""
-    out = []
-    for lw in W.layers:
-        out.append(((lw.wqkv.float() * lw.n1.float()[None, :]).to(lw.wqkv.dtype),
-                    (lw.wgu.float() * lw.n2.float()[None, :]).to(lw.wgu.dtype)))
+    decode path's one-launch norm + projection (mh_gemm_skinny with norm_eps).  Derived data: with ``out`` (a list this
+    function returned earlier) the copies are rewritten in place, which is how a decode session follows weight updates."""
+    if out is None:
+        out = [(torch.empty_like(lw.wqkv), torch.empty_like(lw.wgu)) for lw in W.layers]
+    for lw, (fq, fg) in zip(W.layers, out):
+        fq.copy_(lw.wqkv.float() * lw.n1.float()[None, :])
+        fg.copy_(lw.wgu.float() * lw.n2.float()[None, :])
     return out
 
 

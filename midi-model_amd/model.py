@@ -213,6 +213,14 @@ class MIDIModel(nn.Module):
         if self._flat.dtype not in (torch.float32, torch.bfloat16):
             raise RuntimeError(f"unsupported parameter dtype {self._flat.dtype} (float32 or bfloat16)")
 
+    def _check_ids(self, ids: torch.Tensor) -> None:
+        """Token ids still on the host are range-checked for free; ids already on the device are checked by the embedding
+        kernels themselves (an id outside [0, vocab) traps the kernel, as torch's embedding raises a device assert)."""
+        if not ids.is_cuda and ids.numel():
+            lo, hi = int(ids.min()), int(ids.max())
+            if lo < 0 or hi >= self.tokenizer.vocab_size:
+                raise IndexError(f"token ids outside [0, {self.tokenizer.vocab_size}): min {lo}, max {hi}")
+
     def rope(self, pre: str) -> RopeTable:
         if pre not in self._ropes:
             spec = self._specs[pre]
@@ -292,6 +300,7 @@ class MIDIModel(nn.Module):
         if x.dim() != 3:
             raise ValueError(f"expected (batch, events, tokens) ids, got shape {tuple(x.shape)}")
         B, S, T = x.shape
+        self._check_ids(x)
         x = x.to(device=self.device, dtype=torch.long).contiguous()
         if cache is None:
             from .autograd import NetFn
@@ -322,6 +331,7 @@ class MIDIModel(nn.Module):
         if hidden_state is None and x is None:
             raise ValueError("forward_token needs hidden_state and/or x")
         if x is not None:
+            self._check_ids(x)
             x = x.to(device=self.device, dtype=torch.long)
         if cache is None:
             from .autograd import TokFn
@@ -423,6 +433,8 @@ class MIDIModel(nn.Module):
             inp[:, 0, 0] = tok.bos_id
             return inp
         prompt = np.asarray(prompt)
+        if prompt.size and (prompt.min() < 0 or prompt.max() >= tok.vocab_size):
+            raise ValueError(f"prompt holds token ids outside [0, {tok.vocab_size}): min {prompt.min()}, max {prompt.max()}")
         if prompt.ndim == 2:
             prompt = np.repeat(prompt[None, :], repeats=batch_size, axis=0)
         elif prompt.shape[0] == 1:
@@ -504,11 +516,16 @@ class MIDIModel(nn.Module):
         key = DecodeSession.make_key(self, B, cap, temp, top_p, top_k)
         pool = self._sessions
         with pool.lock:
+            found = None
             for k, ses in enumerate(pool.idle):
                 if ses.key == key:
-                    return pool.idle.pop(k)
-            while len(pool.idle) >= 4:  # bound the memory held by idle sessions
+                    found = pool.idle.pop(k)
+                    break
+            while found is None and len(pool.idle) >= 4:  # bound the memory held by idle sessions
                 pool.idle.pop(0)
+        if found is not None:
+            found.refresh()  # weights may have been trained / merged since the session derived its folded copies
+            return found
         return DecodeSession(self, B, cap, temp, top_p, top_k)
 
     def _return_session(self, ses) -> None:
@@ -528,5 +545,43 @@ class MIDIModel(nn.Module):
         from safetensors.torch import load_file
         cfg = MIDIModelConfig.from_json_file(os.path.join(directory, "config.json"))
         model = cls(cfg)
-        model.load_state_dict(load_file(os.path.join(directory, "model.safetensors")), strict=False)
+        model.load_checkpoint_state(load_file(os.path.join(directory, "model.safetensors")))
         return model
+
+    # keys a reference-side checkpoint may carry that are not parameters of the model (buffers of older HF versions)
+    _BENIGN_EXTRA = ("rotary_emb.inv_freq",)
+
+    def load_checkpoint_state(self, state: dict):
+        """Load a reference checkpoint's tensors the way app.py:311-316 / train.py:433-436 do (``strict=False``) but
+        WITHOUT its silence: a Lightning ``.ckpt`` payload (``{"state_dict": ...}``) is unwrapped, the prefixes other
+        wrappers add (``model.``, ``base_model.model.``, ``module.``) are stripped when they cover every key, known-benign
+        extras are dropped, and any parameter the file does not supply -- or any other unexpected key -- raises instead of
+        leaving random-initialised weights behind.  Returns self."""
+        if "state_dict" in state and not torch.is_tensor(state["state_dict"]):
+            state = state["state_dict"]
+        own = set(self.state_dict().keys())
+        for prefix in ("", "model.", "base_model.model.", "module.", "_orig_mod."):
+            if prefix and all(k.startswith(prefix) for k in state):
+                state = {k[len(prefix):]: v for k, v in state.items()}
+            if own & set(state):
+                break
+        state = {k: v for k, v in state.items() if not k.endswith(self._BENIGN_EXTRA)}
+        res = self.load_state_dict(state, strict=False)
+        if res.missing_keys or res.unexpected_keys:
+            raise RuntimeError(f"checkpoint does not match the model: missing {sorted(res.missing_keys)[:8]} "
+                               f"({len(res.missing_keys)}), unexpected {sorted(res.unexpected_keys)[:8]} "
+                               f"({len(res.unexpected_keys)})")
+        return self
+
+    @classmethod
+    def from_checkpoint(cls, config, path: str, **kwargs):
+        """app.py:304-316: a Lightning ``.ckpt`` (torch pickle with ``state_dict``) or a ``.safetensors`` file next to a
+        config given by name / object."""
+        cfg = config if isinstance(config, MIDIModelConfig) else MIDIModelConfig.from_name(config)
+        model = cls(cfg, **kwargs)
+        if path.endswith(".safetensors"):
+            from safetensors.torch import load_file
+            state = load_file(path)
+        else:
+            state = torch.load(path, map_location="cpu", weights_only=True)
+        return model.load_checkpoint_state(state)

@@ -225,7 +225,7 @@ class TrainMIDIModel(MIDIModel):
         # (names lora_A / lora_B contain neither "bias" nor "norm": weight decay applies, train.py:121-151)
         ops.adamw(lo.flat, lo.grad, o["m"], o["v"], lr, self.betas[0], self.betas[1], self.eps, self.weight_decay,
                   bc1, bc2, coef)
-        lo.dirty = True
+        lo.materialize(self)  # live weights follow the adapters at once: generate()/forward()/state_dict() right after a step
         self.global_step += 1
         self._micro = 0
 
@@ -242,6 +242,7 @@ class TrainMIDIModel(MIDIModel):
             self._lora.materialize(self)  # live weights <- base + scale * B @ A
         tok = self.tokenizer
         dev, dty = self.device, self.dtype
+        self._check_ids(batch)
         batch = batch.to(device=dev, dtype=torch.long)
         x = batch[:, :-1].contiguous()
         y = batch[:, 1:].contiguous()
@@ -280,6 +281,11 @@ class TrainMIDIModel(MIDIModel):
         cnt = torch.empty(1, dtype=torch.float32, device=dev)
         inv = torch.empty(1, dtype=torch.float32, device=dev)
         ops.count_valid(targets, tok.pad_id, cnt, inv)
+        # Lightning's automatic optimisation divides every micro-batch loss by accumulate_grad_batches before its
+        # backward (loops/optimization/automatic.py, ClosureResult normalize=...), so the window's gradient is the MEAN of
+        # the micro-batch gradients and gradient_clip_val acts on that mean; the reported loss stays per micro-batch.
+        nacc = max(1, int(self.accumulate_grad_batches))
+        bwd_scale = inv / nacc if (backward and nacc > 1) else inv
         row_loss = torch.empty(R, dtype=torch.float32, device=dev)
         argmax = torch.empty(R, dtype=torch.long, device=dev) if want_acc else None
         lm_w = self.lm_head.weight.data
@@ -294,7 +300,7 @@ class TrainMIDIModel(MIDIModel):
             r1 = min(R, r0 + chunk)
             lg = logits[: r1 - r0]
             ops.gemm_nt(h[r0:r1], lm_w, lg[:, :V])
-            ops.cross_entropy(lg, V, targets[r0:r1], row_loss[r0:r1], lg if backward else None, inv,
+            ops.cross_entropy(lg, V, targets[r0:r1], row_loss[r0:r1], lg if backward else None, bwd_scale,
                               argmax[r0:r1] if want_acc else None, tok.pad_id)
             if backward:
                 # d h = dlogits @ W_lm and d W_lm += dlogits^T @ h, operands read as they lie (padding columns of

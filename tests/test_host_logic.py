@@ -143,9 +143,10 @@ def test_fused_step_grads_and_optimizer(orc, tiny, golden, tok):
                 np.testing.assert_allclose(got, g[key], rtol=2e-4, atol=2e-6)
 
 
-def test_grad_accumulation_sums_micro_batches(orc, tiny, tok):
-    """accumulate_grad_batches=2: the second micro-batch ADDS to the first one's gradients (each micro-batch
-    loss is its own token mean, as under Lightning), and only then the optimiser runs."""
+def test_grad_accumulation_averages_micro_batches(orc, tiny, tok):
+    """accumulate_grad_batches=2 (the reference default, train.py:355): Lightning divides every micro-batch loss by the
+    window length before its backward, so the window's gradient is the MEAN of the two micro-batch gradients (each
+    micro-batch loss being its own token mean), and only then the optimiser runs."""
     shp, sd, _ = tiny
     b = orc.synthetic_events(tok, 4, 9, seed=21)
     with emu_ops.install():
@@ -164,7 +165,7 @@ def test_grad_accumulation_sums_micro_batches(orc, tiny, tok):
         g2 = m2.grad_buffer().clone()
         m2.optimizer_step()
         assert m2.global_step == 1 and not torch.equal(m2._flat, before)
-    np.testing.assert_allclose(g2.numpy(), (singles[0] + singles[1]).numpy(), rtol=1e-4, atol=1e-7)
+    np.testing.assert_allclose(g2.numpy(), (0.5 * (singles[0] + singles[1])).numpy(), rtol=1e-4, atol=1e-7)
 
 
 def test_generate_matches_reference(tiny, golden, tok):
