@@ -388,7 +388,8 @@ class MIDIModel(nn.Module):
     # ------------------------------------------------------------------------------------- generation
     def _grammar(self):
         if self._tables is None:
-            first, lo, hi, arity = self.tokenizer.grammar_tables()
+            from .tokenizer import grammar_tables
+            first, lo, hi, arity = grammar_tables(self.tokenizer)
             dev = self.device
             self._tables = (torch.tensor(first, dtype=torch.uint8, device=dev),
                             torch.tensor(lo, dtype=torch.int32, device=dev),

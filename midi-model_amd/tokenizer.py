@@ -1,11 +1,20 @@
 """Vocabulary tables of the MIDI event tokenizers (v1 / v2) that the hot path reads.
 
-Only the *static tables* live here: the model and the decode loop need
-``vocab_size, max_token_seq, pad_id, bos_id, eos_id, event_ids, id_events, events,
-parameter_ids`` (reference: midi_tokenizer.py:8-36 for v1, :506-535 for v2; consumed at
-midi_model.py:169-237).  The MIDI-file <-> token codecs (tokenize / detokenize / augment,
-midi_tokenizer.py:608-1186) are CPU data-format code outside the accelerated path
-(SURVEY.md §8(f) "next").
+The model and the decode loop need only the *static tables*: ``vocab_size, max_token_seq, pad_id, bos_id,
+eos_id, event_ids, id_events, events, parameter_ids`` (reference: midi_tokenizer.py:8-36 for v1, :506-535 for
+v2; consumed at midi_model.py:169-237).  The MIDI-file <-> token codecs (``tokenize / detokenize / augment /
+check_quality / midi2img``, midi_tokenizer.py:608-1186) are CPU data-format code outside the accelerated path, but
+``train.py:60-64,214-228,397-406`` and ``app.py:185,250`` reach them through ``config.tokenizer`` /
+``model.tokenizer``.  So the boundary is:
+
+  * when the reference's own ``midi_tokenizer`` module is importable (the drop-in deployment: our ``midi_model.py``
+    next to the reference's ``midi_tokenizer.py`` / ``MIDI.py``), ``MIDITokenizer(version)`` returns an instance of
+    THE REFERENCE'S class, codecs intact -- nothing of it is re-implemented here;
+  * otherwise (the GPU box, the tests) the tables-only classes below stand in; they carry no codec and say so;
+  * the dense grammar tables the device-side masks need come from the free function ``grammar_tables(tok)``, which
+    reads public attributes only and therefore works on either kind of tokenizer object.
+
+``MH_TABLES_ONLY_TOKENIZER=1`` forces the tables-only classes.
 
 The id layout is: [pad, bos, eos] + one id per event type (schema order) + one contiguous id
 range per parameter (parameter-table order).  ``tests/test_tokenizer.py`` checks every table
@@ -13,6 +22,7 @@ against a fixture dumped from the reference class.
 """
 from __future__ import annotations
 
+import os
 from typing import Any, Dict, List
 
 # event name -> ordered parameter names (the token octet is [event_id, *params, pad...])
@@ -111,31 +121,45 @@ class _VocabTables:
             out.append(v)
         return out
 
-    # -- dense tables for the device-side grammar masks (ours) -----------------------------
     def grammar_tables(self):
-        """Return (first_mask, param_lo, param_hi, arity).
+        return grammar_tables(self)
 
-        first_mask : list[vocab] 0/1 — ids legal as token 0 of an event (event ids + EOS)
-        param_lo/hi: [n_ids][max_token_seq] inclusive-exclusive id range legal at position i
-                     (i>=1) for an event whose token 0 is that id; (pad,pad+1) past its arity
-        arity      : [n_ids] number of parameters of the event with that id (0 for non-events)
-        Mirrors the mask construction of midi_model.py:202-214.
-        """
-        V, T = self.vocab_size, self.max_token_seq
-        first = [0] * V
-        for i in self.event_ids.values():
-            first[i] = 1
-        first[self.eos_id] = 1
-        lo = [[self.pad_id] * T for _ in range(V)]
-        hi = [[self.pad_id + 1] * T for _ in range(V)]
-        arity = [0] * V
-        for name, eid in self.event_ids.items():
-            pnames = self.events[name]
-            arity[eid] = len(pnames)
-            for pos, p in enumerate(pnames, start=1):
-                ids = self.parameter_ids[p]
-                lo[eid][pos], hi[eid][pos] = ids[0], ids[-1] + 1
-        return first, lo, hi, arity
+    def _no_codec(self, *a, **k):
+        raise NotImplementedError(
+            "this is the tables-only tokenizer: the MIDI-file codecs (tokenize / detokenize / augment / check_quality / "
+            "midi2img) are the reference's midi_tokenizer.py, which is used as-is when it is importable (put it, with MIDI.py, "
+            "next to midi_model.py); they are CPU data-format code outside the accelerated path")
+
+    tokenize = detokenize = augment = check_quality = midi2img = _no_codec
+
+
+def grammar_tables(tok):
+    """Dense tables for the device-side grammar masks, from the PUBLIC attributes of any tokenizer object (the
+    reference's MIDITokenizerV1/V2 or the tables-only classes here).  Returns (first_mask, param_lo, param_hi, arity):
+
+    first_mask : list[vocab] 0/1 — ids legal as token 0 of an event (event ids + EOS)
+    param_lo/hi: [n_ids][max_token_seq] inclusive-exclusive id range legal at position i
+                 (i>=1) for an event whose token 0 is that id; (pad,pad+1) past its arity
+    arity      : [n_ids] number of parameters of the event with that id (0 for non-events)
+    Mirrors the mask construction of midi_model.py:202-214.  The id ranges of a parameter must be contiguous (they are:
+    ``allocate_ids`` hands out consecutive ids, midi_tokenizer.py:14-17, 512-515); that is checked."""
+    V, T = tok.vocab_size, tok.max_token_seq
+    first = [0] * V
+    for i in tok.event_ids.values():
+        first[i] = 1
+    first[tok.eos_id] = 1
+    lo = [[tok.pad_id] * T for _ in range(V)]
+    hi = [[tok.pad_id + 1] * T for _ in range(V)]
+    arity = [0] * V
+    for name, eid in tok.event_ids.items():
+        pnames = tok.events[name]
+        arity[eid] = len(pnames)
+        for pos, p in enumerate(pnames, start=1):
+            ids = list(tok.parameter_ids[p])
+            if ids != list(range(ids[0], ids[0] + len(ids))):
+                raise ValueError(f"parameter {p!r}: ids are not one contiguous range")
+            lo[eid][pos], hi[eid][pos] = ids[0], ids[-1] + 1
+    return first, lo, hi, arity
 
 
 class MIDITokenizerV1(_VocabTables):
@@ -146,12 +170,33 @@ class MIDITokenizerV2(_VocabTables):
     version = "v2"
 
 
+def reference_tokenizer_module():
+    """The reference's ``midi_tokenizer`` module if it is importable and looks like it (both codec classes present), else
+    None.  Never imported from a fixed path: it is whatever the deployment put on sys.path."""
+    if os.environ.get("MH_TABLES_ONLY_TOKENIZER", "0") == "1":
+        return None
+    try:
+        import midi_tokenizer as ref  # noqa: the reference's module (midi_tokenizer.py), NOT part of this package
+    except Exception:  # absent, or one of its own imports (PIL) is
+        return None
+    ok = all(hasattr(ref, n) for n in ("MIDITokenizer", "MIDITokenizerV1", "MIDITokenizerV2")) and \
+        all(hasattr(ref.MIDITokenizerV2, m) for m in ("tokenize", "detokenize", "augment", "check_quality"))
+    return ref if ok else None
+
+
 class MIDITokenizer:
-    """Factory with the reference's call shape: ``MIDITokenizer("v2")`` (midi_tokenizer.py:1189-1196)."""
+    """Factory with the reference's call shape: ``MIDITokenizer("v2")`` (midi_tokenizer.py:1189-1196).  Hands out the
+    reference's own class when its module is importable (codec methods intact), the tables-only class otherwise."""
 
     def __new__(cls, version: str = "v2"):
-        if version == "v1":
-            return MIDITokenizerV1()
-        if version == "v2":
-            return MIDITokenizerV2()
-        raise ValueError(f"Unsupported version: {version}")
+        if version not in ("v1", "v2"):
+            raise ValueError(f"Unsupported version: {version}")
+        ref = reference_tokenizer_module()
+        if ref is not None:
+            tok = ref.MIDITokenizer(version)
+            mine = MIDITokenizerV1() if version == "v1" else MIDITokenizerV2()
+            for attr in ("vocab_size", "max_token_seq", "pad_id", "bos_id", "eos_id", "event_ids", "events"):
+                if getattr(tok, attr) != getattr(mine, attr):
+                    raise RuntimeError(f"the importable midi_tokenizer disagrees with the {version} vocabulary on {attr}")
+            return tok
+        return MIDITokenizerV1() if version == "v1" else MIDITokenizerV2()

@@ -213,7 +213,11 @@ def adamw_step(p: Tensor, g: Tensor, m: Tensor, v: Tensor, step: int, lr: float,
 # --------------------------------------------------------------------------------------------
 # sampling + generation
 # --------------------------------------------------------------------------------------------
-def sample_top_p_k(probs: Tensor, p: float, k: int, generator=None) -> Tensor:
+def sample_top_p_k(probs: Tensor, p: float, k: int, generator=None, noise: Optional[Tensor] = None) -> Tensor:
+    """midi_model.py:152-165.  ``noise`` (same shape as probs): draw with these Exp(1) variates instead of a generator --
+    torch.multinomial(num_samples=1) is ``argmax(p / q)`` with ``q = empty_like(p).exponential_(1)`` (aten/native
+    Distributions.cpp, multinomial without replacement), applied by the reference to the SORTED probabilities, so variate j
+    belongs to sorted rank j.  A test can hand the device sampler and this chain the same variates."""
     ps, idx = torch.sort(probs, dim=-1, descending=True)
     csum = torch.cumsum(ps, dim=-1)
     ps = ps.masked_fill(csum - ps > p, 0.0)
@@ -222,14 +226,49 @@ def sample_top_p_k(probs: Tensor, p: float, k: int, generator=None) -> Tensor:
     ps = ps * keep
     ps = ps / ps.sum(dim=-1, keepdim=True)
     shape = ps.shape
-    nxt = torch.multinomial(ps.reshape(-1, shape[-1]), num_samples=1, generator=generator).reshape(*shape[:-1], 1)
+    if noise is not None:
+        nxt = (ps / noise).argmax(-1, keepdim=True)
+    else:
+        nxt = torch.multinomial(ps.reshape(-1, shape[-1]), num_samples=1, generator=generator).reshape(*shape[:-1], 1)
     return torch.gather(idx, -1, nxt).reshape(*shape[:-1])
 
 
+def grammar_mask(tok, i: int, names: List[str], end: List[bool], ban_eos: bool = False, disable_patch_change: bool = False,
+                 disable_control_change: bool = False, disable_channels=None) -> Tensor:
+    """The (B, vocab) 0/1 mask of token position i (midi_model.py:202-214) with the serving loop's options
+    (app.py:73-86): finished rows -> PAD; position 0 -> the event ids (+ EOS) minus disabled event types; position i ->
+    the id range of the event's (i-1)-th parameter, a ``channel`` parameter minus the disabled channels; past the event's
+    arity -> PAD."""
+    banned = [tok.parameter_ids["channel"][c] for c in (disable_channels or [])]
+    mask = torch.zeros((len(names), tok.vocab_size), dtype=torch.int64)
+    for b in range(len(names)):
+        if end[b]:
+            mask[b, tok.pad_id] = 1
+        elif i == 0:
+            ids = list(tok.event_ids.values()) + ([] if ban_eos else [tok.eos_id])
+            if disable_patch_change:
+                ids.remove(tok.event_ids["patch_change"])
+            if disable_control_change:
+                ids.remove(tok.event_ids["control_change"])
+            mask[b, ids] = 1
+        else:
+            pn = tok.events[names[b]]
+            if i > len(pn):
+                mask[b, tok.pad_id] = 1
+            else:
+                ids = list(tok.parameter_ids[pn[i - 1]])
+                if pn[i - 1] == "channel":
+                    ids = [t for t in ids if t not in banned]
+                mask[b, ids] = 1
+    return mask
+
+
 def generate(sd: SD, shp: Shape, tok, prompt=None, batch_size=1, max_len=512, temp=1.0, top_p=0.98,
-             top_k=20, generator=None, ban_eos: bool = False) -> np.ndarray:
+             top_k=20, generator=None, ban_eos: bool = False, disable_patch_change: bool = False,
+             disable_control_change: bool = False, disable_channels=None, crop: Optional[int] = None) -> np.ndarray:
     """``tok`` supplies the vocabulary tables.  ``ban_eos`` (ours, throughput runs only) removes
-    EOS from the first-token mask so every row runs to ``max_len``."""
+    EOS from the first-token mask so every row runs to ``max_len``.  ``disable_*`` are the mask options of the serving
+    loop (app.py:27-31, 73-86) and ``crop`` its prompt crop (``input_tensor[:, -4096:]``, app.py:53)."""
     T = tok.max_token_seq
     if prompt is None:
         inp = torch.full((batch_size, 1, T), tok.pad_id, dtype=torch.long)
@@ -246,9 +285,10 @@ def generate(sd: SD, shp: Shape, tok, prompt=None, batch_size=1, max_len=512, te
         if prompt.shape[-1] < T:
             prompt = np.pad(prompt, ((0, 0), (0, 0), (0, T - prompt.shape[-1])), constant_values=tok.pad_id)
         inp = torch.from_numpy(prompt).long()
+    if crop is not None:
+        inp = inp[:, -crop:]
     cur, past = inp.shape[1], 0
     cache1 = KV()
-    first_ids = list(tok.event_ids.values()) + ([] if ban_eos else [tok.eos_id])
     while cur < max_len:
         end = [False] * batch_size
         hidden = midi_forward(sd, shp, inp[:, past:], cache1)[:, -1]
@@ -256,18 +296,7 @@ def generate(sd: SD, shp: Shape, tok, prompt=None, batch_size=1, max_len=512, te
         cache2 = KV()
         seq = None
         for i in range(T):
-            mask = torch.zeros((batch_size, tok.vocab_size), dtype=torch.int64)
-            for b in range(batch_size):
-                if end[b]:
-                    mask[b, tok.pad_id] = 1
-                elif i == 0:
-                    mask[b, first_ids] = 1
-                else:
-                    pn = tok.events[names[b]]
-                    if i > len(pn):
-                        mask[b, tok.pad_id] = 1
-                    else:
-                        mask[b, tok.parameter_ids[pn[i - 1]]] = 1
+            mask = grammar_mask(tok, i, names, end, ban_eos, disable_patch_change, disable_control_change, disable_channels)
             if i == 0:
                 logits = midi_forward_token(sd, shp, hidden, None, cache2)[:, -1:]
             else:

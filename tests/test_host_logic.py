@@ -388,3 +388,89 @@ def test_sample_seq_training_step(orc, tiny, tok):
     for k in ("net.embed_tokens.weight", "net.layers.0.self_attn.q_proj.weight", "net.layers.3.mlp.down_proj.weight",
               "net_token.layers.0.mlp.gate_proj.weight", "net.norm.weight", "lm_head.weight"):
         np.testing.assert_allclose(named[k].grad.numpy(), sdg[k].grad.numpy(), rtol=3e-3, atol=3e-7, err_msg=k)
+
+
+def test_serving_loop_masks_and_crop_match_oracle_seeded(orc, tiny, tok):
+    """generate() / generate_stream() with the serving loop's mask options (app.py:73-86) against the oracle's restatement
+    of that loop, SEEDED (CPU generator, the reference's own draw): same ids.  Through the fake backend, so it runs here."""
+    shp, sd, _ = tiny
+    kw = dict(disable_patch_change=True, disable_control_change=True, disable_channels=[0, 9, 15])
+    prompt = orc.synthetic_events(tok, 1, 4, seed=8)[0].numpy()
+    with emu_ops.install():
+        model = mm.MIDIModel(tiny_config())
+        model.load_state_dict(sd)
+        for seed, temp, top_p, top_k in ((21, 1.0, 0.98, 20), (22, 0.8, 0.9, 6)):
+            want = orc.generate(sd, shp, tok, prompt, batch_size=3, max_len=20, temp=temp, top_p=top_p, top_k=top_k,
+                                generator=torch.Generator().manual_seed(seed), **kw)
+            got = model.generate(prompt, batch_size=3, max_len=20, temp=temp, top_p=top_p, top_k=top_k,
+                                 generator=torch.Generator().manual_seed(seed), **kw)
+            assert got.shape == want.shape and (got == want).all()
+            evs = list(model.generate_stream(prompt, batch_size=3, max_len=20, temp=temp, top_p=top_p, top_k=top_k,
+                                             generator=torch.Generator().manual_seed(seed), **kw))
+            assert (np.stack(evs, 1) == want[:, 4:]).all()
+        banned = [tok.parameter_ids["channel"][c] for c in (0, 9, 15)]
+        assert not np.isin(want[:, 4:], banned).any()
+        assert not np.isin(want[:, 4:, 0], [tok.event_ids["patch_change"], tok.event_ids["control_change"]]).any()
+        with pytest.raises(ValueError, match="outside"):
+            model.generate(np.full((2, 8), tok.vocab_size, dtype=np.int64), batch_size=1, max_len=4)
+
+
+def test_reference_serving_loop_on_the_drop_in_with_real_dynamic_cache(orc, tiny, tok):
+    """tests/ref_loops.py = app.py:27-120 verbatim.  It creates real transformers.DynamicCache objects and hands them to
+    model.forward / model.forward_token, as app.py:56,64 does; with the same seeded generator its stream equals both
+    generate()'s and the oracle's.  (GPU twin: tests/test_decode_gpu.py.)"""
+    from transformers import DynamicCache
+    from ref_loops import serving_loop
+    import midi_model
+    shp, sd, _ = tiny
+    assert midi_model.MIDIModel is mm.MIDIModel and midi_model.config_name_list == mm.config_name_list
+
+    class Mixin:
+        pass
+
+    class T(midi_model.MIDIModel, Mixin):  # train.py:106: class TrainMIDIModel(MIDIModel, pl.LightningModule)
+        def __init__(self, config):
+            super().__init__(config=config)
+
+    with emu_ops.install():
+        model = T(tiny_config())
+        model.load_state_dict(sd, strict=False)
+        model.eval()
+        prompt = orc.synthetic_events(tok, 1, 5, seed=12)[0].numpy()
+        evs = list(serving_loop(model, model.tokenizer, DynamicCache, prompt, batch_size=2, max_len=15,
+                                disable_control_change=True, disable_channels=[9], generator=torch.Generator().manual_seed(4)))
+        want = orc.generate(sd, shp, tok, prompt, batch_size=2, max_len=15, disable_control_change=True, disable_channels=[9],
+                            generator=torch.Generator().manual_seed(4))
+        assert (np.stack(evs, 1) == want[:, 5:]).all()
+        got = model.generate(prompt, batch_size=2, max_len=15, disable_control_change=True, disable_channels=[9],
+                             generator=torch.Generator().manual_seed(4))
+        assert (got == want).all()
+
+
+def test_checkpoint_forms_load_strictly(orc, tiny, tmp_path):
+    """the on-disk forms either side of training -- save_pretrained dir, Lightning-shaped .ckpt, safetensors,
+    prefixed keys -- load key-for-key into the flat buffer; benign extras are dropped, anything else raises."""
+    from safetensors.torch import save_file
+    shp, sd, _ = tiny
+    model = mm.MIDIModel(tiny_config())
+    model.load_state_dict(sd)
+    model.save_pretrained(str(tmp_path / "hf"))
+    again = mm.MIDIModel.from_pretrained(str(tmp_path / "hf"))
+    assert again.config.to_dict() == model.config.to_dict()
+    for k, v in again.state_dict().items():
+        assert torch.equal(v, sd[k]), k
+    state = {k: v.clone() for k, v in sd.items()}
+    torch.save({"state_dict": state, "epoch": 1}, str(tmp_path / "a.ckpt"))
+    torch.save({"state_dict": {"model." + k: v for k, v in state.items()}}, str(tmp_path / "b.ckpt"))
+    save_file({**state, "net.rotary_emb.inv_freq": torch.ones(8)}, str(tmp_path / "c.safetensors"))
+    for name in ("a.ckpt", "b.ckpt", "c.safetensors"):
+        m = mm.MIDIModel.from_checkpoint(tiny_config(), str(tmp_path / name))
+        assert torch.equal(m._flat, model._flat), name
+    bad = dict(state)
+    bad.pop("lm_head.weight")
+    save_file(bad, str(tmp_path / "d.safetensors"))
+    with pytest.raises(RuntimeError, match="missing"):
+        mm.MIDIModel.from_checkpoint(tiny_config(), str(tmp_path / "d.safetensors"))
+    save_file({**state, "net.layers.0.extra.weight": torch.ones(3)}, str(tmp_path / "e.safetensors"))
+    with pytest.raises(RuntimeError, match="unexpected"):
+        mm.MIDIModel.from_checkpoint(tiny_config(), str(tmp_path / "e.safetensors"))

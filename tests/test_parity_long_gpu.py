@@ -1,0 +1,356 @@
+"""Parity of the PRODUCTION kernels at the BENCHMARKED shapes (tv2o-medium, S = 2048 / 4096 events): the bf16 path that
+bench.py times -- gemm_pp256_kernel, the MFMA flash attention, the fused epilogues, split-K weight gradients over 262,144
+token rows, the equal-piece embedding gradient -- against
+
+  * golden vectors of the REAL reference at these lengths (tests/golden/medium_long_S*.npz, tests/gen_golden_long.py), and
+  * the CPU oracle computed inside the test on the same seeded inputs (full tensors, autograd gradients at S = 2048).
+
+Tolerances.  fp32 verification mode: rtol 1e-3 on hidden states / logits (north_star), arg-max exact where the reference's
+top-2 margin exceeds 1e-3.  bf16: multiples of the reference's OWN bf16-vs-fp32 drift measured on the same inputs
+(``ref_bf16_*`` in the golden files): the production path must not be further from the fp32 reference than ~1.5x what the
+reference's own bf16-true run is.  Kernel-level checks feed bf16-exact inputs, so the only error sources are fp32
+accumulation order (~1e-3 of the output scale) and the final bf16 rounding of the output (2^-9 relative).
+"""
+import math
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import midi_model_amd as mm
+from midi_model_amd.train import TrainMIDIModel
+
+pytestmark = pytest.mark.gpu
+
+BF16_ULP = 2.0 ** -8  # |x - bf16(x)| <= 2^-9 |x|; one extra factor 2 for a value rounded on both sides of a comparison
+DRIFT = 1.5           # allowed multiple of the reference's own bf16 drift
+
+
+@pytest.fixture(scope="module")
+def tok():
+    return mm.MIDITokenizerV2()
+
+
+@pytest.fixture(scope="module")
+def medium(orc, tok):
+    shp = orc.Shape(vocab=tok.vocab_size)
+    return shp, orc.make_state_dict(shp, seed=0)
+
+
+def build(sd, dtype, **kw):
+    m = TrainMIDIModel(mm.MIDIModelConfig.from_name("tv2o-medium"), accumulate_grad_batches=1, **kw)
+    m.load_state_dict(sd, strict=True)
+    return m.to("cuda", dtype)
+
+
+_ORACLE = {}
+
+
+def oracle_run(orc, medium, tok, S: int, grads: bool):
+    """oracle forward (and autograd backward) on the host cores, cached per (S, grads) for the module"""
+    key = (S, grads)
+    if key in _ORACLE:
+        return _ORACLE[key]
+    shp, sd = medium
+    batch = orc.synthetic_events(tok, 1, S + 1, seed={2048: 6, 4096: 7}[S])
+    torch.set_num_threads(min(os.cpu_count() or 8, 32))
+    if grads:
+        sdg = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+        loss, logits = orc.training_loss(sdg, shp, batch)
+        loss.backward()
+        out = dict(loss=loss.item(), logits=logits.detach(), grads={k: v.grad for k, v in sdg.items()})
+    else:
+        with torch.no_grad():
+            hidden = orc.midi_forward(sd, shp, batch[:, :-1]).reshape(-1, shp.n_embd)
+            y = batch[:, 1:].reshape(-1, 8)
+            logits = orc.midi_forward_token(sd, shp, hidden, y[:, :-1])
+            loss = torch.nn.functional.cross_entropy(logits.reshape(-1, shp.vocab), y.reshape(-1), ignore_index=0)
+        out = dict(loss=loss.item(), logits=logits, hidden=hidden)
+    out["batch"] = batch
+    _ORACLE[key] = out
+    return out
+
+
+# ------------------------------------------------------------------------------ forward at S = 2048 / 4096
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16], ids=["fp32", "bf16"])
+@pytest.mark.parametrize("S", [2048, 4096])
+def test_forward_at_benchmarked_length(orc, medium, tok, golden, S, dtype):
+    g = golden(f"medium_long_S{S}.npz")
+    shp, sd = medium
+    batch = orc.synthetic_events(tok, 1, S + 1, seed=int(g["batch_seed"]))
+    model = build(sd, dtype)
+    with torch.no_grad():
+        hidden = model.forward(batch[:, :-1].cuda()).reshape(-1, shp.n_embd)
+        y = batch[:, 1:].reshape(-1, 8).cuda()
+        logits = model.forward_token(hidden, y[:, :-1]).float().cpu()
+        loss, _ = model.validation_step(batch.cuda())
+    hidden = hidden.float().cpu()
+    lse = torch.logsumexp(logits, -1).numpy()
+    h_sub, l_sub = hidden[::32, ::4].numpy(), logits[::64, :, ::16].numpy()
+    amax = logits.argmax(-1).numpy()
+    if dtype == torch.float32:
+        assert abs(loss.item() - float(g["loss"])) < 2e-4
+        np.testing.assert_allclose(h_sub, g["hidden_sub"], rtol=1e-3, atol=3e-4)
+        np.testing.assert_allclose(l_sub, g["logits_sub"], rtol=1e-3, atol=3e-4)
+        np.testing.assert_allclose(lse, g["logits_lse"], rtol=1e-4, atol=1e-4)
+        safe = g["logits_margin"] > 1e-3
+        assert (amax == g["logits_argmax"])[safe].all()
+        # and against the oracle's FULL tensors (S = 4096: the whole 4096 x 8 x 3406 logits)
+        ref = oracle_run(orc, medium, tok, S, grads=(S == 2048))
+        assert abs(loss.item() - ref["loss"]) < 2e-4
+        err = (logits - ref["logits"]).abs()
+        assert (err <= 1e-3 * ref["logits"].abs() + 2e-4).all(), err.max().item()
+        return
+    # bf16: bounded by the reference's own bf16 drift on these very inputs
+    herr, lerr = np.abs(h_sub - g["hidden_sub"]), np.abs(l_sub - g["logits_sub"])
+    lse_err = np.abs(lse - g["logits_lse"]).max()
+    agree = (amax == g["logits_argmax"]).mean()
+    ref = oracle_run(orc, medium, tok, S, grads=(S == 2048))
+    full = (logits - ref["logits"])
+    full_max, full_rms = full.abs().max().item(), full.pow(2).mean().sqrt().item()
+    print(f"S={S} bf16: hidden max {herr.max():.4f} (ref bf16 {float(g['ref_bf16_hidden_maxerr']):.4f}), logits max "
+          f"{full_max:.4f} rms {full_rms:.5f} (ref bf16 {float(g['ref_bf16_logits_maxerr']):.4f} / "
+          f"{float(g['ref_bf16_logits_rmserr']):.5f}), lse {lse_err:.4f} (ref {float(g['ref_bf16_lse_maxerr']):.4f}), "
+          f"argmax agree {agree:.4f} (ref {float(g['ref_bf16_argmax_agree']):.4f}), loss {loss.item():.5f} "
+          f"(fp32 {float(g['loss']):.5f}, ref bf16 {float(g['ref_bf16_loss']):.5f})")
+    assert herr.max() <= DRIFT * float(g["ref_bf16_hidden_maxerr"])
+    assert full_max <= DRIFT * float(g["ref_bf16_logits_maxerr"])
+    assert full_rms <= DRIFT * float(g["ref_bf16_logits_rmserr"])
+    assert lse_err <= DRIFT * float(g["ref_bf16_lse_maxerr"]) + 1e-3
+    assert agree >= float(g["ref_bf16_argmax_agree"]) - 0.02
+    assert abs(loss.item() - float(g["loss"])) <= DRIFT * abs(float(g["ref_bf16_loss"]) - float(g["loss"])) + 5e-3
+    safe = g["logits_margin"] > 2.0 * float(g["ref_bf16_logits_maxerr"])
+    assert safe.any() and (amax == g["logits_argmax"])[safe].all()
+
+
+# ------------------------------------------------------------------------------ training step at S = 2048
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16], ids=["fp32", "bf16"])
+def test_training_step_gradients_at_S2048(orc, medium, tok, golden, dtype):
+    """loss + all 140 gradient norms + full named gradient tensors of the fused training step (train.py:168-188 and its
+    backward) at B=1, S=2048: 16,384 token rows through the split-K weight gradients, 32 causal tiles per attention row
+    block, the sorted-segment embedding gradient with the 'note' id occurring ~1800 times"""
+    g = golden("medium_long_S2048.npz")
+    shp, sd = medium
+    ref = oracle_run(orc, medium, tok, 2048, grads=True)
+    batch = ref["batch"]
+    model = build(sd, dtype)
+    loss = model.training_step(batch.cuda())
+    named = {k: p.grad.float().cpu() for k, p in model.named_parameters()}
+    names = [str(n) for n in g["grad_names"]]
+    norms = np.array([named[n].norm().item() for n in names])
+    slices = [k[5:] for k in g.files if k.startswith("grad:")]
+    assert len(slices) >= 6
+    if dtype == torch.float32:
+        assert abs(loss.item() - float(g["loss"])) < 2e-4 and abs(loss.item() - ref["loss"]) < 2e-4
+        np.testing.assert_allclose(norms, g["grad_norms"], rtol=2e-3, atol=1e-8)
+        for k in slices:
+            got = named[k] if named[k].dim() == 1 else named[k][:64:3, ::5]
+            scale = np.abs(g["grad:" + k]).max()
+            np.testing.assert_allclose(got.numpy(), g["grad:" + k], rtol=5e-3, atol=2e-4 * scale, err_msg=k)
+            full = ref["grads"][k]
+            rel = ((named[k] - full).norm() / full.norm()).item()
+            assert rel < 1e-3, (k, rel)
+        return
+    assert abs(loss.item() - float(g["loss"])) <= DRIFT * abs(float(g["ref_bf16_loss"]) - float(g["loss"])) + 5e-3
+    flat = torch.cat([named[n].reshape(-1) for n in names])
+    flat_ref = torch.cat([ref["grads"][n].reshape(-1) for n in names])
+    cos = torch.nn.functional.cosine_similarity(flat, flat_ref, dim=0).item()
+    ratio = (flat.norm() / flat_ref.norm()).item()
+    print(f"bf16 gradients at S=2048: cosine {cos:.5f} (ref bf16 {float(g['ref_bf16_grad_cosine']):.5f}), norm ratio "
+          f"{ratio:.4f} (ref bf16 {float(g['ref_bf16_grad_norm_ratio']):.4f})")
+    assert cos >= 1.0 - DRIFT * (1.0 - float(g["ref_bf16_grad_cosine"])) - 1e-4
+    assert abs(ratio - 1.0) <= DRIFT * abs(float(g["ref_bf16_grad_norm_ratio"]) - 1.0) + 0.01
+    for k in slices:
+        full = ref["grads"][k]
+        rel = ((named[k] - full).norm() / full.norm()).item()
+        want = float(g["ref_bf16_grad_relerr:" + k])
+        print(f"  {k}: relative error {rel:.4f} (reference's own bf16 run: {want:.4f})")
+        assert rel <= DRIFT * want + 2e-3, (k, rel, want)
+    np.testing.assert_allclose(norms, g["grad_norms"], rtol=0.05, atol=1e-6)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16], ids=["fp32", "bf16"])
+def test_accumulation_window_and_sample_seq_on_device(orc, tok, dtype):
+    """Trainer numerics that the headline step does not touch, on the GPU against the oracle:
+    accumulate_grad_batches=2 (the reference default, train.py:355; beta=1 weight gradients, accumulate flags) gives the
+    MEAN of the two micro-batch gradients, and --sample-seq (train.py:172-175) with the same random draw."""
+    import random
+    cfg = mm.MIDIModelConfig.get_config("v2", True, 4, 4, 256, 512)
+    shp = orc.Shape(n_layer=4, n_head=4, n_embd=256, n_inner=512, vocab=tok.vocab_size)
+    sd = orc.make_state_dict(shp, seed=1)
+    b = orc.synthetic_events(tok, 4, 130, seed=21)
+    sdg = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    l0, _ = orc.training_loss(sdg, shp, b[:2])
+    l1, _ = orc.training_loss(sdg, shp, b[2:])
+    (0.5 * (l0 + l1)).backward()
+    m = TrainMIDIModel(cfg, accumulate_grad_batches=2, lr=1e-2, warmup=0)
+    m.load_state_dict(sd)
+    m = m.to("cuda", dtype)
+    before = m._flat.clone()
+    la = m.fit_step(b[:2].cuda())
+    assert torch.equal(m._flat, before) and m.global_step == 0
+    lb = m.training_step(b[2:].cuda())
+    tol_l = 1e-4 if dtype == torch.float32 else 3e-2
+    assert abs(la.item() - l0.item()) < tol_l and abs(lb.item() - l1.item()) < tol_l
+    flat = torch.cat([p.grad.float().cpu().reshape(-1) for _, p in m.named_parameters()])
+    ref = torch.cat([sdg[k].grad.reshape(-1) for k, _ in m.named_parameters()])
+    rel = ((flat - ref).norm() / ref.norm()).item()
+    assert rel < (2e-3 if dtype == torch.float32 else 0.08), rel
+    m.optimizer_step()
+    want_norm = ref.norm().item()
+    assert abs(m.last_grad_norm.item() - want_norm) < (2e-3 if dtype == torch.float32 else 0.05) * want_norm
+    assert m.global_step == 1 and not torch.equal(m._flat, before)
+
+    # --sample-seq: the model draws with random.sample; replay the same draw for the oracle
+    m = TrainMIDIModel(cfg, accumulate_grad_batches=1, sample_seq=True)
+    m.load_state_dict(sd)
+    m = m.to("cuda", dtype)
+    S = b.shape[1] - 1
+    random.seed(123)
+    loss = m.training_step(b[:2].cuda())
+    random.seed(123)
+    idx = [-1] + random.sample(list(range(S - 2)), min(127, (S - 2) // 2))
+    sdg = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    x, y = b[:2, :-1], b[:2, 1:]
+    hidden = orc.midi_forward(sdg, shp, x)[:, idx].reshape(-1, shp.n_embd)
+    yy = y[:, idx].reshape(-1, 8)
+    logits = orc.midi_forward_token(sdg, shp, hidden, yy[:, :-1])
+    lref = torch.nn.functional.cross_entropy(logits.reshape(-1, shp.vocab), yy.reshape(-1), ignore_index=tok.pad_id)
+    lref.backward()
+    assert abs(loss.item() - lref.item()) < tol_l
+    flat = torch.cat([p.grad.float().cpu().reshape(-1) for _, p in m.named_parameters()])
+    ref = torch.cat([sdg[k].grad.reshape(-1) for k, _ in m.named_parameters()])
+    rel = ((flat - ref).norm() / ref.norm()).item()
+    assert rel < (2e-3 if dtype == torch.float32 else 0.08), rel
+
+
+# ------------------------------------------------------------------------------ kernels on bf16-exact inputs
+def _bf16_exact(shape, seed, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return (scale * torch.randn(shape, generator=g)).to(torch.bfloat16)
+
+
+@pytest.mark.parametrize("S", [2048, 4096])
+def test_flash_attention_at_benchmarked_length(orc, S):
+    """MFMA flash attention (attention_mfma.hip) at S = 2048 / 4096, 16 heads of 64, on bf16-exact q, k, v, against the
+    oracle's attention (softmax(QK^T/8 + causal) V, fp32) on the SAME rounded inputs.  Error sources left: fp32
+    accumulation order, P rounded to bf16 before the PV product (averages out over the row), and the bf16 rounding of
+    O itself: |err| <= 2^-8 |O| + 3e-3 * rms(V) elementwise (the rms(V) term covers the first rows, where a
+    row's few P values carry their 2^-9 rounding undiluted) and rms(err) < 2e-3 rms(O); log-sum-exp to 1e-4.  Backward: dq/dk/dv against autograd through the
+    oracle on the same inputs: rms error < 3e-3 rms(g), every element within 2^-7 |g| + 1e-2 rms(g) (P and dS enter the
+    MFMAs rounded to bf16: independent 2^-9 relative errors per term, so the tail over 4M elements reaches a few times
+    2^-9 rms(g) where |g| itself is small)."""
+    from midi_model_amd import ops
+    B, H, hd = 1, 16, 64
+    D = H * hd
+    qkv = _bf16_exact((B * S, 3 * D), 30)
+    do = _bf16_exact((B * S, D), 31)
+    q, k, v = (qkv[:, i * D:(i + 1) * D].float().view(B, S, H, hd).transpose(1, 2).contiguous().requires_grad_(True)
+               for i in range(3))
+    # oracle on the host (scores are 16 x S x S fp32)
+    o_ref = orc.attention(q, k, v, causal=True)
+    with torch.no_grad():
+        s = torch.matmul(q, k.transpose(-1, -2)) * hd ** -0.5
+        s = s.masked_fill(torch.arange(S)[None, :] > torch.arange(S)[:, None], float("-inf"))
+        lse_ref = torch.logsumexp(s, -1)
+        del s
+    o_ref.backward(do.float().view(B, S, H, hd).transpose(1, 2))
+    Sp = (S + 63) // 64 * 64
+    o = torch.empty((B * S, D), dtype=torch.bfloat16, device="cuda")
+    lse = torch.zeros(B * H * Sp, device="cuda")
+    qd = qkv.cuda()
+    ops.attn_fwd(qd, o, lse, B, S, H, hd ** -0.5)
+    want = o_ref.detach().transpose(1, 2).reshape(B * S, D)
+    err = (o.float().cpu() - want).abs()
+    bound = BF16_ULP * want.abs() + 3e-3 * v.detach().pow(2).mean().sqrt().item()
+    assert (err <= bound).all(), (err.max().item(), (err / bound).max().item())
+    rel_rms = (err.pow(2).mean().sqrt() / want.pow(2).mean().sqrt()).item()
+    assert rel_rms < 2e-3, rel_rms
+    lerr = (lse.view(B, H, Sp)[:, :, :S].cpu() - lse_ref).abs().max().item()
+    assert lerr < 1e-4 * max(1.0, lse_ref.abs().max().item()), lerr
+    dqkv = torch.full((B * S, 3 * D), float("nan"), dtype=torch.bfloat16, device="cuda")
+    ops.attn_bwd(qd, o, do.cuda(), lse, dqkv, B, S, H, hd ** -0.5)
+    for i, (nm, t) in enumerate((("dq", q), ("dk", k), ("dv", v))):
+        wantg = t.grad.transpose(1, 2).reshape(B * S, D)
+        e = (dqkv[:, i * D:(i + 1) * D].float().cpu() - wantg).abs()
+        rms = wantg.pow(2).mean().sqrt().item()
+        bnd = 2 * BF16_ULP * wantg.abs() + 1e-2 * rms
+        assert (e <= bnd).all(), (nm, e.max().item(), (e / bnd).max().item())
+        assert e.pow(2).mean().sqrt().item() < 3e-3 * rms, (nm, e.pow(2).mean().sqrt().item() / rms)
+
+
+GEMM_SHAPES = [
+    # (M, N, K, ta, tb, what)           -- the launches of the benchmarked step (bench.py by-shape table)
+    (32768, 3072, 1024, False, False, "q|k|v projection, B=16 x S=2048"),
+    (65536, 1024, 1024, False, False, "o projection, S=4096 rows"),
+    (32768, 1024, 4096, False, False, "down projection"),
+    (32768, 4096, 1024, False, True, "dgrad through down_proj (weight read contraction-major)"),
+    (8192, 1024, 32768, True, True, "gate|up weight gradient (split-K over 32768 event rows)"),
+    (1024, 1024, 262144, True, True, "token-level weight gradient (split-K over 262,144 token rows)"),
+    (262144, 3072, 1024, False, False, "token-level q|k|v projection"),
+    (32768, 3406, 1024, False, False, "lm_head chunk (N = 3406, ragged tile)"),
+]
+
+
+@pytest.mark.parametrize("M,N,K,ta,tb,what", GEMM_SHAPES, ids=[s[5].split(",")[0].split("(")[0].strip().replace(" ", "_") for s in GEMM_SHAPES])
+def test_projection_gemm_at_benchmarked_shapes(M, N, K, ta, tb, what):
+    """gemm_pp256_kernel (+ split-K reduction) on bf16-exact operands at the benchmarked shapes against an fp64 product
+    of the same operands on 128 sampled output rows x 512 sampled columns: |err| <= 2^-8 |c| (output rounding) + 1e-3 rms(c)
+    (fp32 accumulation order; split-K partial sums)."""
+    from midi_model_amd import ops
+    assert ops.get_option("gemm") == 1
+    a = _bf16_exact((K, M) if ta else (M, K), 50, 1.0).cuda()
+    b = _bf16_exact((K, N) if tb else (N, K), 51, 0.05).cuda()
+    ldn = (N + 63) // 64 * 64
+    buf = torch.full((M, ldn), float("nan"), dtype=torch.bfloat16, device="cuda")
+    out = buf[:, :N]
+    ops.gemm_nt(a, b, out, K=K, ta=ta, tb=tb)
+    g = torch.Generator().manual_seed(52)
+    rows = torch.randperm(M, generator=g)[:128].sort().values.cuda()
+    cols = torch.randperm(N, generator=g)[:512].sort().values.cuda()
+    A = (a[:, rows].T if ta else a[rows]).double().cpu()
+    Bm = (b[:, cols].T if tb else b[cols]).double().cpu()
+    want = A @ Bm.T
+    got = out[rows][:, cols].float().cpu().double()
+    assert torch.isnan(buf[:, N:]).all() or ldn == N, "the kernel wrote outside the output view"
+    assert torch.isfinite(got).all()
+    err = (got - want).abs()
+    bound = BF16_ULP * want.abs() + 1e-3 * want.pow(2).mean().sqrt()
+    assert (err <= bound).all(), (what, err.max().item(), (err / bound).max().item())
+
+
+def test_swiglu_epilogues_at_benchmarked_shape():
+    """the fused gate|up -> SwiGLU forward epilogue and the SwiGLU-backward dgrad epilogue at [32768 x 8192 x 1024] on
+    bf16-exact operands against fp64 on sampled rows (roundings as the unfused kernels: gate, up rounded to bf16 first)"""
+    from midi_model_amd import ops
+    M, I, K = 32768, 4096, 1024
+    x = _bf16_exact((M, K), 60).cuda()
+    wgu = _bf16_exact((2 * I, K), 61, 0.05).cuda()
+    if not ops.swiglu_fused_ok(x, I):
+        pytest.skip("fused epilogues disabled")
+    gu = torch.empty((M, 2 * I), dtype=torch.bfloat16, device="cuda")
+    a = torch.empty((M, I), dtype=torch.bfloat16, device="cuda")
+    ops.gemm_swiglu(x, wgu, gu, a)
+    rows = torch.arange(0, M, 131, device="cuda")[:200]
+    want_gu = x[rows].double().cpu() @ wgu.double().cpu().T
+    got_gu = gu[rows].float().cpu().double()
+    e = (got_gu - want_gu).abs()
+    assert (e <= BF16_ULP * want_gu.abs() + 1e-3 * want_gu.pow(2).mean().sqrt()).all(), e.max().item()
+    gr, ur = got_gu[:, :I], got_gu[:, I:]            # the kernel's own rounded gate / up
+    want_a = (gr / (1 + torch.exp(-gr))).float().bfloat16().double() * ur
+    e = (a[rows].float().cpu().double() - want_a).abs()
+    assert (e <= 2 * BF16_ULP * want_a.abs() + 1e-6).all(), e.max().item()
+    # backward: d gate|up = SwiGLU'(gu) * (dx @ wd)
+    dx = _bf16_exact((M, K), 62).cuda()
+    wd = _bf16_exact((K, I), 63, 0.05).cuda()
+    dgu = torch.empty((M, 2 * I), dtype=torch.bfloat16, device="cuda")
+    ops.gemm_dswiglu(dx, wd, gu, dgu)
+    da = (dx[rows].double().cpu() @ wd.double().cpu()).float().bfloat16().double()   # (mh_gemm rounds d a to bf16 first)
+    sg = 1 / (1 + torch.exp(-gr))
+    want_dg = da * ur * (sg * (1 + gr * (1 - sg)))
+    want_du = da * (gr * sg)
+    got = dgu[rows].float().cpu().double()
+    for nm, w_, g_ in (("dgate", want_dg, got[:, :I]), ("dup", want_du, got[:, I:])):
+        e = (g_ - w_).abs()
+        assert (e <= 3 * BF16_ULP * w_.abs() + 2e-3 * w_.pow(2).mean().sqrt()).all(), (nm, e.max().item())

@@ -61,3 +61,58 @@ def test_config_surface():
     cfg2 = mm.MIDIModelConfig.from_dict(d)
     assert cfg2.to_dict() == cfg.to_dict()
     assert cfg2.tokenizer.optimise_midi is True
+
+
+REF_DIR = "/root/reference"
+
+
+@pytest.mark.skipif(not os.path.exists(os.path.join(REF_DIR, "midi_tokenizer.py")), reason="reference tree not present")
+def test_reference_tokenizer_is_used_as_is_when_importable(monkeypatch):
+    """The boundary the reference's callers see: ``config.tokenizer`` / ``model.tokenizer`` is THE REFERENCE'S class when
+    its module is importable (train.py:60-64,214-228,397-406 and app.py:185,250 call tokenize / detokenize / augment /
+    check_quality / midi2img on that very object), and the device-side grammar tables come from its public attributes."""
+    import sys
+    import numpy as np
+    from midi_model_amd.tokenizer import grammar_tables, reference_tokenizer_module
+    monkeypatch.syspath_prepend(REF_DIR)
+    monkeypatch.delitem(sys.modules, "midi_tokenizer", raising=False)
+    try:
+        ref = reference_tokenizer_module()
+        assert ref is not None and ref.__file__.startswith(REF_DIR)
+        cfg = mm.MIDIModelConfig.from_name("tv2o-medium")
+        tok = cfg.tokenizer
+        assert type(tok) is ref.MIDITokenizerV2 and tok.optimise_midi is True
+        assert type(mm.MIDIModelConfig.from_name("tv1-medium").tokenizer) is ref.MIDITokenizerV1
+        # codec methods are the reference's own, intact: events -> tokens -> MIDI score -> tokens
+        events = [["set_tempo", 0, 0, 0, 120], ["patch_change", 0, 0, 1, 0, 5], ["note", 0, 0, 1, 0, 60, 100, 8],
+                  ["note", 1, 4, 1, 0, 64, 90, 4]]
+        seq = [[tok.bos_id] + [tok.pad_id] * 7] + [tok.event2tokens(e) for e in events] + [[tok.eos_id] + [tok.pad_id] * 7]
+        score = tok.detokenize(seq)
+        back = tok.tokenize(score)
+        assert isinstance(score, list) and len(back) >= 3 and all(len(r) == tok.max_token_seq for r in back)
+        assert all(0 <= t < tok.vocab_size for r in back for t in r)
+        aug = tok.augment(np.array(seq).tolist())
+        assert len(aug) == len(seq)
+        # tables: identical to the tables-only class's, through the free function on public attributes
+        mine = mm.MIDITokenizerV2()
+        assert grammar_tables(tok) == grammar_tables(mine)
+        assert tok.to_dict() == {**mine.to_dict(), "optimise_midi": True}
+        # the model takes its masks from the reference object and round-trips it through the config JSON
+        from midi_model_amd.model import MIDIModel
+        model = MIDIModel(mm.MIDIModelConfig.get_config("v2", True, 4, 4, 64, 128))
+        assert type(model.tokenizer) is ref.MIDITokenizerV2
+        first, lo, hi, arity = model._grammar()
+        assert int(first.sum()) == 7 and arity[tok.event_ids["note"]] == 7
+        cfg2 = mm.MIDIModelConfig.from_dict(__import__("json").loads(__import__("json").dumps(cfg.to_dict())))
+        assert type(cfg2.tokenizer) is ref.MIDITokenizerV2 and cfg2.tokenizer.optimise_midi is True
+        monkeypatch.setenv("MH_TABLES_ONLY_TOKENIZER", "1")
+        assert type(mm.MIDITokenizer("v2")) is mm.MIDITokenizerV2
+    finally:
+        sys.modules.pop("midi_tokenizer", None)
+
+
+def test_tables_only_tokenizer_says_it_has_no_codec():
+    tok = mm.MIDITokenizerV2()
+    for m in ("tokenize", "detokenize", "augment", "check_quality", "midi2img"):
+        with pytest.raises(NotImplementedError, match="reference's midi_tokenizer"):
+            getattr(tok, m)([])
