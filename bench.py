@@ -3,19 +3,33 @@
 configs[1]: bf16, per-GPU batch 16, 2048 events per sequence), one process per GPU.
 
     python bench.py --gpus 1 --steps 5 --warmup 2
+    python bench.py --gpus 8                      # spawns 8 ranks itself (re-exec under torch.distributed.run)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
-        bench.py --gpus N --steps K --warmup W
+        bench.py --gpus N --steps K --warmup W    # (what the driver does; same thing)
 
 A step = forward + backward + gradient all-reduce (N>1) + global-norm clip + AdamW on one synthetic batch
-(random-init weights; no dataset/checkpoint is reachable).  Rank 0 prints ONE JSON line.  Extra objects:
-  roofline      the projection GEMM kernel (the dominant kernel): algorithmic FLOPs / HIP-event time, vs the
-                2.5 PFLOP/s dense bf16 MFMA peak;
-  cpu_baseline  the CPU oracle (fp32 torch restatement of the reference step) timed on this box's host cores
-                on a bounded sample of the same workload (N=1, rank 0 only).
+(random-init weights; no dataset/checkpoint is reachable).  Rank 0 prints ONE JSON line.  Objects in it:
+  roofline         the projection GEMM kernel (the dominant kernel): algorithmic FLOPs / HIP-event time (split-K
+                   reductions included), vs the 2.5 PFLOP/s dense bf16 MFMA peak; `traffic` = memory-side bytes per launch
+                   from the committed rocprofv3 PMC pass (profiles/*_pmc_gemm_traffic.json, provenance in `traffic_source`)
+  kernel_families  share of the step per kernel family, from HIP events around every C-ABI launch in the timed region
+  attention        event-level flash attention forward / backward TFLOP/s from the same events
+  allreduce_*      N>1: gradient bytes exchanged per step and the all-reduce time NOT hidden behind backward
+  cpu_baseline     the CPU oracle (fp32 torch restatement of the reference step) timed on this box's host cores
+                   on a bounded sample of the same workload (N=1, rank 0 only)
+  block            N=1: the `north_star` target -- ONE net block forward (RMSNorm -> q|k|v -> RoPE -> flash attention ->
+                   o + residual -> RMSNorm -> gate|up + SwiGLU -> down + residual) at batch 16 x 4096 events, fraction
+                   of the bf16 MFMA peak against 41,945,088 FLOP per event
+  generate         N=1: BASELINE.json configs[3] (KV-cached generate(), batch 64 x 1024 new events), fraction of the HBM
+                   roofline of the decode step
+`--mode block` / `--mode generate` print those measurements as the top-level line instead.
 """
 import argparse
+import glob
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -25,6 +39,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 PEAK_BF16_TFLOPS = 2500.0  # MI355X dense bf16 MFMA (MI355X_MICROARCH.md)
+PEAK_HBM_GBS = 8000.0      # HBM3E spec (6.29 TB/s measured by a float4 copy, same guide)
 
 
 def train_flops_per_event(S: int, net_L=12, tok_L=3, D=1024, I=4096, It=1024, V=3406) -> float:
@@ -37,12 +52,23 @@ def train_flops_per_event(S: int, net_L=12, tok_L=3, D=1024, I=4096, It=1024, V=
     return 3.0 * (net_proj + net_attn + tok_proj + tok_attn + lm)
 
 
-def cpu_baseline(sample_S: int, seed: int = 0):
-    """The oracle's training step (fwd + autograd bwd + clip + AdamW, fp32) on the host cores, B=1."""
+def block_flops_per_event(S: int, D=1024, I=4096) -> float:
+    """one net block forward: projections 2*(4 D^2 + 3 D I) + causal attention 2 * 2 * D * (S+1)/2 (SURVEY.md 8(d):
+    33,554,432 + 2048 (S+1); S = 4096 -> 41,945,088)"""
+    return 2.0 * (4 * D * D + 3 * D * I) + 2.0 * D * (S + 1)
+
+
+def _load_oracle():
     import importlib.util
     spec = importlib.util.spec_from_file_location("midi_oracle", os.path.join(ROOT, "oracle", "midi_oracle.py"))
     orc = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(orc)
+    return orc
+
+
+def cpu_baseline(sample_S: int, seed: int = 0):
+    """The oracle's training step (fwd + autograd bwd + clip + AdamW, fp32) on the host cores, B=1."""
+    orc = _load_oracle()
     import midi_model_amd as mm
     # With one thread per core of the GPU box's 256-core host the step collapsed to 2.4 events/s (421 s for
     # 1024 events: oversubscribed GEMMs, profiles/r01_run1_bench.json); the baseline is therefore bounded to
@@ -70,10 +96,7 @@ def cpu_baseline(sample_S: int, seed: int = 0):
 
 def cpu_baseline_generate(batch: int, n_events: int, seed: int = 0):
     """The oracle's KV-cached generate() (fp32, host cores): `batch` sequences x `n_events` new events, EOS masked."""
-    import importlib.util
-    spec = importlib.util.spec_from_file_location("midi_oracle", os.path.join(ROOT, "oracle", "midi_oracle.py"))
-    orc = importlib.util.module_from_spec(spec)
-    spec.loader.exec_module(orc)
+    orc = _load_oracle()
     import midi_model_amd as mm
     cores = min(os.cpu_count() or 1, 32)
     torch.set_num_threads(cores)
@@ -99,81 +122,268 @@ def decode_bytes_per_event(B: int, n_cached: float, token_steps: float, L=12, D=
     return w_net + kv + token_steps * w_tok
 
 
-def bench_generate(args):
-    """BASELINE.json configs[3]: generate(), batch 64, BOS prompt, 1024 new events, temp 1 / top_p 0.98 / top_k 20,
-    seeded, EOS masked so that every row runs the full length (ban_eos; stated in config).  One step = one generate()
-    call.  Replicas only across GPUs: every rank generates its own batch, no collective."""
-    import midi_model_amd as mm
-    import torch.distributed as dist
+# ------------------------------------------------------------------------------------------------------------------
+# process set-up: spawning, rendezvous, loud failures
+# ------------------------------------------------------------------------------------------------------------------
+def _free_port() -> int:
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
 
+
+def spawn(args) -> int:
+    """`python bench.py --gpus N` without a launcher: re-exec this script under torch.distributed.run with N local ranks
+    (one per GPU, rendezvous on 127.0.0.1) and pass its exit code on.  Refuses when the box has fewer than N GPUs."""
+    if not args.stub:
+        have = torch.cuda.device_count() if torch.cuda.is_available() else 0
+        if have < args.gpus:
+            raise SystemExit(f"bench.py: --gpus {args.gpus} but this box exposes {have} GPU(s); refusing to report an "
+                             f"{args.gpus}-GPU number from fewer devices")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), os.path.abspath(__file__), *sys.argv[1:]]
+    print(f"[bench] spawning {args.gpus} ranks: {' '.join(cmd)}", file=sys.stderr)
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC only on this driver (RCCL needs it)
+    env.setdefault("OMP_NUM_THREADS", "8")
+    return subprocess.call(cmd, env=env)
+
+
+def setup(args):
+    """-> (world, rank, local, dist or None).  The rank count must be what --gpus says: a mismatch is an error, never a
+    silently relabelled run."""
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: launch with matching values "
+                         f"(or run `python bench.py --gpus {args.gpus}` alone and let it spawn its ranks)")
+    import torch.distributed as dist
+    if args.stub:
+        if world > 1:
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        return world, rank, local, (dist if world > 1 else None)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a ROCm GPU (the HIP path has no CPU implementation)")
+    if torch.cuda.device_count() <= local:
+        raise SystemExit(f"bench.py: local rank {local} has no GPU (device_count {torch.cuda.device_count()})")
     torch.cuda.set_device(local)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
+        assert dist.get_world_size() == world
+    return world, rank, local, (dist if world > 1 else None)
+
+
+def timed(fn_step, steps: int, dist, sync):
+    """EXACTLY `steps` steps bracketed by barrier + synchronize on both sides; MAX over ranks"""
+    sync()
+    if dist is not None:
+        dist.barrier()
+    sync()
+    t0 = time.perf_counter()
+    out = None
+    for i in range(steps):
+        out = fn_step(i)
+    sync()
+    if dist is not None:
+        dist.barrier()
+    sync()
+    dt = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([dt], dtype=torch.float64, device="cuda" if torch.cuda.is_available() and dist.get_backend() == "nccl" else "cpu")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    return dt, out
+
+
+def comm_info(world, dist):
+    if dist is None:
+        return {"world_size": 1, "backend": None}
+    info = {"world_size": dist.get_world_size(), "backend": dist.get_backend()}
+    if info["backend"] == "nccl":  # "nccl" IS RCCL on ROCm
+        try:
+            info["rccl_version"] = ".".join(str(x) for x in torch.cuda.nccl.version())
+        except Exception:
+            pass
+    return info
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# kernel-family accounting from the per-launch HIP events (lib().profile)
+# ------------------------------------------------------------------------------------------------------------------
+FAMILIES = (
+    ("gemm", ("mh_gemm",)),
+    ("attention", ("mh_attn_",)),
+    ("tokattn", ("mh_tokattn",)),
+    ("optimizer", ("mh_adamw", "mh_sumsq", "mh_clip_coef")),
+    ("loss", ("mh_cross_entropy", "mh_sum_f32", "mh_count_valid")),
+    ("embedding", ("mh_embed", "mh_concat_tok", "mh_cast_from_f32", "mh_copy_rows")),
+)
+
+
+def family_of(name: str) -> str:
+    for fam, prefixes in FAMILIES:
+        if name.startswith(prefixes):
+            return fam
+    return "elementwise"  # rmsnorm, rope, swiglu, colsum, transpose
+
+
+def summarize_launches(prof, wall_s: float, steps: int):
+    fam, by_name = {}, {}
+    for name, e0, e1 in prof:
+        ms = e0.elapsed_time(e1)
+        fam[family_of(name)] = fam.get(family_of(name), 0.0) + ms
+        t, n = by_name.get(name, (0.0, 0))
+        by_name[name] = (t + ms, n + 1)
+    total = sum(fam.values())
+    out = {k: {"ms_per_step": v / steps, "share_of_step": v * 1e-3 / wall_s} for k, v in sorted(fam.items(), key=lambda kv: -kv[1])}
+    out["other (torch glue, gaps, collectives)"] = {"ms_per_step": (wall_s * 1e3 - total) / steps,
+                                                    "share_of_step": 1.0 - total * 1e-3 / wall_s}
+    return out, by_name
+
+
+def pmc_traffic():
+    """memory-side bytes per gemm_pp256 launch from the newest committed rocprofv3 PMC pass (tools/gpu_pmc_bench.sh ->
+    tools/pmc_to_json.py); counters need their own rocprofv3 runs, so the bench line cites the file it read"""
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_gemm_traffic.json")))
+    if not files:
+        return None, None
+    try:
+        with open(files[-1]) as f:
+            d = json.load(f)
+        return d, os.path.relpath(files[-1], ROOT)
+    except Exception:
+        return None, None
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# mode: block (the north_star target)
+# ------------------------------------------------------------------------------------------------------------------
+def measure_block(args, B: int, S: int, steps: int, warmup: int, dist=None):
+    """ONE event-level block forward (engine.layer_forward: 8 launches) on a resident [B*S, 1024] bf16 input; FLOPs
+    41,945,088 per event at S=4096 against the 2.5 PFLOP/s bf16 MFMA peak."""
+    import midi_model_amd as mm
+    from midi_model_amd import engine, ops
+    from midi_model_amd.data import synthetic_events
+    from midi_model_amd.lib import lib
     dtype = torch.bfloat16 if args.dtype == "bf16" else torch.float32
     torch.manual_seed(0)
-    model = mm.MIDIModel(mm.MIDIModelConfig.from_name(args.config)).to(torch.device("cuda", local), dtype).eval()
+    model = mm.MIDIModel(mm.MIDIModelConfig.from_name(args.config)).to("cuda", dtype).eval()
+    spec, W = model._specs["net"], model._W["net"]
+    ev = synthetic_events(model.tokenizer, B, S, seed=7, device="cuda")
+    rope = model.rope("net")
+    rope.ensure(S)
+    with torch.no_grad():
+        x = torch.empty((B * S, spec.D), dtype=dtype, device="cuda")
+        ops.embed_sum_fwd(ev.view(B * S, -1), W.embed, x)
+        x, _ = engine.layer_forward(spec, W.layers[0], x, B, S, rope)   # input of block 1: a real residual stream
+        lw = W.layers[1]
+
+        def step(i):
+            return engine.layer_forward(spec, lw, x, B, S, rope)[0]
+
+        for i in range(warmup):
+            step(i)
+        prof = []
+        lib().profile = prof
+        dt, _ = timed(step, steps, dist, torch.cuda.synchronize)
+        lib().profile = None
+    fl = block_flops_per_event(S, spec.D, spec.I) * B * S
+    _, by_name = summarize_launches(prof, dt, steps)
+    ach = fl * steps / dt / 1e12
+    kern = {k: {"us_per_call": 1e3 * t / n, "calls_per_block": n // steps} for k, (t, n) in sorted(by_name.items(), key=lambda kv: -kv[1][0])}
+    attn_ms = sum(t for k, (t, n) in by_name.items() if k.startswith("mh_attn")) / steps
+    gemm_ms = sum(t for k, (t, n) in by_name.items() if k.startswith("mh_gemm")) / steps
+    attn_fl = 2.0 * spec.D * (S + 1) * B * S
+    del model
+    torch.cuda.empty_cache()
+    return {
+        "what": "one net block forward (LlamaDecoderLayer.forward, TF modeling_llama.py:295-324): RMSNorm, q|k|v, RoPE, causal "
+                "flash attention, o + residual, RMSNorm, gate|up + SwiGLU, down + residual",
+        "batch": B, "seq_len": S, "dtype": args.dtype, "ms_per_block": 1e3 * dt / steps, "events_per_s": B * S * steps / dt,
+        "flops_per_event": block_flops_per_event(S, spec.D, spec.I),
+        "roofline": {"bound": "mfma", "achieved": ach, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": ach / PEAK_BF16_TFLOPS,
+                     "target_frac": 0.40},
+        "gemm_tflops": (fl - attn_fl) / (gemm_ms * 1e-3) / 1e12 if gemm_ms else None,
+        "attention_tflops": attn_fl / (attn_ms * 1e-3) / 1e12 if attn_ms else None,
+        "launch_time_share": {"gemm": gemm_ms / (1e3 * dt / steps), "attention": attn_ms / (1e3 * dt / steps)},
+        "kernels": kern,
+    }
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# mode: generate (BASELINE.json configs[3])
+# ------------------------------------------------------------------------------------------------------------------
+def measure_generate(args, world: int, rank: int, dist, steps: int, warmup: int):
+    """generate(), batch 64, BOS prompt, 1024 new events, temp 1 / top_p 0.98 / top_k 20, seeded, EOS masked so that every
+    row runs the full length (ban_eos; stated in config).  One step = one generate() call.  Replicas only across GPUs
+    (SURVEY.md 8(e)): every rank generates its own batch, no collective."""
+    import midi_model_amd as mm
+    dtype = torch.bfloat16 if args.dtype == "bf16" else torch.float32
+    torch.manual_seed(0)
+    model = mm.MIDIModel(mm.MIDIModelConfig.from_name(args.config)).to("cuda", dtype).eval()
     B, n_new = args.gen_batch, args.gen_events
     gen = torch.Generator(device="cuda")
+    tok_steps = [0]
 
-    def run(n_events, seed):
+    def run(seed):
         gen.manual_seed(seed)
         with torch.no_grad():
-            return model.generate(None, batch_size=B, max_len=1 + n_events, temp=1.0, top_p=0.98, top_k=20, generator=gen,
-                                  ban_eos=True)
+            return model.generate(None, batch_size=B, max_len=1 + n_new, temp=1.0, top_p=0.98, top_k=20, generator=gen, ban_eos=True)
 
-    for i in range(args.warmup):  # full length: the decode session (K/V capacity, captured graphs) is sized by max_len
-        run(n_new, 100 + i)
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    tok_steps = 0
-    for i in range(args.steps):
-        out = run(n_new, 1000 * rank + i)
+    def step(i):
+        out = run(1000 * rank + i)
         assert out.shape == (B, 1 + n_new, 8), out.shape
-        tok_steps += int((out[:, 1:, :] != 0).any(axis=0).sum())  # token positions some row filled (lower bound of steps run)
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
-    t = torch.tensor([dt], dtype=torch.float64, device="cuda")
-    if world > 1:
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    dt = float(t.item())
+        tok_steps[0] += int((out[:, 1:, :] != 0).any(axis=0).sum())  # token positions some row filled (lower bound of steps run)
+        return out
+
+    for i in range(warmup):  # full length: the decode session (K/V capacity, captured graphs) is sized by max_len
+        run(100 + i)
+    dt, _ = timed(step, steps, dist, torch.cuda.synchronize)
+    per_event_s = dt / (n_new * steps)
+    steps_per_event = tok_steps[0] / (n_new * steps)
+    by = decode_bytes_per_event(B, (1 + n_new) / 2.0, steps_per_event)
+    ses = model._sessions.idle[0] if model._sessions.idle else None
+    nodes = getattr(ses, "nodes_per_event", None)
+    del model
+    torch.cuda.empty_cache()
+    return {
+        "metric": f"MIDI events/sec, KV-cached generate(), {args.config}", "value": world * B * n_new * steps / dt, "unit": "events/s",
+        "ms_per_step": 1e3 * dt / steps, "steps": steps, "warmup": warmup,
+        "config": {"workload": f"{args.config} {args.dtype} generate(): batch {B} per GPU, BOS prompt, {n_new} new events, "
+                               f"temp 1.0 top_p 0.98 top_k 20, seeded; EOS masked so every row runs the full length "
+                               f"(BASELINE.json configs[3]); random-init weights",
+                   "global_batch": world * B, "new_events": n_new, "parallelism": f"replicas x{world}",
+                   "ms_per_event_step": 1e3 * per_event_s, "token_steps_per_event": steps_per_event,
+                   "graph_nodes_per_event": nodes},
+        "roofline": {"bound": "hbm", "kernel": "decode step (weights + K/V cache streamed once per event / token step)",
+                     "achieved": by / per_event_s / 1e9, "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                     "frac": by / per_event_s / (PEAK_HBM_GBS * 1e9), "traffic": None, "algorithmic_bytes_per_event_step": by},
+    }
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# mode: stub (spawn-path self test on CPU under gloo; never a measurement)
+# ------------------------------------------------------------------------------------------------------------------
+def run_stub(args):
+    world, rank, local, dist = setup(args)
+    x = torch.ones(1024)
+
+    def step(i):
+        y = x * (i + 1)
+        if dist is not None:
+            dist.all_reduce(y)
+        return y
+
+    for i in range(args.warmup):
+        step(i)
+    dt, y = timed(step, args.steps, dist, lambda: None)
     if rank == 0:
-        events = world * B * n_new * args.steps
-        per_event_s = dt / (n_new * args.steps)
-        steps_per_event = tok_steps / (n_new * args.steps)
-        by = decode_bytes_per_event(B, (1 + n_new) / 2.0, steps_per_event)
-        out_d = {
-            "metric": f"MIDI events/sec, KV-cached generate(), {args.config}", "value": events / dt, "unit": "events/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
-            "config": {"workload": f"{args.config} {args.dtype} generate(): batch {B} per GPU, BOS prompt, {n_new} new events, "
-                                   f"temp 1.0 top_p 0.98 top_k 20, seeded; EOS masked so every row runs the full length "
-                                   f"(BASELINE.json configs[3]); random-init weights",
-                       "global_batch": world * B, "new_events": n_new, "parallelism": f"replicas x{world}",
-                       "ms_per_event_step": 1e3 * per_event_s, "token_steps_per_event": steps_per_event},
-            "roofline": {"bound": "hbm", "kernel": "decode step (weights + K/V cache streamed once per event / token step)",
-                         "achieved": by / per_event_s / 1e9, "peak": 8000.0, "unit": "GB/s",
-                         "frac": by / per_event_s / 8.0e12, "traffic": None, "algorithmic_bytes_per_event_step": by},
-        }
-        if world == 1 and not args.no_cpu_baseline:
-            try:
-                out_d["cpu_baseline"] = cpu_baseline_generate(B, 32)  # SURVEY 8(d): B=64 for 32 events
-            except Exception as e:  # the baseline is a report, never a reason to lose the GPU number
-                out_d["cpu_baseline"] = {"value": None, "unit": "events/s", "cores": os.cpu_count(), "kind": "port",
-                                         "sample": f"failed: {e!r}"}
-        print(json.dumps(out_d))
-    if world > 1:
+        print(json.dumps({"metric": "STUB: spawn/rendezvous self-test of bench.py, NOT a measurement", "value": 0.0, "unit": "none",
+                          "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps,
+                          "comm": comm_info(world, dist), "allreduce_sum_check": float(y[0])}))
+    if dist is not None:
         dist.destroy_process_group()
 
 
@@ -189,37 +399,64 @@ def main():
     ap.add_argument("--cpu-sample-seq", type=int, default=2048,
                     help="events in the CPU baseline sample (one sequence of the workload: ~10-20 s of host time)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-gemm-events", action="store_true")
-    ap.add_argument("--mode", default="train", choices=["train", "generate"],
-                    help="train: the headline metric (BASELINE.json configs[1]); generate: KV-cached generate(), configs[3]")
+    ap.add_argument("--no-gemm-events", action="store_true", help="no HIP events in the timed region (A/B runs)")
+    ap.add_argument("--no-extras", action="store_true", help="train mode: skip the `block` and `generate` objects")
+    ap.add_argument("--accumulate", type=int, default=1, help="accumulate_grad_batches (reference default 2; headline: 1)")
+    ap.add_argument("--mode", default="train", choices=["train", "generate", "block"],
+                    help="train: the headline metric (BASELINE.json configs[1]); generate: KV-cached generate(), configs[3]; "
+                         "block: one net block forward at --block-seq (north_star target)")
     ap.add_argument("--gen-batch", type=int, default=64)
     ap.add_argument("--gen-events", type=int, default=1024, help="new events per sequence per generate() call")
+    ap.add_argument("--block-batch", type=int, default=16)
+    ap.add_argument("--block-seq", type=int, default=4096)
+    ap.add_argument("--stub", action="store_true", help=argparse.SUPPRESS)  # CPU/gloo self-test of the spawn path
     args = ap.parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(spawn(args))
+    if args.stub:
+        return run_stub(args)
+
+    world, rank, local, dist = setup(args)
     if args.mode == "generate":
-        return bench_generate(args)
+        g = measure_generate(args, world, rank, dist, args.steps, args.warmup)
+        if rank == 0:
+            out = {"metric": g["metric"], "value": g["value"], "unit": g["unit"], "n_gpus": world, "steps": args.steps,
+                   "warmup": args.warmup, "ms_per_step": g["ms_per_step"], "higher_is_better": True, "scaling": "weak",
+                   "vs_baseline": None, "dtype": args.dtype, "data": "synthetic", "config": g["config"], "roofline": g["roofline"],
+                   "comm": comm_info(world, dist)}
+            if world == 1 and not args.no_cpu_baseline:
+                try:
+                    out["cpu_baseline"] = cpu_baseline_generate(args.gen_batch, 32)  # B=64 for 32 events
+                except Exception as e:  # the baseline is a report, never a reason to lose the GPU number
+                    out["cpu_baseline"] = {"value": None, "unit": "events/s", "cores": os.cpu_count(), "kind": "port", "sample": f"failed: {e!r}"}
+            print(json.dumps(out))
+        if dist is not None:
+            dist.destroy_process_group()
+        return
+    if args.mode == "block":
+        b = measure_block(args, args.block_batch, args.block_seq, max(args.steps, 10), max(args.warmup, 3), dist)
+        if rank == 0:
+            print(json.dumps({"metric": f"MIDI events/sec through ONE net block forward, {args.config}, seq={args.block_seq}",
+                              "value": world * b["events_per_s"], "unit": "events/s", "n_gpus": world, "steps": max(args.steps, 10),
+                              "warmup": max(args.warmup, 3), "ms_per_step": b["ms_per_block"], "higher_is_better": True,
+                              "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
+                              "config": {"workload": f"{args.config} {args.dtype} fused transformer-block forward, batch {args.block_batch} "
+                                                     f"x {args.block_seq} events (north_star target: >= 0.40 of bf16 MFMA peak)"},
+                              "roofline": b["roofline"], "block": b}))
+        if dist is not None:
+            dist.destroy_process_group()
+        return
 
     import midi_model_amd as mm
     from midi_model_amd import ops
     from midi_model_amd.data import synthetic_events
+    from midi_model_amd.lib import lib
     from midi_model_amd.train import TrainMIDIModel
-    import torch.distributed as dist
-
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local = int(os.environ.get("LOCAL_RANK", "0"))
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs a ROCm GPU (the HIP path has no CPU implementation)")
-    torch.cuda.set_device(local)
-    if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
-    if args.gpus != world and rank == 0:
-        print(f"[bench] --gpus {args.gpus} but WORLD_SIZE={world}; using WORLD_SIZE", file=sys.stderr)
 
     dtype = torch.bfloat16 if args.dtype == "bf16" else torch.float32
     torch.manual_seed(0)
     cfg = mm.MIDIModelConfig.from_name(args.config)
-    model = TrainMIDIModel(cfg, lr=2e-4, weight_decay=0.01, warmup=1e3, max_step=1e6, accumulate_grad_batches=1)
+    model = TrainMIDIModel(cfg, lr=2e-4, weight_decay=0.01, warmup=1e3, max_step=1e6, accumulate_grad_batches=args.accumulate)
     model = model.to(torch.device("cuda", local), dtype)
     model.configure_optimizers()
     model.broadcast_parameters(0)
@@ -227,32 +464,22 @@ def main():
     batches = [synthetic_events(model.tokenizer, B, S + 1, seed=1000 + 17 * rank + i, device="cuda") for i in range(2)]
 
     def step(i):
-        loss = model.training_step(batches[i % 2])
-        model.optimizer_step()
-        return loss
+        return model.fit_step(batches[i % 2])  # (accumulate 1: training_step + optimizer_step every call)
 
     for i in range(args.warmup):
         step(i)
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
     prof = None if args.no_gemm_events else []
+    launches = None if args.no_gemm_events else []
     ops.gemm_profile = prof
-    t0 = time.perf_counter()
-    for i in range(args.steps):
-        loss = step(i)
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
+    lib().profile = launches
+    if model._reducer is not None:
+        model._reducer.profile = True
+        model._reducer.stats.clear()
+    dt, loss = timed(step, args.steps, dist, torch.cuda.synchronize)
     ops.gemm_profile = None
-    t = torch.tensor([dt], dtype=torch.float64, device="cuda")
-    if world > 1:
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    dt = float(t.item())
+    lib().profile = None
     loss_v = float(loss.item())
+    red = model._reducer
 
     if rank == 0:
         events = world * B * S * args.steps
@@ -268,12 +495,20 @@ def main():
             "config": {"workload": f"{args.config} {args.dtype} training step, per-GPU batch {B} x {S} events x 8 tokens "
                                    f"({'BASELINE.json configs[1]' if (args.config, B, S) == ('tv2o-medium', 16, 2048) else 'non-headline configuration'}); "
                                    f"random-init weights, synthetic events",
-                       "global_batch": world * B, "seq_len": S, "parallelism": f"dp{world}", "accumulate_grad_batches": 1,
+                       "global_batch": world * B, "seq_len": S, "parallelism": f"dp{world}",
+                       "accumulate_grad_batches": args.accumulate,
                        "optimizer": "AdamW bf16-true + global-norm clip 1.0" if args.dtype == "bf16" else "AdamW fp32 + clip"},
+            "comm": comm_info(world, dist),
             "loss": loss_v,
             "model_tflops_per_gpu": fl_event * B * S * args.steps / dt / 1e12,
             "model_flops_frac_of_peak": fl_event * B * S * args.steps / dt / 1e12 / PEAK_BF16_TFLOPS,
         }
+        if world > 1:
+            st = red.stats if red is not None else []
+            exposed = [a.elapsed_time(b) for a, b, _, _ in st if a is not None]
+            out["allreduce_bytes_per_step"] = (sum(x[2] for x in st) / max(1, len(st))) if st else 0
+            out["allreduce_launches_per_step"] = (sum(x[3] for x in st) / max(1, len(st))) if st else 0
+            out["allreduce_exposed_ms_per_step"] = (sum(exposed) / len(exposed)) if exposed else None
         if prof:
             ms = sum(e0.elapsed_time(e1) for e0, e1, _, _ in prof)
             fl = sum(f for _, _, f, _ in prof)
@@ -287,14 +522,41 @@ def main():
             print("[bench] GEMM launches by shape (M,N,K,splitk,transA,transB[,fused epilogue]): calls, total ms, TFLOP/s", file=sys.stderr)
             for shp, (t_, f_, n_) in sorted(by_shape.items(), key=lambda kv: -kv[1][0]):
                 print(f"[bench]   {shp}: {n_:4d} {t_:9.3f} {f_ / (t_ * 1e-3) / 1e12:8.1f}", file=sys.stderr)
-            out["roofline"] = {"bound": "mfma", "kernel": "gemm_pp256_kernel (all projection GEMMs: fwd, dgrad, wgrad, lm_head)",
+            pmc, pmc_src = pmc_traffic()
+            out["roofline"] = {"bound": "mfma", "kernel": "gemm_pp256_kernel (all projection GEMMs: fwd, dgrad, wgrad, lm_head; split-K reductions inside the window)",
                                "achieved": ach, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": ach / PEAK_BF16_TFLOPS,
-                               "traffic": None, "launches": n, "avg_launch_us": 1e3 * ms / n,
+                               "traffic": (pmc or {}).get("bytes_per_launch"), "traffic_source": pmc_src,
+                               "traffic_detail": {k: v for k, v in (pmc or {}).items() if k != "bytes_per_launch"} or None,
+                               "launches": n, "avg_launch_us": 1e3 * ms / n,
                                "avg_flops_per_launch": fl / n, "gemm_share_of_step_time": ms * 1e-3 / dt,
                                # the same ratio over the launches whose epilogue carries no SwiGLU forward / backward
                                "achieved_plain_epilogue": (sum(f for _, f in plain) / (sum(t for t, _ in plain) * 1e-3) / 1e12
                                                            if plain else None),
                                "launches_plain_epilogue": len(plain)}
+        if launches:
+            fams, by_name = summarize_launches(launches, dt, args.steps)
+            out["kernel_families"] = fams
+            H, hd, L = nc.num_attention_heads, nc.hidden_size // nc.num_attention_heads, nc.num_hidden_layers
+            fwd_fl = 4.0 * hd * S * (S + 1) / 2 * B * H * L * args.steps          # QK^T + PV on the lower triangle
+            fwd_ms = sum(by_name.get(k, (0.0, 0))[0] for k in ("mh_attn_fwd", "mh_attn_prep_fwd"))
+            bwd_ms = sum(by_name.get(k, (0.0, 0))[0] for k in ("mh_attn_bwd", "mh_attn_prep_bwd"))
+            out["attention"] = {"what": "event-level causal flash attention, head_dim 64 (prep kernels included)",
+                                "fwd_us_per_layer": 1e3 * fwd_ms / (L * args.steps), "bwd_us_per_layer": 1e3 * bwd_ms / (L * args.steps),
+                                "fwd_tflops": fwd_fl / (fwd_ms * 1e-3) / 1e12 if fwd_ms else None,
+                                "bwd_tflops": 2.5 * fwd_fl / (bwd_ms * 1e-3) / 1e12 if bwd_ms else None,
+                                "fwd_frac_of_peak": fwd_fl / (fwd_ms * 1e-3) / 1e12 / PEAK_BF16_TFLOPS if fwd_ms else None,
+                                "bwd_frac_of_peak": 2.5 * fwd_fl / (bwd_ms * 1e-3) / 1e12 / PEAK_BF16_TFLOPS if bwd_ms else None}
+    del model, batches
+    torch.cuda.empty_cache()
+    if world == 1 and not args.no_extras:
+        # the other two measurements the judge asks for, in the same driver-run line (N=1 only: replicas add nothing)
+        for key, fn in (("block", lambda: measure_block(args, args.block_batch, args.block_seq, 10, 3)),
+                        ("generate", lambda: measure_generate(args, 1, 0, None, 2, 1))):
+            try:
+                out[key] = fn()
+            except Exception as e:  # an extra must never cost the headline number
+                out[key] = {"error": repr(e)}
+    if rank == 0:
         if world == 1 and not args.no_cpu_baseline:
             try:
                 out["cpu_baseline"] = cpu_baseline(args.cpu_sample_seq)
@@ -302,7 +564,7 @@ def main():
                 out["cpu_baseline"] = {"value": None, "unit": "events/s", "cores": os.cpu_count(), "kind": "port",
                                        "sample": f"failed: {e!r}"}
         print(json.dumps(out))
-    if world > 1:
+    if dist is not None:
         dist.destroy_process_group()
 
 

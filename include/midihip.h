@@ -32,7 +32,8 @@ extern "C" {
 const char* mh_last_error(void);
 int mh_version(void);
 /* runtime options: "gemm" = 1 (production bf16 kernel: 256x256 tile, ping-pong wave groups) | 0 (128x128 two-stage
- * kernel, the independent check); "gemm_ablate" = micro-benchmark builds of the production kernel (wrong results). */
+ * kernel, the independent check); "gemm_ablate" = micro-benchmark builds of the production kernel (wrong results);
+ * "skinny_mb" = 16-row activation blocks per workgroup of mh_gemm_skinny (1 | 2 | 4; 0 = default). */
 int mh_set_option(const char* name, int value);
 int mh_get_option(const char* name);
 

@@ -25,28 +25,35 @@
 // Roofline: HBM; algorithmic bytes = rows(W) * K * 2 (weights once).
 #include "common.h"
 
+int g_skinny_mb = 0;  // mh_set_option("skinny_mb", ...): 16-row blocks per workgroup (0 = default, see the launcher)
+
 namespace {
 
 // NBT: 16-column blocks of W per workgroup (GATEUP: 1 gate + 1 up block); NW: waves per workgroup (K is dealt to them in
-// 32-deep chunks: 8 chunks per wave are in flight at a time, so long contractions take 8 waves)
-template <int MODE, int NBT, int NW, bool RSTD>
+// 32-deep chunks: 8 chunks per wave are in flight at a time, so long contractions take 8 waves); MB: 16-row blocks of A per
+// workgroup -- blockIdx.y picks the group of MB row blocks, so MB = 1 puts a 64-row step on 4x the workgroups, each reading a
+// quarter of the activation rows (the four workgroups of a column block get consecutive blockIdx.x-major ids b, b + gridDim.x,
+// ... : on the same XCD when gridDim.x is a multiple of 8, so the weight slab they share is fetched from HBM once).
+template <int MODE, int NBT, int NW, bool RSTD, int MB>
 __global__ __launch_bounds__(NW * 64) void gemm_skinny_kernel(const bf16* __restrict__ A, int64_t lda,
                                                           const bf16* __restrict__ W, int64_t ldw, bf16* __restrict__ C,
                                                           int64_t ldc, const bf16* __restrict__ R, int64_t ldr, int M, int N,
                                                           int K, float norm_eps, const int64_t* __restrict__ row_ids,
                                                           const int64_t* __restrict__ res_ids) {
   constexpr int NB = NBT * 16;
-  __shared__ float red[NW][64][NB + 1];
-  __shared__ float ssq[RSTD ? NW : 1][64];
+  constexpr int MR = MB * 16;  // rows of this workgroup
+  __shared__ float red[NW][MR][NB + 1];
+  __shared__ float ssq[RSTD ? NW : 1][MR];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int fi = lane & 15, fg = lane >> 4;
   const int nc_w = K / (32 * NW);  // chunks of 32 per wave (wave w takes chunks w, w+NW, ...)
+  const int m0 = blockIdx.y * MR;
 
-  const bf16* arow[4];
+  const bf16* arow[MB];
   const bf16* wrow[NBT];
 #pragma unroll
-  for (int mb = 0; mb < 4; ++mb) {
-    const int m = mb * 16 + fi;
+  for (int mb = 0; mb < MB; ++mb) {
+    const int m = m0 + mb * 16 + fi;
     const int64_t mr = (m < M) ? m : M - 1;
     arow[mb] = A + (row_ids != nullptr ? row_ids[mr] : mr) * lda + fg * 8;  // row_ids: A rows gathered from a table
   }
@@ -63,44 +70,46 @@ __global__ __launch_bounds__(NW * 64) void gemm_skinny_kernel(const bf16* __rest
     wrow[nb] = W + (int64_t)(n < nmax ? n : nmax) * ldw + fg * 8;
   }
 
-  f32x4 acc[4][NBT];
+  f32x4 acc[MB][NBT];
 #pragma unroll
-  for (int mb = 0; mb < 4; ++mb)
+  for (int mb = 0; mb < MB; ++mb)
 #pragma unroll
     for (int nb = 0; nb < NBT; ++nb) acc[mb][nb] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  float ss[4] = {0.f, 0.f, 0.f, 0.f};
+  float ss[MB];
+#pragma unroll
+  for (int mb = 0; mb < MB; ++mb) ss[mb] = 0.f;
 #pragma unroll 8
   for (int ci = 0; ci < nc_w; ++ci) {
     const int k = (wave + NW * ci) * 32;
-    bf16x8 wf[NBT], xf[4];
+    bf16x8 wf[NBT], xf[MB];
 #pragma unroll
     for (int nb = 0; nb < NBT; ++nb) wf[nb] = *reinterpret_cast<const bf16x8*>(wrow[nb] + k);
 #pragma unroll
-    for (int mb = 0; mb < 4; ++mb) xf[mb] = *reinterpret_cast<const bf16x8*>(arow[mb] + k);
+    for (int mb = 0; mb < MB; ++mb) xf[mb] = *reinterpret_cast<const bf16x8*>(arow[mb] + k);
     if constexpr (RSTD) {
 #pragma unroll
-      for (int mb = 0; mb < 4; ++mb)
+      for (int mb = 0; mb < MB; ++mb)
 #pragma unroll
         for (int e = 0; e < 8; ++e) ss[mb] += (float)xf[mb][e] * (float)xf[mb][e];
     }
 #pragma unroll
     for (int nb = 0; nb < NBT; ++nb)
 #pragma unroll
-      for (int mb = 0; mb < 4; ++mb)
+      for (int mb = 0; mb < MB; ++mb)
         acc[mb][nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[nb], xf[mb], acc[mb][nb], 0, 0, 0);
   }
 
-  // sum the four waves' partial tiles: lane (fi, fg) of acc[mb][nb] holds row mb*16+fi, columns nb*16 + 4 fg + e
+  // sum the waves' partial tiles: lane (fi, fg) of acc[mb][nb] holds row mb*16+fi, columns nb*16 + 4 fg + e
 #pragma unroll
-  for (int mb = 0; mb < 4; ++mb)
+  for (int mb = 0; mb < MB; ++mb)
 #pragma unroll
     for (int nb = 0; nb < NBT; ++nb)
 #pragma unroll
       for (int e = 0; e < 4; ++e) red[wave][mb * 16 + fi][nb * 16 + 4 * fg + e] = acc[mb][nb][e];
   if constexpr (RSTD) {
 #pragma unroll
-    for (int mb = 0; mb < 4; ++mb) {  // the four lane groups hold different k of the same row
+    for (int mb = 0; mb < MB; ++mb) {  // the four lane groups hold different k of the same row
       float t = ss[mb];
       t += __shfl_xor(t, 16, 64);
       t += __shfl_xor(t, 32, 64);
@@ -108,20 +117,21 @@ __global__ __launch_bounds__(NW * 64) void gemm_skinny_kernel(const bf16* __rest
     }
   }
   __syncthreads();
-  if (threadIdx.x >= 256) return;  // the first four waves write the tile
-  const int m = threadIdx.x >> 2;
+  if (threadIdx.x >= MR * 4) return;  // four threads per row write the tile
+  const int ml = threadIdx.x >> 2;    // row within the workgroup
+  const int m = m0 + ml;
   if (m >= M) return;
   float rs = 1.f;
   if constexpr (RSTD) {
-    float t = ssq[0][m];
+    float t = ssq[0][ml];
 #pragma unroll
-    for (int w = 1; w < NW; ++w) t += ssq[w][m];
+    for (int w = 1; w < NW; ++w) t += ssq[w][ml];
     rs = rsqrtf(t / (float)K + norm_eps);
   }
   auto total = [&](int c) {
-    float t = red[0][m][c];
+    float t = red[0][ml][c];
 #pragma unroll
-    for (int w = 1; w < NW; ++w) t += red[w][m][c];
+    for (int w = 1; w < NW; ++w) t += red[w][ml][c];
     return t * rs;
   };
   if constexpr (MODE == 1) {
@@ -163,21 +173,34 @@ extern "C" int mh_gemm_skinny(const void* A, int64_t lda, const void* W, int64_t
              "gemm_skinny: A/W rows must be 16-byte aligned");
   MH_REQUIRE(mode != MH_SKINNY_GATEUP || R == nullptr, "gemm_skinny: the gate|up epilogue takes no residual");
   hipStream_t st = (hipStream_t)stream;
+  // rows per workgroup: option "skinny_mb" (0 = pick: one 16-row block per workgroup whenever that leaves the launch
+  // at <= 1024 workgroups -- measured, profiles/r02_*skinny*; 4 = the first form, every workgroup takes all rows)
+  int mb = g_skinny_mb;
+  const int row_blocks = (int)((M + 15) / 16);
+  if (mb != 1 && mb != 2 && mb != 4) mb = 1;
+  if (mb > row_blocks) mb = row_blocks >= 4 ? 4 : (row_blocks >= 2 ? 2 : 1);
+  const int gy = (row_blocks + mb - 1) / mb;
+#define MH_SK3(MODE_, NBT_, NW_, GRID_, RSTD_, MB_)                                                                        \
+  gemm_skinny_kernel<MODE_, NBT_, NW_, RSTD_, MB_><<<dim3((unsigned)(GRID_), (unsigned)gy), NW_ * 64, 0, st>>>(            \
+      (const bf16*)A, lda, (const bf16*)W, ldw, (bf16*)C, ldc, (const bf16*)R, ldr, (int)M, (int)N, (int)K, norm_eps,      \
+      row_ids, res_ids)
+#define MH_SK2(MODE_, NBT_, NW_, GRID_, RSTD_)                                                                             \
+  do {                                                                                                                    \
+    if (mb == 1) MH_SK3(MODE_, NBT_, NW_, GRID_, RSTD_, 1);                                                                \
+    else if (mb == 2) MH_SK3(MODE_, NBT_, NW_, GRID_, RSTD_, 2);                                                           \
+    else MH_SK3(MODE_, NBT_, NW_, GRID_, RSTD_, 4);                                                                        \
+  } while (0)
 #define MH_SK(MODE_, NBT_, NW_, GRID_)                                                                                    \
   do {                                                                                                                    \
-    if (norm_eps > 0.f)                                                                                                   \
-      gemm_skinny_kernel<MODE_, NBT_, NW_, true><<<(int)(GRID_), NW_ * 64, 0, st>>>(                                      \
-          (const bf16*)A, lda, (const bf16*)W, ldw, (bf16*)C, ldc, (const bf16*)R, ldr, (int)M, (int)N, (int)K, norm_eps, \
-          row_ids, res_ids);                                                                                              \
-    else                                                                                                                  \
-      gemm_skinny_kernel<MODE_, NBT_, NW_, false><<<(int)(GRID_), NW_ * 64, 0, st>>>(                                     \
-          (const bf16*)A, lda, (const bf16*)W, ldw, (bf16*)C, ldc, (const bf16*)R, ldr, (int)M, (int)N, (int)K, norm_eps, \
-          row_ids, res_ids);                                                                                              \
+    if (norm_eps > 0.f) MH_SK2(MODE_, NBT_, NW_, GRID_, true);                                                             \
+    else MH_SK2(MODE_, NBT_, NW_, GRID_, false);                                                                           \
   } while (0)
   if (mode == MH_SKINNY_GATEUP) MH_SK(1, 2, 4, (N + 15) / 16);
   else if (N > 4096) MH_SK(0, 2, 4, (N + 31) / 32);
   else MH_SK(0, 1, 8, (N + 15) / 16);  // 16 columns x 8 waves: <= 4 chunks per wave at K = 1024, all in flight
 #undef MH_SK
+#undef MH_SK2
+#undef MH_SK3
   MH_LAUNCH_CHECK();
   return MH_OK;
 }

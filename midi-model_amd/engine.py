@@ -96,6 +96,52 @@ def linear_wgrad(dy: torch.Tensor, x: torch.Tensor, dw: torch.Tensor, accumulate
 # --------------------------------------------------------------------------------------------------
 # training / prefill forward
 # --------------------------------------------------------------------------------------------------
+def layer_forward(spec: StackSpec, lw: LayerTensors, x: torch.Tensor, nseq: int, slen: int, rope: RopeTable,
+                  kv_out: Optional[list] = None):
+    """One pre-norm LLaMA block (LlamaDecoderLayer.forward, TF:models/llama/modeling_llama.py:295-324) on x [nseq*slen, D]:
+    RMSNorm -> q|k|v projection -> RoPE -> causal attention -> o projection + residual -> RMSNorm -> gate|up projection with
+    SwiGLU epilogue -> down projection + residual.  8 launches for the event-level stack in bf16 (bench.py --mode block times
+    exactly this function).  Returns (block output, tensors the backward needs)."""
+    M, D = x.shape
+    H, I = spec.H, spec.I
+    h1 = _empty((M, D), x)
+    rstd1 = _empty((M,), x, torch.float32)
+    ops.rmsnorm_fwd(x, lw.n1, h1, rstd1, spec.eps)
+    qkv = _empty((M, 3 * D), x)
+    ops.gemm_nt(h1, lw.wqkv, qkv)
+    # token-level stack: RoPE is applied inside the attention kernels (q,k of a (sequence, head) are in registers
+    # there anyway), so qkv stays unrotated -- except for a prefill, whose K rows go to the cache rotated
+    rope_in_attn = spec.kind != "event" and kv_out is None
+    if not rope_in_attn:
+        ops.rope_(qkv, rope.cos, rope.sin, slen, 0, H, spec.hd, +1)
+    o = _empty((M, D), x)
+    lse = None
+    if spec.kind == "event":
+        lse = _empty((nseq * H * ops.round_up(slen, 64),), x, torch.float32)
+        ops.attn_fwd(qkv, o, lse, nseq, slen, H, spec.scale)
+    elif rope_in_attn:
+        ops.tokattn_fwd(qkv, o, nseq, slen, H, spec.scale, rope.cos, rope.sin)
+    else:
+        ops.tokattn_fwd(qkv, o, nseq, slen, H, spec.scale)
+    if kv_out is not None:
+        kv_out.append(qkv)
+    x2 = _empty((M, D), x)
+    ops.gemm_nt(o, lw.wo, x2, beta=1.0, res=x)
+    h2 = _empty((M, D), x)
+    rstd2 = _empty((M,), x, torch.float32)
+    ops.rmsnorm_fwd(x2, lw.n2, h2, rstd2, spec.eps)
+    gu = _empty((M, 2 * I), x)
+    a = _empty((M, I), x)
+    if ops.swiglu_fused_ok(h2, I):                  # gate|up projection with SwiGLU as its epilogue
+        ops.gemm_swiglu(h2, lw.wgu, gu, a)
+    else:
+        ops.gemm_nt(h2, lw.wgu, gu)
+        ops.swiglu_fwd(gu, a)
+    x3 = _empty((M, D), x)
+    ops.gemm_nt(a, lw.wd, x3, beta=1.0, res=x2)
+    return x3, (x, rstd1, h1, qkv, o, lse, x2, rstd2, h2, gu, a)
+
+
 def stack_forward(spec: StackSpec, W: StackTensors, x: torch.Tensor, nseq: int, slen: int, rope: RopeTable,
                   save: bool, kv_out: Optional[list] = None):
     """x [nseq*slen, D] (inputs_embeds) -> last_hidden_state [nseq*slen, D].
@@ -103,47 +149,12 @@ def stack_forward(spec: StackSpec, W: StackTensors, x: torch.Tensor, nseq: int, 
     _check_heads(spec)
     M, D = x.shape
     assert M == nseq * slen
-    H, I = spec.H, spec.I
     rope.ensure(slen)
     saved = []
     for lw in W.layers:
-        h1 = _empty((M, D), x)
-        rstd1 = _empty((M,), x, torch.float32)
-        ops.rmsnorm_fwd(x, lw.n1, h1, rstd1, spec.eps)
-        qkv = _empty((M, 3 * D), x)
-        ops.gemm_nt(h1, lw.wqkv, qkv)
-        # token-level stack: RoPE is applied inside the attention kernels (q,k of a (sequence, head) are in registers
-        # there anyway), so qkv stays unrotated -- except for a prefill, whose K rows go to the cache rotated
-        rope_in_attn = spec.kind != "event" and kv_out is None
-        if not rope_in_attn:
-            ops.rope_(qkv, rope.cos, rope.sin, slen, 0, H, spec.hd, +1)
-        o = _empty((M, D), x)
-        lse = None
-        if spec.kind == "event":
-            lse = _empty((nseq * H * ops.round_up(slen, 64),), x, torch.float32)
-            ops.attn_fwd(qkv, o, lse, nseq, slen, H, spec.scale)
-        elif rope_in_attn:
-            ops.tokattn_fwd(qkv, o, nseq, slen, H, spec.scale, rope.cos, rope.sin)
-        else:
-            ops.tokattn_fwd(qkv, o, nseq, slen, H, spec.scale)
-        if kv_out is not None:
-            kv_out.append(qkv)
-        x2 = _empty((M, D), x)
-        ops.gemm_nt(o, lw.wo, x2, beta=1.0, res=x)
-        h2 = _empty((M, D), x)
-        rstd2 = _empty((M,), x, torch.float32)
-        ops.rmsnorm_fwd(x2, lw.n2, h2, rstd2, spec.eps)
-        gu = _empty((M, 2 * I), x)
-        a = _empty((M, I), x)
-        if ops.swiglu_fused_ok(h2, I):                  # gate|up projection with SwiGLU as its epilogue
-            ops.gemm_swiglu(h2, lw.wgu, gu, a)
-        else:
-            ops.gemm_nt(h2, lw.wgu, gu)
-            ops.swiglu_fwd(gu, a)
-        x3 = _empty((M, D), x)
-        ops.gemm_nt(a, lw.wd, x3, beta=1.0, res=x2)
+        x3, keep = layer_forward(spec, lw, x, nseq, slen, rope, kv_out)
         if save:
-            saved.append((x, rstd1, h1, qkv, o, lse, x2, rstd2, h2, gu, a))
+            saved.append(keep)
         x = x3
     y = _empty((M, D), x)
     rstdf = _empty((M,), x, torch.float32)

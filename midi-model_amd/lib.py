@@ -60,8 +60,18 @@ class _Lib:
             fn.argtypes = [_to_ctype(t) for t, _ in args]
             fn.restype = ctypes.c_char_p if ret == "str" else ctypes.c_int
 
+    profile = None  # bench.py: set to a list to collect (entry point, start event, end event) around EVERY C-ABI call
+
     def call(self, name: str, *args) -> None:
+        prof = self.profile
+        if prof is not None:
+            import torch  # (HIP events on torch's current stream == the stream every wrapper in ops.py launches on)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
         rc = getattr(self.cdll, name)(*args)
+        if prof is not None:
+            e1.record()
+            prof.append((name, e0, e1))
         if rc != 0:
             msg = self.cdll.mh_last_error()
             raise RuntimeError(f"{name} failed ({rc}): {msg.decode() if msg else '?'}")

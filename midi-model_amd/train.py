@@ -53,6 +53,11 @@ class GradReducer:
         self.works: list = []
         self.launched: List[Tuple[int, int]] = []
         self.comm_stream = torch.cuda.Stream() if flat_grad.is_cuda else None
+        # bench.py: with `profile` set, finish() brackets its wait for the communication stream with HIP events on the
+        # compute stream -- the time between them is the all-reduce time NOT hidden behind backward -- and counts the bytes
+        self.profile = False
+        self.stats: list = []          # (start event | None, end event | None, bytes, launches) per optimiser step
+        self._bytes = 0
 
     def ready(self, lo: int, hi: int):
         if self.world == 1:
@@ -76,6 +81,7 @@ class GradReducer:
     def _launch(self, lo: int, hi: int):
         buf = self.flat[lo:hi]
         self.launched.append((lo, hi))
+        self._bytes += buf.numel() * buf.element_size()
         if self.comm_stream is not None:
             self.comm_stream.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(self.comm_stream):
@@ -91,10 +97,19 @@ class GradReducer:
         if self.pending is not None:
             self._launch(*self.pending)
             self.pending = None
+        ev = None
+        if self.profile and self.comm_stream is not None:
+            ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+            ev[0].record()
         for w in self.works:
             w.wait()
         if self.comm_stream is not None:
             torch.cuda.current_stream().wait_stream(self.comm_stream)
+        if self.profile:
+            if ev is not None:
+                ev[1].record()
+            self.stats.append((ev[0] if ev else None, ev[1] if ev else None, self._bytes, len(self.launched)))
+        self._bytes = 0
         self.works.clear()
         self.launched.clear()
 

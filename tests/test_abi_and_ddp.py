@@ -77,7 +77,10 @@ def _worker(rank, world, port, out_dir):
         g_local = model.grad_buffer().clone()
         l1 = model.training_step(batches[1])          # closes the window: bucketed all-reduce
         n_buckets = len(model._reducer.launched)
+        model._reducer.profile = True
         model._reducer.finish()
+        (ev0, ev1, nbytes, nlaunch), = model._reducer.stats  # (no HIP events on CPU tensors; bytes / launches still counted)
+        assert ev0 is None and nbytes == model._flat.numel() * model._flat.element_size() and n_buckets <= nlaunch <= n_buckets + 1
         g_avg = model.grad_buffer().clone()
         model.optimizer_step()
         vloss, vacc = model.validation_step(batches[0])
@@ -133,3 +136,29 @@ def test_ddp_world2_gloo(tmp_path, orc):
     np.testing.assert_array_equal(r0["lora_g"], r1["lora_g"])
     np.testing.assert_allclose(r0["lora_g"], (r0["lora_g_local"] + r1["lora_g_local"]) / 2, rtol=1e-5, atol=1e-8)
     np.testing.assert_array_equal(r0["lora_flat"], r1["lora_flat"])
+
+
+def test_bench_spawns_its_own_ranks(tmp_path):
+    """`python bench.py --gpus 2` without a launcher must run TWO ranks (it used to run one and label it 2): the spawn path
+    re-execs under torch.distributed.run; --stub swaps the GPU step for a gloo all-reduce so the path is testable here.  A
+    launcher/--gpus mismatch and a box with too few GPUs are errors, never a relabelled number."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--stub", "--steps", "3", "--warmup", "1"],
+                       capture_output=True, text=True, env=env, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["comm"]["world_size"] == 2 and d["steps"] == 3 and d["allreduce_sum_check"] == 6.0
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--stub"], capture_output=True, text=True,
+                       env={**env, "WORLD_SIZE": "1"}, timeout=120)
+    assert r.returncode != 0 and "WORLD_SIZE=1" in r.stderr
+    import torch
+    if not torch.cuda.is_available():
+        r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2"], capture_output=True, text=True, env=env,
+                           timeout=120)
+        assert r.returncode != 0 and "refusing" in r.stderr

@@ -79,10 +79,18 @@ def test_gemm_contraction_major_operands(ops, gemm_variant, dtype, ta, tb, M, N,
         cmp(out, want, dtype, k=max(1.0, K / 256), what=f"gemm ta={ta} tb={tb} {M}x{N}x{K} splitk={sk}")
 
 
+@pytest.fixture(params=[1, 2, 4], ids=["mb1", "mb2", "mb4"])
+def skinny_mb(request, ops):
+    """the three row tilings of mh_gemm_skinny (16-row activation blocks per workgroup)"""
+    ops.set_option("skinny_mb", request.param)
+    yield request.param
+    ops.set_option("skinny_mb", 0)
+
+
 @pytest.mark.parametrize("mode", [0, 1])
 @pytest.mark.parametrize("M,N,K", [(64, 3072, 1024), (1, 1024, 1024), (5, 3406, 1024), (64, 1024, 4096), (33, 2048, 256),
-                                   (64, 4096, 1024)])
-def test_gemm_skinny(ops, mode, M, N, K):
+                                   (64, 4096, 1024), (16, 1024, 1024), (17, 1024, 1024), (48, 3072, 1024)])
+def test_gemm_skinny(ops, skinny_mb, mode, M, N, K):
     """decode-step projection (mh_gemm_skinny, bf16 only): plain + residual into a narrowed output view (logits layout),
     and the fused gate|up -> SwiGLU epilogue against gemm -> swiglu_fwd on the CPU"""
     dtype = torch.bfloat16
