@@ -88,8 +88,9 @@ def main():
                 d = nb[k].grad.float() - grads32[k]
                 g["ref_bf16_grad_relerr:" + k] = np.float64((d.norm() / grads32[k].norm()).item())
             flatb = torch.cat([p.grad.float().reshape(-1) for p in nb.values()])
-            g["ref_bf16_grad_cosine"] = np.float64(torch.nn.functional.cosine_similarity(flatb, flat32, dim=0).item())
-            g["ref_bf16_grad_norm_ratio"] = np.float64((flatb.norm() / flat32.norm()).item())
+            fb, f32_ = flatb.double(), flat32.double()  # (234 M elements: fp32 accumulation is not good enough for a cosine)
+            g["ref_bf16_grad_cosine"] = np.float64((torch.dot(fb, f32_) / (fb.norm() * f32_.norm())).item())
+            g["ref_bf16_grad_norm_ratio"] = np.float64((fb.norm() / f32_.norm()).item())
             lb, lgb, hb = lb.detach(), lgb.detach(), hb.detach()
         else:
             with torch.no_grad():

@@ -262,7 +262,7 @@ def test_checkpoint_round_trips_on_device(orc, tok, tmp_path, dtype):
     model.save_pretrained(str(tmp_path / "hf"))
     assert sorted(os.listdir(tmp_path / "hf")) == ["config.json", "model.safetensors"]
     state = {k: v.detach().cpu().contiguous() for k, v in model.state_dict().items()}
-    assert len(state) == 68 and state["net.layers.0.self_attn.q_proj.weight"].dtype == dtype
+    assert len(state) == 50 and state["net.layers.0.self_attn.q_proj.weight"].dtype == dtype
     torch.save({"state_dict": state, "epoch": 3, "global_step": 17}, str(tmp_path / "last.ckpt"))
     save_file(state, str(tmp_path / "model.safetensors"))
     torch.save({"state_dict": {"model." + k: v for k, v in state.items()}}, str(tmp_path / "prefixed.ckpt"))
