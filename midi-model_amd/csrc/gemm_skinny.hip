@@ -70,6 +70,24 @@ __global__ __launch_bounds__(NW * 64) void gemm_skinny_kernel(const bf16* __rest
     wrow[nb] = W + (int64_t)(n < nmax ? n : nmax) * ldw + fg * 8;
   }
 
+  // The residual lines are requested before anything else: read after the reduction they would put a second memory round
+  // trip (~0.5 us of the ~2.7 us a launch spends in the kernel, tools/skinny_probe.hip) on the critical path.
+  constexpr int CPT = (MODE == 1) ? 4 : NB / 4;  // output columns per writing thread (four threads per row)
+  const int ml = threadIdx.x >> 2;               // row within the workgroup (threads < MR * 4 write)
+  const int cw0 = (threadIdx.x & 3) * CPT;
+  float rpre[CPT];
+#pragma unroll
+  for (int j = 0; j < CPT; ++j) rpre[j] = 0.f;
+  if constexpr (MODE == 0) {
+    if (R != nullptr && threadIdx.x < MR * 4 && m0 + ml < M) {
+      const int m = m0 + ml;
+      const bf16* rrow = R + (res_ids != nullptr ? res_ids[m] : (int64_t)m) * ldr + blockIdx.x * NB + cw0;
+#pragma unroll
+      for (int j = 0; j < CPT; ++j)
+        if (blockIdx.x * NB + cw0 + j < N) rpre[j] = (float)rrow[j];
+    }
+  }
+
   f32x4 acc[MB][NBT];
 #pragma unroll
   for (int mb = 0; mb < MB; ++mb)
@@ -118,7 +136,6 @@ __global__ __launch_bounds__(NW * 64) void gemm_skinny_kernel(const bf16* __rest
   }
   __syncthreads();
   if (threadIdx.x >= MR * 4) return;  // four threads per row write the tile
-  const int ml = threadIdx.x >> 2;    // row within the workgroup
   const int m = m0 + ml;
   if (m >= M) return;
   float rs = 1.f;
@@ -146,16 +163,11 @@ __global__ __launch_bounds__(NW * 64) void gemm_skinny_kernel(const bf16* __rest
       }
     }
   } else {
-    constexpr int CPT = NB / 4;  // columns per thread
-    const int c0 = (threadIdx.x & 3) * CPT;
+    const int c0 = cw0;
 #pragma unroll
     for (int j = 0; j < CPT; ++j) {
       const int n = blockIdx.x * NB + c0 + j;
-      if (n < N) {
-        float v = total(c0 + j);
-        if (R != nullptr) v += (float)R[(res_ids != nullptr ? res_ids[m] : (int64_t)m) * ldr + n];
-        C[(int64_t)m * ldc + n] = (bf16)v;
-      }
+      if (n < N) C[(int64_t)m * ldc + n] = (bf16)(total(c0 + j) + rpre[j]);
     }
   }
 }

@@ -416,6 +416,14 @@ constexpr int SAMPLE_MAX_K = 64;
 // four waves (the exact fp32 division by the temperature makes it the expensive part).
 constexpr int SAMPLE_MAX_RANGE = 2048;
 
+// Latency notes (r02, tools/decode_probe.py: the first form took 19-38 us per call, 8 calls per generated event).  Every
+// global load whose address does not depend on the softmax statistics is requested at kernel entry -- the Exp(1) variates of
+// the top_k ranks (the first form read them one by one on lane 0 inside the final loop: top_k dependent L2 round trips), the
+// event id -> range-table -> candidate-logit chain -- and the vocabulary pass keeps its <= 14 values per thread in registers
+// (one batch of loads, independent exponentials) instead of an online max/sum recurrence.  Ranges of at most 128 ids (six of
+// the eight token positions) are ranked by counting (each lane compares its two candidates with all 128 through v_readlane)
+// instead of top_k rounds of a wave-wide arg-max; the cumulative top-p filter and the final argmax(p / q) run with one rank
+// per lane, the sums in the reference's sequential order.
 template <typename T, int TMAX>  // TMAX: candidates per lane (64 * TMAX >= the longest mask range of this position)
 __global__ __launch_bounds__(256) void sample_top_p_k_kernel(const T* __restrict__ logits, int64_t ldl,
                                                              const uint8_t* __restrict__ first_mask,
@@ -428,31 +436,63 @@ __global__ __launch_bounds__(256) void sample_top_p_k_kernel(const T* __restrict
                                                              int64_t* __restrict__ out_b, int64_t* __restrict__ out_c,
                                                              int64_t B, int V, float temp, float top_p, int top_k,
                                                              int fill_rest, int64_t fill_id) {
-  __shared__ float sel_v[1][SAMPLE_MAX_K];
-  __shared__ int sel_i[1][SAMPLE_MAX_K];
+  __shared__ float sel_v[SAMPLE_MAX_K];
+  __shared__ int sel_i[SAMPLE_MAX_K];
   __shared__ float part_m[4], part_s[4];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  constexpr int wv = 0;
   const int64_t b = blockIdx.x;
   const T* row = logits + b * ldl;
-  // softmax statistics over the whole vocabulary
+  // ---- wave 0: everything that does not need the softmax statistics, requested first
+  float qv = 1.f, zc[TMAX];
+  int l = first_lo, h = first_hi;
+  if (wave == 0) {
+    if (lane < top_k) qv = q[b * (int64_t)V + lane];
+    if (pos > 0) {
+      const int64_t e = ev[b];
+      l = lo_tab[e * tab_stride + pos];
+      h = hi_tab[e * tab_stride + pos];
+    }
+    if (h > V) h = V;
+#pragma unroll
+    for (int t = 0; t < TMAX; ++t) {
+      const int c = l + lane + 64 * t;
+      const bool ok = c < h && (pos > 0 || first_mask[c] != 0) && (ban_mask == nullptr || ban_mask[c] == 0);
+      zc[t] = ok ? rnd<T>(to_f(row[c]) / temp) : -INFINITY;  // -inf: not a candidate
+    }
+  }
+  // ---- softmax statistics over the whole vocabulary (logits / temp in the activation dtype, as the reference)
   float m = -INFINITY, ssum = 0.f;
-  for (int c = threadIdx.x; c < V; c += 256) {
-    const float z = rnd<T>(to_f(row[c]) / temp);  // logits / temp in the activation dtype, as the reference
-    if (z > m) {
-      ssum = ssum * __expf(m - z) + 1.f;
-      m = z;
-    } else {
-      ssum += __expf(z - m);
+  constexpr int NZ = 14;  // 14 x 256 = 3584 >= vocab 3406: one batch
+  for (int base = 0; base < V; base += NZ * 256) {
+    float zl[NZ];
+#pragma unroll
+    for (int i = 0; i < NZ; ++i) {
+      const int c = base + threadIdx.x + 256 * i;
+      zl[i] = c < V ? rnd<T>(to_f(row[c]) / temp) : -INFINITY;
+    }
+    float cm = zl[0];
+#pragma unroll
+    for (int i = 1; i < NZ; ++i) cm = fmaxf(cm, zl[i]);
+    if (cm > m) {
+      ssum *= __expf(m - cm);  // (m = -inf: 0)
+      m = cm;
+    }
+    if (m > -INFINITY) {
+#pragma unroll
+      for (int i = 0; i < NZ; ++i) ssum += __expf(zl[i] - m);
     }
   }
   {
     const float wm = wave_max(m);
-    const float ws = wave_sum(ssum * __expf(m - wm));
+    const float ws = wave_sum(m > -INFINITY ? ssum * __expf(m - wm) : 0.f);
     if (lane == 0) {
       part_m[wave] = wm;
       part_s[wave] = ws;
     }
+  }
+  if (wave == 0 && lane < SAMPLE_MAX_K) {  // fewer than top_k candidates: the tail has probability 0
+    sel_v[lane] = 0.f;
+    sel_i[lane] = 0x7fffffff;
   }
   __syncthreads();
   if (wave != 0) return;
@@ -461,63 +501,75 @@ __global__ __launch_bounds__(256) void sample_top_p_k_kernel(const T* __restrict
 #pragma unroll
   for (int w = 0; w < 4; ++w) tot += part_s[w] * __expf(part_m[w] - mx);
   const float inv = 1.f / tot;
-  int l = first_lo, h = first_hi;
-  if (pos > 0) {
-    const int64_t e = ev[b];
-    l = lo_tab[e * tab_stride + pos];
-    h = hi_tab[e * tab_stride + pos];
-  }
-  if (h > V) h = V;
   float pv[TMAX];
 #pragma unroll
-  for (int t = 0; t < TMAX; ++t) {
-    const int c = l + lane + 64 * t;
-    const bool ok = c < h && (pos > 0 || first_mask[c] != 0) && (ban_mask == nullptr || ban_mask[c] == 0);
-    pv[t] = ok ? __expf(rnd<T>(to_f(row[c < V ? c : V - 1]) / temp) - mx) * inv : -1.f;  // -1: not a candidate
-  }
-  uint32_t taken = 0;
-  for (int j = 0; j < top_k; ++j) {
-    float bv = -1.f;
-    int bt = TMAX;
+  for (int t = 0; t < TMAX; ++t) pv[t] = (zc[t] > -INFINITY) ? __expf(zc[t] - mx) * inv : -1.f;  // -1: not a candidate
+
+  // ---- the top_k largest candidates in the order of torch's stable descending sort (value descending, id ascending):
+  // rank j -> sel_v[j], sel_i[j]
+  if constexpr (TMAX <= 2) {
+    int rank[TMAX];
+#pragma unroll
+    for (int t = 0; t < TMAX; ++t) rank[t] = 0;
+    for (int sl = 0; sl < 64; ++sl) {
+#pragma unroll
+      for (int u = 0; u < TMAX; ++u) {
+        const float ov = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(pv[u]), sl));
+        const int ot = sl + 64 * u;  // position of the other candidate within the range (id = l + ot)
+#pragma unroll
+        for (int t = 0; t < TMAX; ++t) rank[t] += (ov > pv[t] || (ov == pv[t] && ot < lane + 64 * t)) ? 1 : 0;
+      }
+    }
 #pragma unroll
     for (int t = 0; t < TMAX; ++t)
-      if (!((taken >> t) & 1u) && pv[t] > bv) {  // ascending t = ascending id: the lowest id of equal values stays
-        bv = pv[t];
-        bt = t;
+      if (pv[t] >= 0.f && rank[t] < top_k) {
+        sel_v[rank[t]] = pv[t];
+        sel_i[rank[t]] = l + lane + 64 * t;
       }
-    // key = (probability bits, 0x7fffffff - id): larger probability first, lower id among equal probabilities; a lane
-    // without candidates left offers key 0 (below every candidate, whose low word is positive)
-    const uint64_t mykey = (bt < TMAX) ? ((uint64_t)__float_as_uint(bv) << 32) | (uint32_t)(0x7fffffff - (l + lane + 64 * bt)) : 0ull;
-    const uint64_t wkey = wave_max_u64_fast(mykey);
-    const float wvv = __uint_as_float((uint32_t)(wkey >> 32));
-    const int wi = (wkey != 0ull) ? 0x7fffffff - (int)(uint32_t)wkey : 0x7fffffff;
-    if (lane == 0) {
-      sel_v[wv][j] = wvv;  // fewer than top_k candidates: the tail has probability 0
-      sel_i[wv][j] = wi;
+  } else {
+    uint32_t taken = 0;
+    for (int j = 0; j < top_k; ++j) {
+      float bv = -1.f;
+      int bt = TMAX;
+#pragma unroll
+      for (int t = 0; t < TMAX; ++t)
+        if (!((taken >> t) & 1u) && pv[t] > bv) {  // ascending t = ascending id: the lowest id of equal values stays
+          bv = pv[t];
+          bt = t;
+        }
+      // key = (probability bits, 0x7fffffff - id): larger probability first, lower id among equal probabilities; a lane
+      // without candidates left offers key 0 (below every candidate, whose low word is positive)
+      const uint64_t mykey = (bt < TMAX) ? ((uint64_t)__float_as_uint(bv) << 32) | (uint32_t)(0x7fffffff - (l + lane + 64 * bt)) : 0ull;
+      const uint64_t wkey = wave_max_u64_fast(mykey);
+      const int wi = (wkey != 0ull) ? 0x7fffffff - (int)(uint32_t)wkey : 0x7fffffff;
+      if (lane == 0 && wkey != 0ull) {
+        sel_v[j] = __uint_as_float((uint32_t)(wkey >> 32));
+        sel_i[j] = wi;
+      }
+      if (wi != 0x7fffffff && ((wi - l) & 63) == lane) taken |= 1u << ((wi - l) >> 6);
     }
-    if (wi != 0x7fffffff && ((wi - l) & 63) == lane) taken |= 1u << ((wi - l) >> 6);
   }
+  __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0): the LDS writes of this wave are done (one wave, in-order LDS queue)
+  __builtin_amdgcn_wave_barrier();
+  // ---- probs_sort[cumsum - probs_sort > p] = 0; keep the first k; renormalise; argmax(p / q): rank j on lane j
+  const float v = lane < top_k ? sel_v[lane] : 0.f;
+  const int vid = lane < top_k ? sel_i[lane] : 0x7fffffff;
+  float cum = 0.f, mycum = 0.f;
+  for (int j = 0; j < top_k; ++j) {  // the reference's sequential cumsum, recomputed identically by every lane
+    cum += __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), j));
+    if (lane == j) mycum = cum;
+  }
+  const float kept = (lane < top_k && !(mycum - v > top_p)) ? v : 0.f;
+  float s = 0.f;
+  for (int j = 0; j < top_k; ++j) s += __int_as_float(__builtin_amdgcn_readlane(__float_as_int(kept), j));
+  float r = (kept / s) / qv;
+  if (!(r == r)) r = 0.f;  // (no candidate at all: 0 / 0)
+  // first maximum = lowest rank among equal ratios (`if (r > best)` of the serial form); ratios are >= 0, so their bits order them
+  const uint64_t key = lane < top_k ? ((uint64_t)__float_as_uint(r) << 32) | (uint32_t)(63 - lane) : 0ull;
+  const uint64_t wkey = wave_max_u64_fast(key);
+  const int bj = 63 - (int)(uint32_t)wkey;
+  const int64_t id = (int64_t)__builtin_amdgcn_readlane(vid, bj);
   if (lane == 0) {
-    // probs_sort[cumsum - probs_sort > p] = 0; keep the first k; renormalise; argmax(p / q)
-    float cum = 0.f, s = 0.f;
-    for (int j = 0; j < top_k; ++j) {
-      const float v = sel_v[wv][j];
-      cum += v;
-      const float kept = (cum - v > top_p) ? 0.f : v;
-      sel_v[wv][j] = kept;
-      s += kept;
-    }
-    float best = -1.f;
-    int bj = 0;
-    const float* qr = q + b * (int64_t)V;
-    for (int j = 0; j < top_k; ++j) {
-      const float r = (sel_v[wv][j] / s) / qr[j];
-      if (r > best) {
-        best = r;
-        bj = j;
-      }
-    }
-    const int64_t id = (int64_t)sel_i[wv][bj];
     out[b * out_stride] = id;
     for (int j = 1; j <= fill_rest; ++j) out[b * out_stride + j] = fill_id;  // position 0 opens a fresh event row
     if (out_b != nullptr) out_b[b] = id;

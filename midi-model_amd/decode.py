@@ -1,14 +1,23 @@
 """KV-cached decode driver for ``MIDIModel.generate`` (midi_model.py:167-250).
 
-The reference spends a generated event in ~1000 launches and B host syncs.  Here one event is
+The reference spends a generated event in ~1000 launches and B host syncs.  Here one event is THREE graph replays and
+ONE device->host copy:
 
-    1 graph replay   net step: embedding sum of the previous event's 8 tokens -> 12 decoder layers on one position
-                     per sequence -> final norm; K/V appended to preallocated caches at a position kept in DEVICE memory
-    <=8 graph replays  token step i: (embedding of the token just sampled) -> 3 decoder layers at position i ->
-                     lm_head -> grammar-masked softmax -> the reference's own sampling ops (torch.sort / cumsum /
-                     multinomial, midi_model.py:152-165) drawing from a session generator that carries the caller's
-                     generator state in and out, so a seeded torch.Generator is consumed exactly as the reference does
-    + ONE device->host copy per event (the sampled event ids, for the reference's break rule).
+    noise graph  (side stream, overlapping the previous event's net step): the Exp(1) variates torch.multinomial would draw
+                 inside sample_top_p_k for the 8 token positions, [8, B, vocab], from a session generator that carries the
+                 caller's generator state in and out
+    steps graph  all 8 token steps back to back: (embedding of the token just sampled ->) 3 decoder layers at position i ->
+                 lm_head -> fused grammar-masked softmax + top-p/top-k + draw (mh_sample_top_p_k) on that noise
+    [copy]       the event's 8 tokens to the host; the reference's break rule (midi_model.py:232-235) is evaluated on them
+                 AFTERWARDS: positions past an event's arity sample PAD whether or not the loop runs them, so running all 8
+                 changes nothing but the number of draws -- and the generator is wound back to exactly the draws the
+                 reference would have made (philox offset arithmetic), so a seeded torch.Generator still yields the
+                 reference loop's stream (tests/test_decode_gpu.py drives app.py's loop against generate())
+    net graph    embedding sum of the event's 8 tokens -> 12 decoder layers on one position per sequence -> final norm;
+                 K/V appended to preallocated caches at a position kept in DEVICE memory
+
+Samplers the fused kernel does not cover (top_k > 64) and the eager mode (MH_DECODE_GRAPHS=0, the CPU fake backend of the
+tests) keep the step-by-step form: one graph / call per token step with the reference's own sampling ops inside.
 
 The graphs are hipGraphs captured through torch.cuda.CUDAGraph from the same Python schedule the eager path runs
 (``engine.stack_decode``), so there is one implementation of the step.  A session owns every buffer the graphs touch and
@@ -65,7 +74,9 @@ class DecodeSession:
         self.pad_id = tok.pad_id
         self.neg1 = torch.full((B,), -1, dtype=torch.int32, device=dev)
         self.probs = torch.zeros((B, 1, self.V), dtype=torch.float32, device=dev)
-        self.q = torch.zeros((B, self.V), dtype=torch.float32, device=dev)  # Exp(1) noise of the sampler
+        # Exp(1) noise of the sampler, one [B, V] slice per token position (ones: a step sampled before any draw is greedy-safe)
+        self.q_all = torch.ones((self.T, B, self.V), dtype=torch.float32, device=dev)
+        self.q = self.q_all[0]
         self.logits = torch.zeros((B, self.Vp), dtype=dt, device=dev)
         # RMSNorm weights folded into the projections that follow them (one launch for norm + projection)
         self.fold1 = self.fold2 = self.lm_fold = None
@@ -78,9 +89,15 @@ class DecodeSession:
             self.refresh()
         self.g_net = None
         self.g_tok: List[Optional[torch.cuda.CUDAGraph]] = [None] * self.T
+        self.g_noise = self.g_steps = None
         self.use_graphs = graphs_enabled(dev)
         self.gen = torch.Generator(device=dev) if self.use_graphs else None  # the generator the captured sampler draws from
         self._user_gen = None
+        self._pool = None
+        self._off = 0          # philox offset of the next draw the reference loop would make
+        self._draw_inc = 0     # philox offset consumed by one [B, V] exponential_ call
+        self._noise_pending = False
+        self.noise_stream = self.noise_done = None
         if self.use_graphs:
             self._capture()
 
@@ -111,7 +128,12 @@ class DecodeSession:
         self.hidden.copy_(y)
         self.pos.add_(1)
 
-    def _tok_body(self, i: int, generator=None):
+    def _noise_body(self, generator=None):
+        """the draws of one event: what torch.multinomial(probs_sort [B, V]) would draw at each of the T token positions"""
+        for i in range(self.T):
+            self.q_all[i].exponential_(1.0, generator=generator)
+
+    def _tok_body(self, i: int, generator=None, draw: bool = True):
         m = self.model
         tspec, Wt = m._specs["net_token"], m._W["net_token"]
         self.kv2.len = i
@@ -134,9 +156,11 @@ class DecodeSession:
             self.seq.fill_(self.pad_id)
         if self.fused_sampler:
             # one launch instead of sample_top_p_k's ~25: the Exp(1) noise torch.multinomial would draw internally
-            # (empty_like(probs).exponential_(1, generator)) is drawn here, the rest is mh_sample_top_p_k
-            self.q.exponential_(1.0, generator=generator)
-            ops.sample_top_p_k(self.logits, self.first_mask, self.lo_tab, self.hi_tab, self.ev, i, self.q, self.seq[:, i],
+            # (empty_like(probs).exponential_(1, generator)) is drawn here (eager form) or by the noise graph ahead of the
+            # step (draw=False), the rest is mh_sample_top_p_k
+            if draw:
+                self.q_all[i].exponential_(1.0, generator=generator)
+            ops.sample_top_p_k(self.logits, self.first_mask, self.lo_tab, self.hi_tab, self.ev, i, self.q_all[i], self.seq[:, i],
                                self.V, self.temp, self.top_p, self.top_k, out_b=self.samples_in,
                                out_c=self.ev if i == 0 else None, first_span=self.first_span, max_range=self.max_range[i],
                                ban_mask=self.ban, fill_rest=self.T - 1 if i == 0 else 0, fill_id=self.pad_id)
@@ -169,17 +193,43 @@ class DecodeSession:
                 self._tok_body(i, self.gen)
         cur.wait_stream(side)
         torch.cuda.synchronize()
-        pool = torch.cuda.graph_pool_handle()
+        self._pool = pool = torch.cuda.graph_pool_handle()
         self.g_net = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self.g_net, pool=pool, capture_error_mode="thread_local"):
             self._net_body()
-        for i in range(self.T):
-            g = torch.cuda.CUDAGraph()
-            g.register_generator_state(self.gen)  # philox seed/offset are read at replay time, offsets advance per replay
-            with torch.cuda.graph(g, pool=pool, capture_error_mode="thread_local"):
-                self._tok_body(i, self.gen)
-            self.g_tok[i] = g
+        if self.fused_sampler:
+            # the event's draws in one graph (the only one that touches the generator) ...
+            self.g_noise = torch.cuda.CUDAGraph()
+            self.g_noise.register_generator_state(self.gen)  # philox seed/offset are read at replay time, offsets advance per replay
+            # (its own memory pool: it replays on the noise stream WHILE the net graph runs on the caller's stream)
+            with torch.cuda.graph(self.g_noise, capture_error_mode="thread_local"):
+                self._noise_body(self.gen)
+            # ... and all T token steps in another
+            self.g_steps = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self.g_steps, pool=pool, capture_error_mode="thread_local"):
+                for i in range(self.T):
+                    self._tok_body(i, draw=False)
+            o0 = self.gen.get_offset()
+            self.g_noise.replay()
+            torch.cuda.synchronize()
+            self._draw_inc = (self.gen.get_offset() - o0) // self.T
+            assert self._draw_inc > 0 and self._draw_inc * self.T == self.gen.get_offset() - o0
+            self.noise_stream = torch.cuda.Stream()
+            self.noise_done = torch.cuda.Event()
+        else:
+            for i in range(self.T):
+                self._capture_step(i)
         self.reset()
+
+    def _capture_step(self, i: int):
+        """a graph of token step i alone (the step-by-step form; with the fused sampler only tests / debugging use it: the
+        noise then comes from draw_noise())"""
+        g = torch.cuda.CUDAGraph()
+        if not self.fused_sampler:
+            g.register_generator_state(self.gen)
+        with torch.cuda.graph(g, pool=self._pool, capture_error_mode="thread_local"):
+            self._tok_body(i, self.gen, draw=not self.fused_sampler)
+        self.g_tok[i] = g
 
     # ---- driver interface ---------------------------------------------------------------------------------
     def reset(self):
@@ -202,12 +252,19 @@ class DecodeSession:
     def begin(self, generator) -> None:
         """take over the caller's random stream (None = the device's default generator)"""
         self._user_gen = generator
+        self._noise_pending = False
         if self.gen is not None:
             src = generator if generator is not None else torch.cuda.default_generators[self.model.device.index or 0]
             self.gen.set_state(src.get_state())
+            self._off = self.gen.get_offset()
 
     def end(self) -> None:
         """hand the advanced random stream back to the caller's generator"""
+        if self.g_noise is not None:
+            if self._noise_pending:  # draws made ahead for an event that was never sampled: not consumed
+                self.noise_stream.synchronize()
+                self._noise_pending = False
+            self.gen.set_offset(self._off)
         if self.gen is not None:
             dst = self._user_gen if self._user_gen is not None else torch.cuda.default_generators[self.model.device.index or 0]
             dst.set_state(self.gen.get_state())
@@ -222,8 +279,63 @@ class DecodeSession:
         self.kv1.len += 1
 
     def tok_step(self, i: int) -> None:
-        """sample token position i of the current event into seq[:, i] (and ev for i == 0)"""
-        if self.g_tok[i] is not None:
+        """sample token position i of the current event into seq[:, i] (and ev for i == 0) -- the step-by-step form"""
+        if self.use_graphs:
+            if self.g_tok[i] is None:
+                with _CAPTURE_LOCK:
+                    self._capture_step(i)
+            if self.g_noise is not None and self._noise_pending:
+                torch.cuda.current_stream().wait_event(self.noise_done)
             self.g_tok[i].replay()
         else:
             self._tok_body(i, self._user_gen)
+
+    # ---- one event per call: the form generate() drives ----------------------------------------------------
+    def draw_noise(self) -> None:
+        """(fused graphs) draw the next event's T x [B, V] variates on the noise stream, starting at the offset the reference
+        loop would be at; they overlap whatever the caller queues next on its own stream (the net step)"""
+        if self.g_noise is None:
+            return
+        cur = torch.cuda.current_stream()
+        self.noise_stream.wait_stream(cur)  # the token steps that read the previous draws are queued on `cur`
+        self.gen.set_offset(self._off)
+        with torch.cuda.stream(self.noise_stream):
+            self.g_noise.replay()
+            self.noise_done.record(self.noise_stream)
+        self._noise_pending = True
+
+    def consumed(self, n_steps: int) -> None:
+        """the reference loop ran n_steps sampling calls for the event just sampled: its generator stands n_steps draws on"""
+        if self.g_noise is not None:
+            self._off += n_steps * self._draw_inc
+            self._noise_pending = False
+
+    def n_steps_of(self, ids) -> tuple:
+        """(number of sampling calls the reference makes for an event whose first tokens are `ids`, all rows ended?) --
+        the break rule of midi_model.py:232-235: the inner loop stops after position i iff every live row's event has
+        exactly i parameters (vacuously true at i == 1 when no row is live)"""
+        tok = self.model.tokenizer
+        arity = self.model._grammar()[3]
+        alive = [arity[t] for t in ids if t != tok.eos_id]
+        if not alive:
+            return 2, True
+        return (alive[0] + 1 if all(a == alive[0] for a in alive) else self.T), False
+
+    def sample_event(self):
+        """sample the T tokens of the next event from `hidden`; -> (np.ndarray [B, T] int64, all rows ended?)"""
+        if self.g_steps is not None:
+            if not self._noise_pending:
+                self.draw_noise()
+            torch.cuda.current_stream().wait_event(self.noise_done)
+            self.g_steps.replay()
+            event = self.seq.cpu().numpy().copy()  # the one host sync per event
+            n, end_all = self.n_steps_of(event[:, 0].tolist())
+            self.consumed(n)
+            return event, end_all
+        n_steps, end_all, i = self.T, False, 0
+        while i < n_steps:
+            self.tok_step(i)  # ... lm_head -> masked softmax -> sample_top_p_k -> seq[:, i]
+            if i == 0:
+                n_steps, end_all = self.n_steps_of(self.ev.tolist())  # (a host sync)
+            i += 1
+        return self.seq.cpu().numpy().copy(), end_all  # (a CPU tensor would share memory with the session buffer)

@@ -459,7 +459,6 @@ class MIDIModel(nn.Module):
         if cur_len >= max_len:
             return
         with torch.inference_mode():
-            arity = self._grammar()[3]
             ses = self._checkout_session(B, max(max_len, cur_len) + 1, float(temp), float(top_p), int(top_k))
         try:
             with torch.inference_mode():
@@ -478,29 +477,12 @@ class MIDIModel(nn.Module):
                 ses.prefill(inp)  # causal forward over the prompt; hidden = last position
             while cur_len < max_len:
                 with torch.inference_mode():
-                    n_steps = T
-                    end_all = False
-                    i = 0
-                    while i < n_steps:
-                        ses.tok_step(i)  # ... lm_head -> masked softmax -> sample_top_p_k -> ses.seq[:, i]
-                        if i == 0:
-                            ids = ses.ev.tolist()  # the one host sync per event
-                            alive = [a for a in (arity[t] for t in ids if t != tok.eos_id)]
-                            end_all = len(alive) == 0
-                            # reference break rule: the inner loop stops after position i iff every live row's event
-                            # has exactly i parameters (vacuously true at i == 1 when no row is live)
-                            if end_all:
-                                n_steps = 2
-                            elif all(a == alive[0] for a in alive):
-                                n_steps = alive[0] + 1
-                            else:
-                                n_steps = T
-                        i += 1
-                    event = ses.seq.cpu().numpy().copy()  # (a CPU tensor would share memory with the session buffer)
+                    event, end_all = ses.sample_event()  # the event's 8 token steps (one replayed graph, one host copy)
                     cur_len += 1
                     last = end_all or cur_len >= max_len
                     if not last:
-                        ses.net_step()  # decode the event just sampled; hidden = its net output (overlaps the consumer)
+                        ses.draw_noise()  # the next event's draws, on a side stream under the net step
+                        ses.net_step()    # decode the event just sampled; hidden = its net output (overlaps the consumer)
                 yield event
                 if last:
                     break

@@ -57,7 +57,7 @@ def test_production_decode_session_matches_oracle(orc, tok, medium_bf16, golden)
     torch.set_num_threads(min(os.cpu_count() or 8, 32))
     with torch.inference_mode():
         ses = DecodeSession(model, B, 256, 1.0, 0.98, 1)
-        assert ses.g_net is not None and all(x is not None for x in ses.g_tok), "captured graphs are the production form"
+        assert ses.g_net is not None and ses.g_steps is not None and ses.g_noise is not None, "captured graphs are the production form"
         assert ses.fold1 is not None and ses.lm_fold is not None and ses.fused_sampler, "folded norms + fused sampler"
         ses.first_mask.copy_(model._grammar()[0])
         ses.ban.zero_()
@@ -131,9 +131,10 @@ def test_fused_sampler_inside_graphs_equals_oracle_chain_on_same_noise(orc, tok,
         for ev_i in range(6):
             names, end = [""] * B, [False] * B
             n_steps, i = tok.max_token_seq, 0
+            ses.draw_noise()  # the event's Exp(1) variates (the noise graph, on its side stream)
             while i < n_steps:
                 ses.tok_step(i)
-                lg, q, ids = ses.logits[:, :V].float().cpu(), ses.q.cpu(), ses.seq[:, i].cpu()
+                lg, q, ids = ses.logits[:, :V].float().cpu(), ses.q_all[i].cpu(), ses.seq[:, i].cpu()
                 mask = orc.grammar_mask(tok, i, names, end)
                 scores = torch.softmax(lg / 1.0, dim=-1) * mask
                 want = orc.sample_top_p_k(scores[:, None], 0.98, 20, noise=q[:, None])[:, 0]
@@ -145,10 +146,52 @@ def test_fused_sampler_inside_graphs_equals_oracle_chain_on_same_noise(orc, tok,
                     names = [tok.id_events.get(int(t), "") for t in ids]
                     end = [int(t) == tok.eos_id for t in ids]
                     n_steps = _n_steps(tok, ids.tolist())
+                    assert ses.n_steps_of(ids.tolist())[0] == n_steps
                 i += 1
+            ses.consumed(n_steps)
             ses.net_step()
         ses.end()
     assert n > 100
+
+
+def test_steps_graph_equals_step_by_step_and_rng_stream_is_the_reference_loops(orc, tok, medium_bf16):
+    """generate()'s form -- ONE graph for the 8 token steps on noise drawn ahead by the noise graph, generator wound back to
+    the draws the reference loop makes -- against the step-by-step form on the same noise (same kernels: identical tokens),
+    and the generator state it hands back against the count of sampling calls the reference's break rule gives."""
+    from midi_model_amd.decode import DecodeSession
+    shp, sd, model = medium_bf16
+    B = 6
+    prompt = orc.synthetic_events(tok, B, 5, seed=35).cuda()
+    gen = torch.Generator(device="cuda")
+    with torch.inference_mode():
+        ses = DecodeSession(model, B, 256, 1.0, 0.98, 20)
+        ses.first_mask.copy_(model._grammar()[0])
+        ses.ban.zero_()
+        events, calls = [], 0
+        ses.reset()
+        ses.begin(gen.manual_seed(11))
+        off0 = gen.get_offset()
+        ses.prefill(prompt)
+        for _ in range(5):
+            ev, end_all = ses.sample_event()
+            calls += ses.n_steps_of(ev[:, 0].tolist())[0]
+            events.append(ev)
+            ses.draw_noise()
+            ses.net_step()
+        ses.end()
+        assert gen.get_offset() == off0 + calls * ses._draw_inc, "the generator stands exactly `calls` draws on"
+        # the same five events, token step by token step, on the same seed
+        ses.reset()
+        ses.begin(gen.manual_seed(11))
+        ses.prefill(prompt)
+        for k in range(5):
+            ses.draw_noise()
+            for i in range(tok.max_token_seq):
+                ses.tok_step(i)
+            assert (ses.seq.cpu().numpy() == events[k]).all(), k
+            ses.consumed(ses.n_steps_of(events[k][:, 0].tolist())[0])
+            ses.net_step()
+        ses.end()
 
 
 def test_generate_with_mask_options_equals_oracle(orc, tok):
