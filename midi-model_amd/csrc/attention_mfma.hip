@@ -239,6 +239,218 @@ __global__ __launch_bounds__(256, 3) void attn_fwd_kernel(const bf16* __restrict
 }
 
 // ---------------------------------------------------------------------------------------------------
+// forward, second structure (r02): no transposed V copy, three-stage K/V ring
+// ---------------------------------------------------------------------------------------------------
+// * V is staged row-major [key][d] exactly like K (straight out of the fused qkv rows) and the V^T operand fragments of
+//   O^T += V^T P^T are assembled by ds_read_b64_tr_b16: within a 16-lane group lane p supplies 4 contiguous d of key row
+//   p>>2 and output lane i receives element i&3 of supplier 4j + (i>>2) for j = 0..3 (semantics pinned by tools/probe.hip,
+//   profiles/r01_probe_gfx950_semantics.txt), i.e. 4 consecutive keys of ONE d.  Supplier p of lane group g therefore
+//   points at V[key0 + (p>>2)][db*32 + 16*(g&1) + 8*(p&1) + 4*((p>>1)&1)], which hands output lane i the d index
+//   db*32 + pi32(16*(g&1) + i) the accumulator layout wants; two reads (keys +0..3, +4..7) make one 8-key fragment.
+//   The mh_attn_prep_fwd pass and its [B,H,64,Sp] buffer (55 us per layer at B=16, S=4096) are gone.
+// * K/V tiles live in a ring of three 16 KiB stages filled two tiles ahead by global_load_lds; a wave waits with a COUNTED
+//   s_waitcnt vmcnt (the stage one tile ahead stays in flight) and the workgroup meets at one raw s_barrier per tile
+//   (__syncthreads would drain the queue: cdna_hip_programming.md 5, "Pipelining across barriers").
+// * every LDS address of the tile loop is a per-lane constant + the stage base + an immediate.
+__device__ inline void wait_vmcnt4() { asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); }
+__device__ inline void wait_vmcnt0() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+
+// The transpose reads are issued from inline asm: through the builtin hipcc puts an s_waitcnt vmcnt(0) in front of every
+// ds_read_b64_tr_b16 while an LDS-DMA is outstanding (it cannot tell the stages apart), which would drain the stage requested
+// at the top of the tile.  The asm reads are invisible to its counters, so they are waited for by hand (lgkmcnt(0) +
+// sched_barrier before the first consumer; cdna_hip_programming.md 5.7 form iii).
+typedef __attribute__((ext_vector_type(2))) unsigned int u32x2;
+template <int OFF>
+__device__ inline u32x2 ds_tr16(unsigned lds_addr) {
+  u32x2 r;
+  asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(r) : "v"(lds_addr), "i"(OFF));
+  return r;
+}
+__device__ inline unsigned lds_addr32(const char* p) {
+  return (unsigned)(uintptr_t)(__attribute__((address_space(3))) const char*)p;
+}
+__device__ inline bf16x8 join8(const u32x2& a, const u32x2& b) {
+  union {
+    bf16x8 v;
+    u32x2 h[2];
+  } u;
+  u.h[0] = a;
+  u.h[1] = b;
+  return u.v;
+}
+
+// one 64-key tile for one wave (32 query rows); koff[s] / voff[db][half]: this lane's byte offsets inside a K / V tile
+template <bool MASK>
+__device__ inline void fwd2_tile(const char* tK, const char* tV, const int (&koff)[4], const int (&voff)[2][2],
+                                 const bf16x8 (&qf)[4], f32x16 (&oacc)[2], float& m, float& l, int hi, int qrel, float sc) {
+  f32x16 sacc[2] = {zero16(), zero16()};
+#pragma unroll
+  for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+    for (int s = 0; s < 4; ++s)
+      sacc[kb] = mfma32(*reinterpret_cast<const bf16x8*>(tK + koff[s] + kb * 4096), qf[s], sacc[kb]);
+  float mx = -INFINITY;
+#pragma unroll
+  for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      if (MASK) {
+        if (kb * 32 + reg_index(r, hi) > qrel) sacc[kb][r] = -INFINITY;
+      }
+      mx = fmaxf(mx, sacc[kb][r]);
+    }
+  mx = fmaxf(mx, __shfl_xor(mx, 32, 64)) * sc;  // running max kept in scaled (log2) units
+  float mn = m, alpha = 1.f;
+  if (__any(mx > m + RESCALE_THR)) {  // (see fwd_tile)
+    mn = fmaxf(m, mx);
+    alpha = fast_exp2(m - mn);
+#pragma unroll
+    for (int db = 0; db < 2; ++db)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) oacc[db][r] *= alpha;
+  }
+  float psum = 0.f;
+#pragma unroll
+  for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const float p = fast_exp2(__builtin_fmaf(sacc[kb][r], sc, -mn));
+      sacc[kb][r] = p;
+      psum += p;
+    }
+  l = l * alpha + psum;
+  m = mn;
+  // O^T += V^T P^T: the 16 transpose reads of the tile in two batches of 8 (keys 0..31, 32..63)
+  unsigned va[2][2];
+#pragma unroll
+  for (int db = 0; db < 2; ++db)
+#pragma unroll
+    for (int half = 0; half < 2; ++half) va[db][half] = lds_addr32(tV) + (unsigned)voff[db][half];
+#define MH_PV_BATCH(T0)                                                                                              \
+  {                                                                                                                 \
+    u32x2 r[2][2][2];                                                                                               \
+    r[0][0][0] = ds_tr16<(T0) * 2048>(va[0][0]);                                                                    \
+    r[0][0][1] = ds_tr16<(T0) * 2048>(va[0][1]);                                                                    \
+    r[0][1][0] = ds_tr16<(T0) * 2048>(va[1][0]);                                                                    \
+    r[0][1][1] = ds_tr16<(T0) * 2048>(va[1][1]);                                                                    \
+    r[1][0][0] = ds_tr16<(T0 + 1) * 2048>(va[0][0]);                                                                \
+    r[1][0][1] = ds_tr16<(T0 + 1) * 2048>(va[0][1]);                                                                \
+    r[1][1][0] = ds_tr16<(T0 + 1) * 2048>(va[1][0]);                                                                \
+    r[1][1][1] = ds_tr16<(T0 + 1) * 2048>(va[1][1]);                                                                \
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                              \
+    __builtin_amdgcn_sched_barrier(0);                                                                              \
+    _Pragma("unroll") for (int tt = 0; tt < 2; ++tt) {                                                              \
+      const bf16x8 pf = pack8(sacc[((T0) + tt) >> 1], 8 * (((T0) + tt) & 1));                                       \
+      _Pragma("unroll") for (int db = 0; db < 2; ++db)                                                              \
+        oacc[db] = mfma32(join8(r[tt][db][0], r[tt][db][1]), pf, oacc[db]);                                         \
+    }                                                                                                               \
+  }
+  MH_PV_BATCH(0)
+  MH_PV_BATCH(2)
+#undef MH_PV_BATCH
+}
+
+__global__ __launch_bounds__(256, 3) void attn_fwd2_kernel(const bf16* __restrict__ qkv, bf16* __restrict__ o,
+                                                        float* __restrict__ lse, int S, int Sp, int H,
+                                                        float sc /* scale*log2(e) */, int BH, int nqt) {
+  // dynamic LDS (3 stages x [K | V] x 8 KiB = 48 KiB): with a static __shared__ array hipcc's LDS-DMA alias tracking puts
+  // an s_waitcnt vmcnt(0) in front of the first fragment read of every tile, which drains the stage just requested
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  int bh_, tile_;
+  if (!attn_work(BH, nqt, bh_, tile_)) return;
+  const int64_t bh = bh_;
+  const int64_t b = bh / H;
+  const int h = (int)(bh - b * H);
+  const int64_t D = (int64_t)H * HD, D3 = 3 * D;
+  const int q0 = (nqt - 1 - tile_) * 128;  // heavy (late) query tiles first
+  const int qw0 = q0 + wave * 32;
+  const int li = lane & 31, hi = lane >> 5;
+  const int qrow = qw0 + li;
+  const int qld = (qrow < S) ? qrow : S - 1;
+
+  const bf16* kbase = qkv + b * S * D3 + D + (int64_t)h * HD;
+  const bf16* vbase = kbase + D;
+
+  bf16x8 qf[4];
+  {
+    const bf16* qp = qkv + (b * S + qld) * D3 + (int64_t)h * HD + 8 * hi;
+#pragma unroll
+    for (int s = 0; s < 4; ++s) qf[s] = *reinterpret_cast<const bf16x8*>(qp + 16 * s);
+  }
+  f32x16 oacc[2] = {zero16(), zero16()};
+  float m = -INFINITY, l = 0.f;
+
+  int last_q = q0 + 127;
+  if (last_q > S - 1) last_q = S - 1;
+  const int kt_last = last_q / 64;
+  const int pli = pi32(li);
+  int koff[4], voff[2][2];
+#pragma unroll
+  for (int s = 0; s < 4; ++s) koff[s] = lds_tile_off(pli, 2 * s + hi);
+  {
+    const int p = lane & 15, gb = (lane >> 4) & 1;
+#pragma unroll
+    for (int db = 0; db < 2; ++db)
+#pragma unroll
+      for (int half = 0; half < 2; ++half) {
+        const int row = 8 * hi + 4 * half + (p >> 2);                             // (+ 16 t: immediate t * 2048)
+        const int col = db * 32 + 16 * gb + 8 * (p & 1) + 4 * ((p >> 1) & 1);
+        voff[db][half] = lds_tile_off(row, col >> 3) + (col & 7) * 2;
+      }
+  }
+
+  // prologue: stages 0 and 1 in flight
+  stage64(kbase, D3, 0, S - 1, 0, smem, wave, lane);
+  stage64(vbase, D3, 0, S - 1, 0, smem + TILE64, wave, lane);
+  if (kt_last >= 1) {
+    stage64(kbase, D3, 64, S - 1, 0, smem + 2 * TILE64, wave, lane);
+    stage64(vbase, D3, 64, S - 1, 0, smem + 3 * TILE64, wave, lane);
+  }
+  // The Q fragments are ordinary register loads: left pending, their first use inside the loop would make hipcc wait
+  // vmcnt(0) THERE on every tile (it cannot count across the LDS-DMA of the loop).  Passing them through an empty asm here
+  // puts that wait in front of the loop once.
+#pragma unroll
+  for (int s = 0; s < 4; ++s) asm volatile("" : "+v"(qf[s]));
+  int cur = 0;  // ring slot of tile kt
+  for (int kt = 0; kt <= kt_last; ++kt) {
+    if (kt + 1 <= kt_last) wait_vmcnt4(); else wait_vmcnt0();   // tile kt has landed (tile kt+1 may still be in flight)
+    __builtin_amdgcn_s_barrier();                               // ... for every wave, and everyone is done with tile kt-1
+    if (kt + 2 <= kt_last) {                                    // refill the slot of tile kt-1
+      int nx = cur + 2;
+      if (nx >= 3) nx -= 3;
+      stage64(kbase, D3, (int64_t)(kt + 2) * 64, S - 1, 0, smem + nx * 2 * TILE64, wave, lane);
+      stage64(vbase, D3, (int64_t)(kt + 2) * 64, S - 1, 0, smem + nx * 2 * TILE64 + TILE64, wave, lane);
+    }
+    const char* tK = smem + cur * 2 * TILE64;
+    const int k0 = kt * 64;
+    if (k0 <= qw0 + 31) {  // wave-uniform: this wave still has unmasked keys in the tile
+      if (k0 + 63 > qw0)   // wave-uniform: the tile crosses this wave's diagonal
+        fwd2_tile<true>(tK, tK + TILE64, koff, voff, qf, oacc, m, l, hi, qrow - k0, sc);
+      else
+        fwd2_tile<false>(tK, tK + TILE64, koff, voff, qf, oacc, m, l, hi, 0, sc);
+    }
+    cur = (cur == 2) ? 0 : cur + 1;
+  }
+  const float lt = l + __shfl_xor(l, 32, 64);
+  if (qrow < S) {
+    const float inv = 1.f / lt;
+    bf16* orow = o + (b * S + qrow) * D + (int64_t)h * HD;
+#pragma unroll
+    for (int db = 0; db < 2; ++db)
+#pragma unroll
+      for (int r8 = 0; r8 < 2; ++r8) {
+        bf16x8 v;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = (bf16)(oacc[db][8 * r8 + e] * inv);
+        *reinterpret_cast<bf16x8*>(orow + db * 32 + 16 * r8 + 8 * hi) = v;
+      }
+    if (hi == 0) lse[bh * Sp + qrow] = (m + log2f(lt)) * 0.6931471805599453f;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------
 // backward, dQ: block = 128 query rows, loop over key tiles
 // ---------------------------------------------------------------------------------------------------
 template <bool MASK>
@@ -475,11 +687,15 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const bf16* __rest
 // ---------------------------------------------------------------------------------------------------
 int mh_attn_fwd_mfma(const void* qkv, const void* vt, void* o, float* lse, int64_t B, int64_t S, int H, float scale,
                      hipStream_t st) {
-  MH_REQUIRE(vt != nullptr, "attn_fwd(bf16): needs the transposed V copy (mh_attn_prep_fwd)");
   MH_REQUIRE(S < (1 << 24), "attn_fwd: sequence too long");
   const int64_t Sp = (S + 63) / 64 * 64;
   const int nt = (int)((S + 127) / 128), BH = (int)(B * H);
   const unsigned grid = (unsigned)(nt * 8 * ((BH + 7) / 8));
+  if (vt == nullptr) {  // second structure: V read row-major through transpose reads, no prepared copy
+    attn_fwd2_kernel<<<grid, 256, 3 * 2 * TILE64, st>>>((const bf16*)qkv, (bf16*)o, lse, (int)S, (int)Sp, H, scale * LOG2E, BH, nt);
+    MH_LAUNCH_CHECK();
+    return MH_OK;
+  }
   attn_fwd_kernel<<<grid, 256, 0, st>>>((const bf16*)qkv, (const bf16*)vt, (bf16*)o, lse, (int)S, (int)Sp, H,
                                         scale * LOG2E, BH, nt);
   MH_LAUNCH_CHECK();

@@ -310,9 +310,12 @@ def rope_(qkv: torch.Tensor, cos_t: torch.Tensor, sin_t: torch.Tensor, S: int, p
 
 
 # ----------------------------------------------------------------------------------------- attention
+ATTN_FWD_FORM = int(os.environ.get("MH_ATTN_FWD", "2"))  # 2: transpose-read V + 3-stage ring; 1: first structure (prepared V^T copy)
+
+
 def attn_fwd(qkv, o, lse, B: int, S: int, H: int, scale: float):
     vt = None
-    if qkv.dtype == torch.bfloat16:
+    if qkv.dtype == torch.bfloat16 and ATTN_FWD_FORM == 1:
         Sp = round_up(S, 64)
         vt = torch.empty((B * H * 64 * Sp,), dtype=qkv.dtype, device=qkv.device)
         lib().call("mh_attn_prep_fwd", _p(qkv), _p(vt), B, S, H, dt(qkv), _stream())

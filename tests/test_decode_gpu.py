@@ -121,7 +121,7 @@ def test_fused_sampler_inside_graphs_equals_oracle_chain_on_same_noise(orc, tok,
     prompt = orc.synthetic_events(tok, B, 9, seed=33)
     with torch.inference_mode():
         ses = DecodeSession(model, B, 256, 1.0, 0.98, 20)
-        assert ses.fused_sampler and ses.g_tok[0] is not None
+        assert ses.fused_sampler and ses.g_steps is not None and ses.g_noise is not None
         ses.first_mask.copy_(model._grammar()[0])
         ses.ban.zero_()
         ses.reset()

@@ -281,9 +281,15 @@ def test_rope(ops, dtype, H, hd, S, M):
 
 
 # ------------------------------------------------------------------------------ event-level attention
+@pytest.mark.parametrize("form", [2, 1], ids=["fwd2_trV_ring3", "fwd1_preparedVT"])
 @pytest.mark.parametrize("dtype", DTYPES)
-@pytest.mark.parametrize("B,S,H", [(1, 1, 1), (2, 33, 3), (1, 64, 2), (2, 128, 1), (1, 200, 4), (1, 515, 2)])
-def test_attention_fwd_bwd(ops, dtype, B, S, H):
+@pytest.mark.parametrize("B,S,H", [(1, 1, 1), (2, 33, 3), (1, 64, 2), (2, 128, 1), (1, 200, 4), (1, 515, 2), (1, 129, 1), (2, 321, 2)])
+def test_attention_fwd_bwd(ops, monkeypatch, form, dtype, B, S, H):
+    """(bf16: both forward structures -- the transpose-read / three-stage-ring kernel and the first one with its prepared
+    V^T copy; fp32 runs the plain verification kernel either way)"""
+    if dtype == torch.float32 and form == 1:
+        pytest.skip("fp32 has one forward kernel")
+    monkeypatch.setattr(ops, "ATTN_FWD_FORM", form)
     D = H * 64
     scale = 64 ** -0.5
     qkv = rnd((B * S, 3 * D), dtype, 18)
