@@ -474,24 +474,35 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(const T* __restrict__ 
   for (int e = 0; e < N; ++e) acc[e] = 0.f;
   const T* kb = kc + bh * Lmax * HD;
   const T* vb = vc + bh * Lmax * HD;
-  for (int64_t j0 = (int64_t)wv * KPW; j0 < len; j0 += 4 * KPW) {
-    const int64_t j = j0 + grp;
-    const bool ok = j < len;
-    const int64_t jj = ok ? j : 0;
-    Pack<T> kv = ld16(kb + jj * HD + ch * N);
-    Pack<T> vv = ld16(vb + jj * HD + ch * N);
-    float s = 0.f;
+  // four steps of the key loop at a time with all K / V rows requested first: one step per memory round trip was one
+  // round trip per 32 keys of head_dim 64 (13 us per layer at 128 cached events, r02 trace)
+  constexpr int UNR = 4;
+  for (int64_t j0 = (int64_t)wv * KPW; j0 < len; j0 += 4 * KPW * UNR) {
+    Pack<T> kv[UNR], vv[UNR];
+    bool ok[UNR];
 #pragma unroll
-    for (int e = 0; e < N; ++e) s += q[e] * kv.get(e);
+    for (int u = 0; u < UNR; ++u) {
+      const int64_t j = j0 + (int64_t)u * 4 * KPW + grp;
+      ok[u] = j < len;
+      const int64_t jj = ok[u] ? j : 0;
+      kv[u] = ld16(kb + jj * HD + ch * N);
+      vv[u] = ld16(vb + jj * HD + ch * N);
+    }
 #pragma unroll
-    for (int x = 1; x < LPK; x <<= 1) s += __shfl_xor(s, x, 64);
-    if (ok) {
-      const float nm = fmaxf(m, s);
-      const float a = __expf(m - nm), p = __expf(s - nm);
-      l = l * a + p;
+    for (int u = 0; u < UNR; ++u) {
+      float s = 0.f;
 #pragma unroll
-      for (int e = 0; e < N; ++e) acc[e] = acc[e] * a + p * vv.get(e);
-      m = nm;
+      for (int e = 0; e < N; ++e) s += q[e] * kv[u].get(e);
+#pragma unroll
+      for (int x = 1; x < LPK; x <<= 1) s += __shfl_xor(s, x, 64);
+      if (ok[u]) {
+        const float nm = fmaxf(m, s);
+        const float a = __expf(m - nm), p = __expf(s - nm);
+        l = l * a + p;
+#pragma unroll
+        for (int e = 0; e < N; ++e) acc[e] = acc[e] * a + p * vv[u].get(e);
+        m = nm;
+      }
     }
   }
   // merge the KPW lane groups of the wave (lanes with equal `ch`)

@@ -28,16 +28,39 @@ __global__ __launch_bounds__(256) void embed_sum_fwd_kernel(const int64_t* __res
   const int lane = threadIdx.x & 63;
   const int64_t wave0 = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
   for (int64_t m = wave0; m < M; m += (int64_t)gridDim.x * 4) {
+    // the octet's ids first (one batch of loads), then all table rows: id -> row inside one loop is a chain of 2 TT dependent
+    // memory round trips (14 us per decode step for TT = 8, r02 trace)
+    constexpr int TMAXI = 8;
+    int64_t ids[TMAXI];
+    if (TT <= TMAXI) {
+#pragma unroll
+      for (int j = 0; j < TMAXI; ++j) ids[j] = tok[m * TT + (j < TT ? j : 0)];
+#pragma unroll
+      for (int j = 0; j < TMAXI; ++j)
+        if ((uint64_t)ids[j] >= (uint64_t)V) __builtin_trap();  // torch's embedding raises a device assert here; never read out of bounds
+    }
     for (int c = lane * N; c < D; c += 64 * N) {
       float acc[N];
 #pragma unroll
       for (int e = 0; e < N; ++e) acc[e] = 0.f;
-      for (int j = 0; j < TT; ++j) {
-        const int64_t id = tok[m * TT + j];
-        if ((uint64_t)id >= (uint64_t)V) __builtin_trap();  // torch's embedding raises a device assert here; never read out of bounds
-        Pack<T> v = ld16(table + id * D + c);
+      if (TT <= TMAXI) {
+        Pack<T> v[TMAXI];
 #pragma unroll
-        for (int e = 0; e < N; ++e) acc[e] += v.get(e);
+        for (int j = 0; j < TMAXI; ++j) v[j] = ld16(table + ids[j] * D + c);
+#pragma unroll
+        for (int j = 0; j < TMAXI; ++j)
+          if (j < TT) {
+#pragma unroll
+            for (int e = 0; e < N; ++e) acc[e] += v[j].get(e);
+          }
+      } else {
+        for (int j = 0; j < TT; ++j) {
+          const int64_t id = tok[m * TT + j];
+          if ((uint64_t)id >= (uint64_t)V) __builtin_trap();
+          Pack<T> v = ld16(table + id * D + c);
+#pragma unroll
+          for (int e = 0; e < N; ++e) acc[e] += v.get(e);
+        }
       }
       Pack<T> o;
 #pragma unroll

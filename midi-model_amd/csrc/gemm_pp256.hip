@@ -77,15 +77,21 @@ __device__ inline bf16x8 frag(const char* tile, int row0, int fi, int fg) {
     const int row = row0 + fi;
     return *reinterpret_cast<const bf16x8*>(tile + row * 64 + ((fg ^ xswz(row)) << 4));
   } else {
+    // Issued from inline asm (r02): through __builtin_amdgcn_ds_read_tr16_b64 hipcc's LDS-DMA alias tracking put an
+    // s_waitcnt vmcnt(0) in front of the first transpose read of every K-step -- it cannot tell the ring's stages apart --
+    // which drained the two steps meant to stay in flight (dgrad and both weight-gradient forms).  The asm reads are
+    // invisible to its counters: load_segment's own s_waitcnt lgkmcnt(0) + sched_barrier covers them.
+    typedef __attribute__((ext_vector_type(2))) unsigned int u32x2_t;
     union {
       bf16x8 v;
-      s16x4_t h[2];
+      u32x2_t h[2];
     } u;
 #pragma unroll
     for (int t = 0; t < 2; ++t) {
       const int krow = fg * 8 + t * 4 + (fi >> 2);
       const int off = krow * 512 + (((row0 >> 4) ^ tswz(krow)) << 5) + ((fi & 3) << 3);
-      u.h[t] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t*)(tile + off));
+      const unsigned addr = (unsigned)(uintptr_t)(__attribute__((address_space(3))) const char*)(tile + off);
+      asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(u.h[t]) : "v"(addr));
     }
     return u.v;
   }
@@ -203,6 +209,7 @@ __global__ __launch_bounds__(512, 2) void gemm_pp256_kernel(const bf16* __restri
       for (int j = 0; j < 4; ++j) issue_one(t + 3, j);
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);  // (no MFMA may be scheduled above the wait: the asm reads above are opaque to hipcc)
   };
   // Barrier 2t+1 keeps the two groups strictly out of phase (group 0 reads while group 1 multiplies and vice versa); LDS
   // safety only needs barrier 2t (every wave has seen its own pieces of step t land, and has finished reading step t-1

@@ -81,10 +81,19 @@ __global__ __launch_bounds__(NW * 64) void gemm_skinny_kernel(const bf16* __rest
   if constexpr (MODE == 0) {
     if (R != nullptr && threadIdx.x < MR * 4 && m0 + ml < M) {
       const int m = m0 + ml;
-      const bf16* rrow = R + (res_ids != nullptr ? res_ids[m] : (int64_t)m) * ldr + blockIdx.x * NB + cw0;
+      const int64_t rr = res_ids != nullptr ? res_ids[m] : (int64_t)m;
+      const bf16* rrow = R + rr * ldr + blockIdx.x * NB + cw0;
+      if (blockIdx.x * NB + cw0 + CPT <= N) {  // the whole group is inside the row (always, but for a ragged last block)
+        bf16 rv[CPT];
 #pragma unroll
-      for (int j = 0; j < CPT; ++j)
-        if (blockIdx.x * NB + cw0 + j < N) rpre[j] = (float)rrow[j];
+        for (int j = 0; j < CPT; ++j) rv[j] = rrow[j];  // unconditional: one batch of loads, no per-element branch + wait
+#pragma unroll
+        for (int j = 0; j < CPT; ++j) rpre[j] = (float)rv[j];
+      } else {
+#pragma unroll
+        for (int j = 0; j < CPT; ++j)
+          if (blockIdx.x * NB + cw0 + j < N) rpre[j] = (float)rrow[j];
+      }
     }
   }
 

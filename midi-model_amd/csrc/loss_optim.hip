@@ -453,22 +453,41 @@ __global__ __launch_bounds__(256) void sample_top_p_k_kernel(const T* __restrict
       h = hi_tab[e * tab_stride + pos];
     }
     if (h > V) h = V;
+    // every load unconditional on a clamped index, all requested before the first use: a per-element "load or constant"
+    // select makes hipcc branch around each load and wait for it -- one memory round trip per element (r02: the first form
+    // of this kernel took 19-38 us that way; cdna_hip_programming.md 5 trap (c))
+    T zraw[TMAX];
+    uint8_t fm[TMAX], bm[TMAX];
+#pragma unroll
+    for (int t = 0; t < TMAX; ++t) {
+      int c = l + lane + 64 * t;
+      c = c < V ? c : V - 1;
+      zraw[t] = row[c];
+      fm[t] = first_mask[c];
+      bm[t] = ban_mask != nullptr ? ban_mask[c] : (uint8_t)0;  // (uniform condition)
+    }
 #pragma unroll
     for (int t = 0; t < TMAX; ++t) {
       const int c = l + lane + 64 * t;
-      const bool ok = c < h && (pos > 0 || first_mask[c] != 0) && (ban_mask == nullptr || ban_mask[c] == 0);
-      zc[t] = ok ? rnd<T>(to_f(row[c]) / temp) : -INFINITY;  // -inf: not a candidate
+      const bool ok = c < h && (pos > 0 || fm[t] != 0) && bm[t] == 0;
+      zc[t] = ok ? rnd<T>(to_f(zraw[t]) / temp) : -INFINITY;  // -inf: not a candidate
     }
   }
   // ---- softmax statistics over the whole vocabulary (logits / temp in the activation dtype, as the reference)
   float m = -INFINITY, ssum = 0.f;
   constexpr int NZ = 14;  // 14 x 256 = 3584 >= vocab 3406: one batch
   for (int base = 0; base < V; base += NZ * 256) {
+    T zr[NZ];
+#pragma unroll
+    for (int i = 0; i < NZ; ++i) {  // (clamped index: unconditional loads, see above)
+      const int c = base + threadIdx.x + 256 * i;
+      zr[i] = row[c < V ? c : V - 1];
+    }
     float zl[NZ];
 #pragma unroll
     for (int i = 0; i < NZ; ++i) {
       const int c = base + threadIdx.x + 256 * i;
-      zl[i] = c < V ? rnd<T>(to_f(row[c]) / temp) : -INFINITY;
+      zl[i] = c < V ? rnd<T>(to_f(zr[i]) / temp) : -INFINITY;
     }
     float cm = zl[0];
 #pragma unroll

@@ -12,7 +12,7 @@ from typing import Dict, List, Tuple
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 HEADER = os.path.join(os.path.dirname(HERE), "include", "midihip.h")
-LIB_PATH = os.path.join(HERE, "libmidihip.so")
+LIB_PATH = os.environ.get("MH_LIB_PATH") or os.path.join(HERE, "libmidihip.so")  # (MH_LIB_PATH: A/B runs of two builds)
 
 MH_F32, MH_BF16 = 0, 1
 

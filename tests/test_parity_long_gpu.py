@@ -239,9 +239,9 @@ def test_flash_attention_at_benchmarked_length(orc, S):
     accumulation order, P rounded to bf16 before the PV product (averages out over the row), and the bf16 rounding of
     O itself: |err| <= 2^-8 |O| + 3e-3 * rms(V) elementwise (the rms(V) term covers the first rows, where a
     row's few P values carry their 2^-9 rounding undiluted) and rms(err) < 3e-3 rms(O); log-sum-exp to 1e-4.  Backward: dq/dk/dv against the
-    closed-form gradients in fp32 on the same inputs (incl. the stored bf16 O): rms error < 3e-3 rms(g), every element within 2^-7 |g| + 1e-2 rms(g) (P and dS enter the
-    MFMAs rounded to bf16: independent 2^-9 relative errors per term, so the tail over 4M elements reaches a few times
-    2^-9 rms(g) where |g| itself is small)."""
+    closed-form gradients in fp32 on the same inputs (incl. the stored bf16 O): rms error < 3e-3 rms(g), every element within
+    2^-8 |g| (output rounding) + 2^-9 sum_k |dS_k| |K_k| (the worst case of rounding the MFMA operand dS -- resp. P for dV --
+    to bf16, computed per element: the first rows have few, large terms that nearly cancel) + 1e-3 rms(g)."""
     from midi_model_amd import ops
     B, H, hd = 1, 16, 64
     D = H * hd
@@ -283,12 +283,16 @@ def test_flash_attention_at_benchmarked_length(orc, S):
         ds = p * (dp - delta) * hd ** -0.5
         del dp
         grads = {"dq": torch.matmul(ds, k), "dk": torch.matmul(ds.transpose(-1, -2), q), "dv": torch.matmul(p.transpose(-1, -2), dof)}
+        # what rounding the MFMA operand (dS resp. P) to bf16 can cost each output element: 2^-9 * sum_k |operand| |other|
+        round_bound = {"dq": torch.matmul(ds.abs(), k.abs()), "dk": torch.matmul(ds.abs().transpose(-1, -2), q.abs()),
+                       "dv": torch.matmul(p.transpose(-1, -2), dof.abs())}
         del ds, p
     for i, nm in enumerate(("dq", "dk", "dv")):
         wantg = grads[nm].transpose(1, 2).reshape(B * S, D)
+        rb = round_bound[nm].transpose(1, 2).reshape(B * S, D)
         e = (dqkv[:, i * D:(i + 1) * D].float().cpu() - wantg).abs()
         rms = wantg.pow(2).mean().sqrt().item()
-        bnd = 2 * BF16_ULP * wantg.abs() + 1e-2 * rms
+        bnd = BF16_ULP * wantg.abs() + 2.0 ** -9 * rb + 1e-3 * rms
         assert (e <= bnd).all(), (nm, e.max().item(), (e / bnd).max().item(), int((e / bnd).argmax()) // D)
         assert e.pow(2).mean().sqrt().item() < 3e-3 * rms, (nm, e.pow(2).mean().sqrt().item() / rms)
 
