@@ -280,8 +280,8 @@ def measure_block(args, B: int, S: int, steps: int, warmup: int, dist=None):
         x, _ = engine.layer_forward(spec, W.layers[0], x, B, S, rope)   # input of block 1: a real residual stream
         lw = W.layers[1]
 
-        def step(i):
-            return engine.layer_forward(spec, lw, x, B, S, rope)[0]
+        def step(i):  # (save=False: the forward-only form a prompt prefill runs -- gate|up is not written for a backward)
+            return engine.layer_forward(spec, lw, x, B, S, rope, save=args.block_save)[0]
 
         for i in range(warmup):
             step(i)
@@ -301,6 +301,7 @@ def measure_block(args, B: int, S: int, steps: int, warmup: int, dist=None):
     return {
         "what": "one net block forward (LlamaDecoderLayer.forward, TF modeling_llama.py:295-324): RMSNorm, q|k|v, RoPE, causal "
                 "flash attention, o + residual, RMSNorm, gate|up + SwiGLU, down + residual",
+        "form": "training forward (activations kept for the backward)" if args.block_save else "forward only (prefill / validation: gate|up not stored)",
         "batch": B, "seq_len": S, "dtype": args.dtype, "ms_per_block": 1e3 * dt / steps, "events_per_s": B * S * steps / dt,
         "flops_per_event": block_flops_per_event(S, spec.D, spec.I),
         "roofline": {"bound": "mfma", "achieved": ach, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": ach / PEAK_BF16_TFLOPS,
@@ -409,6 +410,8 @@ def main():
     ap.add_argument("--gen-events", type=int, default=1024, help="new events per sequence per generate() call")
     ap.add_argument("--block-batch", type=int, default=16)
     ap.add_argument("--block-seq", type=int, default=4096)
+    ap.add_argument("--block-save", action="store_true",
+                    help="block mode: the TRAINING forward (also stores gate|up for the backward) instead of the forward-only form")
     ap.add_argument("--stub", action="store_true", help=argparse.SUPPRESS)  # CPU/gloo self-test of the spawn path
     args = ap.parse_args()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:

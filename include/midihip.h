@@ -59,7 +59,8 @@ int mh_gemm(const void* A, int64_t lda, int transA, const void* B, int64_t ldb, 
 /* gate|up projection with the SwiGLU forward as its epilogue (LlamaMLP.forward, modeling_llama.py:174-176):
  *   GU[M, 2I] = A[M,K] * W[2I,K]^T (W = [gate_proj.weight; up_proj.weight], kept for the backward) and
  *   ACT[M, I] = round(silu(GU[:, :I])) * GU[:, I:]   -- the results of mh_gemm_nt followed by mh_swiglu_fwd, without
- * reading GU back.  bf16, production GEMM kernel only (option "gemm" != 0), I % 128 == 0; fails loudly otherwise. */
+ * reading GU back.  GU == NULL: forward only (nothing will backpropagate: a prompt prefill), only ACT is written.
+ * bf16, production GEMM kernel only (option "gemm" != 0), I % 128 == 0; fails loudly otherwise. */
 int mh_gemm_swiglu(const void* A, int64_t lda, const void* W, int64_t ldw, void* GU, int64_t ldgu, void* ACT,
                    int64_t ldact, int64_t M, int64_t I, int64_t K, int dtype, void* stream);
 /* down_proj dgrad with the SwiGLU backward as its epilogue (LlamaMLP backward, modeling_llama.py:174-176):

@@ -339,8 +339,9 @@ extern "C" int mh_gemm_swiglu(const void* A, int64_t lda, const void* W, int64_t
              "gemm_swiglu: served by the production bf16 kernel only (use mh_gemm + mh_swiglu_fwd otherwise)");
   MH_REQUIRE(M > 0 && I > 0 && K > 0 && I % 128 == 0, "gemm_swiglu: bad shape M=%ld I=%ld K=%ld (I must be a multiple of 128)",
              (long)M, (long)I, (long)K);
-  MH_REQUIRE(lda % 8 == 0 && ldw % 8 == 0 && ldgu % 8 == 0 && ldact % 8 == 0 && lda >= K && ldw >= K && ldgu >= 2 * I &&
-                 ldact >= I,
+  // (GU == NULL: the forward-only form -- a prompt prefill has no backward to keep gate|up for: only ACT is written)
+  MH_REQUIRE(lda % 8 == 0 && ldw % 8 == 0 && ldact % 8 == 0 && lda >= K && ldw >= K && ldact >= I &&
+                 (GU == nullptr || (ldgu % 8 == 0 && ldgu >= 2 * I)),
              "gemm_swiglu: leading dimensions must be multiples of 8 elements and cover the rows");
   MH_REQUIRE((((uintptr_t)A | (uintptr_t)W | (uintptr_t)GU | (uintptr_t)ACT) & 15) == 0, "gemm_swiglu: 16-byte alignment");
   return mh_gemm_pp256_swiglu_bf16(A, lda, W, ldw, GU, ldgu, ACT, ldact, M, I, K, (hipStream_t)stream);

@@ -343,8 +343,10 @@ __global__ __launch_bounds__(512, 2) void gemm_pp256_kernel(const bf16* __restri
           const float sv = (float)(bf16)(gv / (1.f + __expf(-gv)));
           oa[e] = (bf16)(sv * (float)ou[e]);
         }
-        *reinterpret_cast<bf16x8*>(C + m * ldc + col) = og;      // (read again by the backward only)
-        *reinterpret_cast<bf16x8*>(C + m * ldc + I + col) = ou;
+        if (C != nullptr) {  // (read again by the backward only; the forward-only caller passes no buffer: 1 GB less to
+          *reinterpret_cast<bf16x8*>(C + m * ldc + col) = og;      //  write per net block at batch 16 x 4096 events)
+          *reinterpret_cast<bf16x8*>(C + m * ldc + I + col) = ou;
+        }
         *reinterpret_cast<bf16x8*>(act + m * ldr + col) = oa;
       }
     }

@@ -25,7 +25,8 @@
 // Roofline: HBM; algorithmic bytes = rows(W) * K * 2 (weights once).
 #include "common.h"
 
-int g_skinny_mb = 0;  // mh_set_option("skinny_mb", ...): 16-row blocks per workgroup (0 = default, see the launcher)
+int g_skinny_mb = 0;   // mh_set_option("skinny_mb", ...): 16-row blocks per workgroup (0 = default, see the launcher)
+int g_skinny_nbt = 0;  // mh_set_option("skinny_nbt", ...): 16-column blocks per workgroup of the plain form (0 = default)
 
 namespace {
 
@@ -216,8 +217,10 @@ extern "C" int mh_gemm_skinny(const void* A, int64_t lda, const void* W, int64_t
     if (norm_eps > 0.f) MH_SK2(MODE_, NBT_, NW_, GRID_, true);                                                             \
     else MH_SK2(MODE_, NBT_, NW_, GRID_, false);                                                                           \
   } while (0)
+  const int nbt = g_skinny_nbt == 1 || g_skinny_nbt == 2 ? g_skinny_nbt : (N > 4096 ? 2 : 1);
   if (mode == MH_SKINNY_GATEUP) MH_SK(1, 2, 4, (N + 15) / 16);
-  else if (N > 4096) MH_SK(0, 2, 4, (N + 31) / 32);
+  else if (nbt == 2 && N > 4096) MH_SK(0, 2, 4, (N + 31) / 32);
+  else if (nbt == 2) MH_SK(0, 2, 8, (N + 31) / 32);
   else MH_SK(0, 1, 8, (N + 15) / 16);  // 16 columns x 8 waves: <= 4 chunks per wave at K = 1024, all in flight
 #undef MH_SK
 #undef MH_SK2

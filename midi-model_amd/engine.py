@@ -97,11 +97,12 @@ def linear_wgrad(dy: torch.Tensor, x: torch.Tensor, dw: torch.Tensor, accumulate
 # training / prefill forward
 # --------------------------------------------------------------------------------------------------
 def layer_forward(spec: StackSpec, lw: LayerTensors, x: torch.Tensor, nseq: int, slen: int, rope: RopeTable,
-                  kv_out: Optional[list] = None):
+                  kv_out: Optional[list] = None, save: bool = True):
     """One pre-norm LLaMA block (LlamaDecoderLayer.forward, TF:models/llama/modeling_llama.py:295-324) on x [nseq*slen, D]:
     RMSNorm -> q|k|v projection -> RoPE -> causal attention -> o projection + residual -> RMSNorm -> gate|up projection with
     SwiGLU epilogue -> down projection + residual.  8 launches for the event-level stack in bf16 (bench.py --mode block times
-    exactly this function).  Returns (block output, tensors the backward needs)."""
+    exactly this function).  ``save=False`` is the forward-only form (prompt prefill, validation): gate|up is never written,
+    only the activation.  Returns (block output, tensors the backward needs | None)."""
     M, D = x.shape
     H, I = spec.H, spec.I
     h1 = _empty((M, D), x)
@@ -130,16 +131,19 @@ def layer_forward(spec: StackSpec, lw: LayerTensors, x: torch.Tensor, nseq: int,
     h2 = _empty((M, D), x)
     rstd2 = _empty((M,), x, torch.float32)
     ops.rmsnorm_fwd(x2, lw.n2, h2, rstd2, spec.eps)
-    gu = _empty((M, 2 * I), x)
     a = _empty((M, I), x)
+    gu = None
     if ops.swiglu_fused_ok(h2, I):                  # gate|up projection with SwiGLU as its epilogue
+        if save:
+            gu = _empty((M, 2 * I), x)
         ops.gemm_swiglu(h2, lw.wgu, gu, a)
     else:
+        gu = _empty((M, 2 * I), x)
         ops.gemm_nt(h2, lw.wgu, gu)
         ops.swiglu_fwd(gu, a)
     x3 = _empty((M, D), x)
     ops.gemm_nt(a, lw.wd, x3, beta=1.0, res=x2)
-    return x3, (x, rstd1, h1, qkv, o, lse, x2, rstd2, h2, gu, a)
+    return x3, ((x, rstd1, h1, qkv, o, lse, x2, rstd2, h2, gu, a) if save else None)
 
 
 def stack_forward(spec: StackSpec, W: StackTensors, x: torch.Tensor, nseq: int, slen: int, rope: RopeTable,
@@ -152,7 +156,7 @@ def stack_forward(spec: StackSpec, W: StackTensors, x: torch.Tensor, nseq: int, 
     rope.ensure(slen)
     saved = []
     for lw in W.layers:
-        x3, keep = layer_forward(spec, lw, x, nseq, slen, rope, kv_out)
+        x3, keep = layer_forward(spec, lw, x, nseq, slen, rope, kv_out, save)
         if save:
             saved.append(keep)
         x = x3

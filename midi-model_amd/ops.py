@@ -139,17 +139,19 @@ def swiglu_fused_ok(x: torch.Tensor, I: int) -> bool:
     return x.dtype == torch.bfloat16 and I % 128 == 0 and get_option("gemm") != 0 and (_FUSE & 1) != 0
 
 
-def gemm_swiglu(x: torch.Tensor, wgu: torch.Tensor, gu: torch.Tensor, a: torch.Tensor) -> torch.Tensor:
-    """gu [M, 2I] = x @ wgu^T (wgu = [gate; up], [2I, K]) and a [M, I] = silu(gate) * up"""
+def gemm_swiglu(x: torch.Tensor, wgu: torch.Tensor, gu: Optional[torch.Tensor], a: torch.Tensor) -> torch.Tensor:
+    """gu [M, 2I] = x @ wgu^T (wgu = [gate; up], [2I, K]) and a [M, I] = silu(gate) * up; gu=None: forward only, gate|up is
+    not written (nothing will backpropagate)"""
     M, K = x.shape
     I = a.shape[1]
-    assert wgu.shape == (2 * I, K) and gu.shape == (M, 2 * I) and a.shape[0] == M and x.dtype == wgu.dtype == gu.dtype == a.dtype
+    assert wgu.shape == (2 * I, K) and a.shape[0] == M and x.dtype == wgu.dtype == a.dtype
+    assert gu is None or (gu.shape == (M, 2 * I) and gu.dtype == x.dtype)
     prof = gemm_profile
     if prof is not None:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-    lib().call("mh_gemm_swiglu", _p(x), _rowmajor(x), _p(wgu), _rowmajor(wgu), _p(gu), _rowmajor(gu), _p(a), _rowmajor(a),
-               M, I, K, dt(x), _stream())
+    lib().call("mh_gemm_swiglu", _p(x), _rowmajor(x), _p(wgu), _rowmajor(wgu), _p(gu), _rowmajor(gu) if gu is not None else 0,
+               _p(a), _rowmajor(a), M, I, K, dt(x), _stream())
     if prof is not None:
         e1.record()
         prof.append((e0, e1, 2.0 * M * 2 * I * K, (M, 2 * I, K, 1, 0, 0, "+swiglu")))

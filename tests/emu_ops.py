@@ -49,6 +49,8 @@ def swiglu_fused_ok(x, I):
 
 
 def gemm_swiglu(x, wgu, gu, a):
+    if gu is None:  # forward-only form: gate|up is not kept
+        gu = torch.empty((x.shape[0], wgu.shape[0]), dtype=x.dtype)
     gemm_nt(x, wgu, gu)
     return swiglu_fwd(gu, a)
 

@@ -23,7 +23,7 @@ from midi_model_amd.train import TrainMIDIModel
 
 pytestmark = pytest.mark.gpu
 
-BF16_ULP = 2.0 ** -8  # |x - bf16(x)| <= 2^-9 |x|; one extra factor 2 for a value rounded on both sides of a comparison
+BF16_ULP = 2.0 ** -8  # unit roundoff of bf16 (8 significand bits): |x - bf16(x)| <= 2^-8 |x|
 DRIFT = 1.5           # allowed multiple of the reference's own bf16 drift
 
 
@@ -240,8 +240,8 @@ def test_flash_attention_at_benchmarked_length(orc, S):
     O itself: |err| <= 2^-8 |O| + 3e-3 * rms(V) elementwise (the rms(V) term covers the first rows, where a
     row's few P values carry their 2^-9 rounding undiluted) and rms(err) < 3e-3 rms(O); log-sum-exp to 1e-4.  Backward: dq/dk/dv against the
     closed-form gradients in fp32 on the same inputs (incl. the stored bf16 O): rms error < 3e-3 rms(g), every element within
-    2^-8 |g| (output rounding) + 2^-9 sum_k |dS_k| |K_k| (the worst case of rounding the MFMA operand dS -- resp. P for dV --
-    to bf16, computed per element: the first rows have few, large terms that nearly cancel) + 1e-3 rms(g)."""
+    1.25 x 2^-8 (|g| + sum_k |dS_k| |K_k|): the output rounding plus the worst case of rounding the MFMA operand dS (resp. P
+    for dV) to bf16, computed per element -- the first rows have few, large terms that nearly cancel -- + 1e-3 rms(g)."""
     from midi_model_amd import ops
     B, H, hd = 1, 16, 64
     D = H * hd
@@ -292,7 +292,7 @@ def test_flash_attention_at_benchmarked_length(orc, S):
         rb = round_bound[nm].transpose(1, 2).reshape(B * S, D)
         e = (dqkv[:, i * D:(i + 1) * D].float().cpu() - wantg).abs()
         rms = wantg.pow(2).mean().sqrt().item()
-        bnd = BF16_ULP * wantg.abs() + 2.0 ** -9 * rb + 1e-3 * rms
+        bnd = 1.25 * BF16_ULP * (wantg.abs() + rb) + 1e-3 * rms
         assert (e <= bnd).all(), (nm, e.max().item(), (e / bnd).max().item(), int((e / bnd).argmax()) // D)
         assert e.pow(2).mean().sqrt().item() < 3e-3 * rms, (nm, e.pow(2).mean().sqrt().item() / rms)
 
@@ -354,6 +354,9 @@ def test_swiglu_epilogues_at_benchmarked_shape():
     got_gu = gu[rows].float().cpu().double()
     e = (got_gu - want_gu).abs()
     assert (e <= BF16_ULP * want_gu.abs() + 1e-3 * want_gu.pow(2).mean().sqrt()).all(), e.max().item()
+    a2 = torch.full_like(a, float("nan"))
+    ops.gemm_swiglu(x, wgu, None, a2)                 # forward-only form: same activation, gate|up not written
+    assert torch.equal(a2, a)
     gr, ur = got_gu[:, :I], got_gu[:, I:]            # the kernel's own rounded gate / up
     want_a = (gr / (1 + torch.exp(-gr))).float().bfloat16().double() * ur
     e = (a[rows].float().cpu().double() - want_a).abs()

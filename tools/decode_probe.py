@@ -90,6 +90,40 @@ def section_1():
                   f"(weights {wbytes / 1e6:.1f} MB per layer = {wbytes / 6.3e12 * 1e6:.1f} us at 6.3 TB/s for the 4 launches)")
 
 
+def section_1b():
+    print("== 1b. each decode projection alone, 48 chained launches in a replayed graph (us per launch), by row tiling ==")
+    M, D = 64, 1024
+    g = torch.Generator().manual_seed(0)
+    shapes = [("q|k|v      N=3072 K=1024 rstd", 3072, 1024, 0, True, False),
+              ("o / down   N=1024 K=1024 +res", 1024, 1024, 0, False, True),
+              ("down (net) N=1024 K=4096 +res", 1024, 4096, 0, False, True),
+              ("gate|up    I=4096 K=1024 rstd", 4096, 1024, 1, True, False),
+              ("gate|up    I=1024 K=1024 rstd", 1024, 1024, 1, True, False),
+              ("lm_head    N=3406 K=1024 rstd", 3406, 1024, 0, True, False)]
+    for name, N, K, mode, rstd, res in shapes:
+        ws = [(0.02 * torch.randn(((2 if mode else 1) * N, K), generator=g)).to(dev, bf) for _ in range(6)]
+        x = torch.randn((M, K), generator=g).to(dev, bf)
+        outs = [torch.zeros((M, (max(N, K) + 127) // 64 * 64), device=dev, dtype=bf) for _ in range(2)]
+        r = torch.randn((M, N), generator=g).to(dev, bf) if res else None
+
+        def body():
+            a = x
+            for l in range(48):
+                o = outs[l & 1][:, :N]
+                ops.gemm_skinny(a, ws[l % 6], o, mode=mode, norm_eps=1e-6 if rstd else 0.0, res=r)
+                a = outs[l & 1][:, :K] if K <= N else x  # (chained where the shapes allow; K > N re-reads x)
+        line = []
+        for nbt in ((1, 2) if mode == 0 else (0,)):
+            ops.set_option("skinny_nbt", nbt)
+            for mb in (4, 2, 1):
+                ops.set_option("skinny_mb", mb)
+                line.append(f"nbt{nbt}/mb{mb} {1e3 * graph_time(body) / 48:5.2f}")
+        ops.set_option("skinny_mb", 0)
+        ops.set_option("skinny_nbt", 0)
+        wb = 2.0 * (2 if mode else 1) * N * K
+        print(f"{name}: " + "  ".join(line) + f"   ({wb / 1e6:5.1f} MB of weights = {wb / 6.3e12 * 1e6:.2f} us at 6.3 TB/s)")
+
+
 def section_2(model):
     print("== 2. replay time of the session graphs (B=64, capacity 2048) ==")
     for mb in (4, 1):
@@ -156,6 +190,8 @@ if __name__ == "__main__":
     which = sys.argv[1:] or ["1", "2", "3"]
     if "1" in which:
         section_1()
+    if "1b" in which:
+        section_1b()
     model = mm.MIDIModel(mm.MIDIModelConfig.from_name("tv2o-medium")).to(dev, bf).eval()
     if "2" in which:
         section_2(model)
