@@ -24,6 +24,8 @@
 // Roofline: MFMA (2.5 PFLOP/s bf16 dense), VALU co-limited.
 #include "common.h"
 
+int g_attn_fwd_wps = 2;  // mh_set_option("attn_fwd_wps", 2 | 3): register budget of the second forward structure (A/B runs)
+
 constexpr int HD = 64;
 constexpr int TILE64 = 64 * 128;  // bytes
 constexpr float LOG2E = 1.4426950408889634f;
@@ -279,16 +281,38 @@ __device__ inline bf16x8 join8(const u32x2& a, const u32x2& b) {
   return u.v;
 }
 
-// one 64-key tile for one wave (32 query rows); koff[s] / voff[db][half]: this lane's byte offsets inside a K / V tile
+// one 64-key tile for one wave (32 query rows); koff[s] / voff[db][half]: this lane's byte offsets inside a K / V tile.
+// LDS latency is taken off the critical path by hand: all 8 K fragments are requested before the first S^T MFMA, and the 16
+// transpose reads of V are requested right after the S^T MFMAs are issued, i.e. BEFORE the softmax arithmetic that produces
+// P -- they do not depend on it -- so O^T += V^T P^T starts with its operands in registers (the first form interleaved a
+// pair of fragment reads with each MFMA and waited for them there: ~100 cycles of LDS latency in front of every second MFMA).
 template <bool MASK>
 __device__ inline void fwd2_tile(const char* tK, const char* tV, const int (&koff)[4], const int (&voff)[2][2],
                                  const bf16x8 (&qf)[4], f32x16 (&oacc)[2], float& m, float& l, int hi, int qrel, float sc) {
-  f32x16 sacc[2] = {zero16(), zero16()};
+  bf16x8 kf[2][4];
 #pragma unroll
   for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
-    for (int s = 0; s < 4; ++s)
-      sacc[kb] = mfma32(*reinterpret_cast<const bf16x8*>(tK + koff[s] + kb * 4096), qf[s], sacc[kb]);
+    for (int s = 0; s < 4; ++s) kf[kb][s] = *reinterpret_cast<const bf16x8*>(tK + koff[s] + kb * 4096);
+  f32x16 sacc[2] = {zero16(), zero16()};
+#pragma unroll
+  for (int s = 0; s < 4; ++s)
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb) sacc[kb] = mfma32(kf[kb][s], qf[s], sacc[kb]);  // two independent accumulator chains
+  // V^T fragments of the whole tile, in flight under the softmax below
+  unsigned va[2][2];
+#pragma unroll
+  for (int db = 0; db < 2; ++db)
+#pragma unroll
+    for (int half = 0; half < 2; ++half) va[db][half] = lds_addr32(tV) + (unsigned)voff[db][half];
+  u32x2 vr[4][2][2];
+#define MH_VREADS(T)                          \
+  vr[T][0][0] = ds_tr16<(T) * 2048>(va[0][0]); \
+  vr[T][0][1] = ds_tr16<(T) * 2048>(va[0][1]); \
+  vr[T][1][0] = ds_tr16<(T) * 2048>(va[1][0]); \
+  vr[T][1][1] = ds_tr16<(T) * 2048>(va[1][1]);
+  MH_VREADS(0) MH_VREADS(1) MH_VREADS(2) MH_VREADS(3)
+#undef MH_VREADS
   float mx = -INFINITY;
 #pragma unroll
   for (int kb = 0; kb < 2; ++kb)
@@ -299,7 +323,12 @@ __device__ inline void fwd2_tile(const char* tK, const char* tV, const int (&kof
       }
       mx = fmaxf(mx, sacc[kb][r]);
     }
-  mx = fmaxf(mx, __shfl_xor(mx, 32, 64)) * sc;  // running max kept in scaled (log2) units
+  {  // the other half-wave's maximum through v_permlane32_swap (VALU): __shfl_xor is a ds_bpermute, whose lgkmcnt wait
+     // would also wait for the transpose reads just requested
+    const int ix = __float_as_int(mx);
+    const auto pr = __builtin_amdgcn_permlane32_swap(ix, ix, false, false);
+    mx = fmaxf(__int_as_float(pr[0]), __int_as_float(pr[1])) * sc;  // running max kept in scaled (log2) units
+  }
   float mn = m, alpha = 1.f;
   if (__any(mx > m + RESCALE_THR)) {  // (see fwd_tile)
     mn = fmaxf(m, mx);
@@ -309,50 +338,31 @@ __device__ inline void fwd2_tile(const char* tK, const char* tV, const int (&kof
 #pragma unroll
       for (int r = 0; r < 16; ++r) oacc[db][r] *= alpha;
   }
-  float psum = 0.f;
+  float psum0 = 0.f, psum1 = 0.f;  // (two partial sums: half the length of the dependent add chain)
 #pragma unroll
-  for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const float p = fast_exp2(__builtin_fmaf(sacc[kb][r], sc, -mn));
-      sacc[kb][r] = p;
-      psum += p;
-    }
-  l = l * alpha + psum;
-  m = mn;
-  // O^T += V^T P^T: the 16 transpose reads of the tile in two batches of 8 (keys 0..31, 32..63)
-  unsigned va[2][2];
-#pragma unroll
-  for (int db = 0; db < 2; ++db)
-#pragma unroll
-    for (int half = 0; half < 2; ++half) va[db][half] = lds_addr32(tV) + (unsigned)voff[db][half];
-#define MH_PV_BATCH(T0)                                                                                              \
-  {                                                                                                                 \
-    u32x2 r[2][2][2];                                                                                               \
-    r[0][0][0] = ds_tr16<(T0) * 2048>(va[0][0]);                                                                    \
-    r[0][0][1] = ds_tr16<(T0) * 2048>(va[0][1]);                                                                    \
-    r[0][1][0] = ds_tr16<(T0) * 2048>(va[1][0]);                                                                    \
-    r[0][1][1] = ds_tr16<(T0) * 2048>(va[1][1]);                                                                    \
-    r[1][0][0] = ds_tr16<(T0 + 1) * 2048>(va[0][0]);                                                                \
-    r[1][0][1] = ds_tr16<(T0 + 1) * 2048>(va[0][1]);                                                                \
-    r[1][1][0] = ds_tr16<(T0 + 1) * 2048>(va[1][0]);                                                                \
-    r[1][1][1] = ds_tr16<(T0 + 1) * 2048>(va[1][1]);                                                                \
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                              \
-    __builtin_amdgcn_sched_barrier(0);                                                                              \
-    _Pragma("unroll") for (int tt = 0; tt < 2; ++tt) {                                                              \
-      const bf16x8 pf = pack8(sacc[((T0) + tt) >> 1], 8 * (((T0) + tt) & 1));                                       \
-      _Pragma("unroll") for (int db = 0; db < 2; ++db)                                                              \
-        oacc[db] = mfma32(join8(r[tt][db][0], r[tt][db][1]), pf, oacc[db]);                                         \
-    }                                                                                                               \
+  for (int r = 0; r < 16; ++r) {
+    const float p0 = fast_exp2(__builtin_fmaf(sacc[0][r], sc, -mn)), p1 = fast_exp2(__builtin_fmaf(sacc[1][r], sc, -mn));
+    sacc[0][r] = p0;
+    sacc[1][r] = p1;
+    psum0 += p0;
+    psum1 += p1;
   }
-  MH_PV_BATCH(0)
-  MH_PV_BATCH(2)
-#undef MH_PV_BATCH
+  l = l * alpha + (psum0 + psum1);
+  m = mn;
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the V^T fragments (asm reads: invisible to hipcc's counters)
+  __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+  for (int t = 0; t < 4; ++t) {
+    const bf16x8 pf = pack8(sacc[t >> 1], 8 * (t & 1));
+#pragma unroll
+    for (int db = 0; db < 2; ++db) oacc[db] = mfma32(join8(vr[t][db][0], vr[t][db][1]), pf, oacc[db]);
+  }
 }
 
-__global__ __launch_bounds__(256, 3) void attn_fwd2_kernel(const bf16* __restrict__ qkv, bf16* __restrict__ o,
-                                                        float* __restrict__ lse, int S, int Sp, int H,
-                                                        float sc /* scale*log2(e) */, int BH, int nqt) {
+template <int WPS>  // waves per SIMD the register allocation is held to (3: 168 VGPRs, 2: 256)
+__global__ __launch_bounds__(256, WPS) void attn_fwd2_kernel(const bf16* __restrict__ qkv, bf16* __restrict__ o,
+                                                          float* __restrict__ lse, int S, int Sp, int H,
+                                                          float sc /* scale*log2(e) */, int BH, int nqt) {
   // dynamic LDS (3 stages x [K | V] x 8 KiB = 48 KiB): with a static __shared__ array hipcc's LDS-DMA alias tracking puts
   // an s_waitcnt vmcnt(0) in front of the first fragment read of every tile, which drains the stage just requested
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -692,7 +702,10 @@ int mh_attn_fwd_mfma(const void* qkv, const void* vt, void* o, float* lse, int64
   const int nt = (int)((S + 127) / 128), BH = (int)(B * H);
   const unsigned grid = (unsigned)(nt * 8 * ((BH + 7) / 8));
   if (vt == nullptr) {  // second structure: V read row-major through transpose reads, no prepared copy
-    attn_fwd2_kernel<<<grid, 256, 3 * 2 * TILE64, st>>>((const bf16*)qkv, (bf16*)o, lse, (int)S, (int)Sp, H, scale * LOG2E, BH, nt);
+    if (g_attn_fwd_wps == 3)
+      attn_fwd2_kernel<3><<<grid, 256, 3 * 2 * TILE64, st>>>((const bf16*)qkv, (bf16*)o, lse, (int)S, (int)Sp, H, scale * LOG2E, BH, nt);
+    else
+      attn_fwd2_kernel<2><<<grid, 256, 3 * 2 * TILE64, st>>>((const bf16*)qkv, (bf16*)o, lse, (int)S, (int)Sp, H, scale * LOG2E, BH, nt);
     MH_LAUNCH_CHECK();
     return MH_OK;
   }

@@ -312,10 +312,16 @@ def rope_(qkv: torch.Tensor, cos_t: torch.Tensor, sin_t: torch.Tensor, S: int, p
 
 
 # ----------------------------------------------------------------------------------------- attention
+_attn_wps_set = False
 ATTN_FWD_FORM = int(os.environ.get("MH_ATTN_FWD", "2"))  # 2: transpose-read V + 3-stage ring; 1: first structure (prepared V^T copy)
 
 
 def attn_fwd(qkv, o, lse, B: int, S: int, H: int, scale: float):
+    global _attn_wps_set
+    if not _attn_wps_set:  # (A/B runs: MH_ATTN_FWD_WPS = 2 | 3)
+        _attn_wps_set = True
+        if "MH_ATTN_FWD_WPS" in os.environ:
+            set_option("attn_fwd_wps", int(os.environ["MH_ATTN_FWD_WPS"]))
     vt = None
     if qkv.dtype == torch.bfloat16 and ATTN_FWD_FORM == 1:
         Sp = round_up(S, 64)
