@@ -195,11 +195,20 @@ extern "C" int mh_gemm_skinny(const void* A, int64_t lda, const void* W, int64_t
              "gemm_skinny: A/W rows must be 16-byte aligned");
   MH_REQUIRE(mode != MH_SKINNY_GATEUP || R == nullptr, "gemm_skinny: the gate|up epilogue takes no residual");
   hipStream_t st = (hipStream_t)stream;
-  // rows per workgroup: option "skinny_mb" (0 = pick: one 16-row block per workgroup whenever that leaves the launch
-  // at <= 1024 workgroups -- measured, profiles/r02_*skinny*; 4 = the first form, every workgroup takes all rows)
-  int mb = g_skinny_mb;
+  // Tiling (r02, tools/decode_probe.py section 1b, profiles/r02_*decode_probe*): a launch spends its time in the TA/L1 path
+  // of the CUs (64 B/clk each) and in fixed latencies, so the best tile is the LARGEST one that still puts about one
+  // workgroup on each of the 256 CUs: two column blocks for the wide projections (q|k|v, lm_head), and as many 16-row
+  // blocks per workgroup as leave >= ~256 workgroups -- q|k|v 32 rows x 32 columns (6.9 us against 8.3 for 16 x 16), gate|up
+  // of the event-level stack all 64 rows (9.4 us against 13.7), the N = 1024 projections 16 x 16 (4.3 us against 7.2 for 64 rows).
+  // Options "skinny_mb" / "skinny_nbt" force a form (tests, probes).
   const int row_blocks = (int)((M + 15) / 16);
-  if (mb != 1 && mb != 2 && mb != 4) mb = 1;
+  const int nbt = (mode == MH_SKINNY_GATEUP) ? 2 : (g_skinny_nbt == 1 || g_skinny_nbt == 2 ? g_skinny_nbt : (N >= 2048 ? 2 : 1));
+  const int col_tiles = (mode == MH_SKINNY_GATEUP) ? (int)((N + 15) / 16) : (int)((N + 16 * nbt - 1) / (16 * nbt));
+  int mb = g_skinny_mb;
+  if (mb != 1 && mb != 2 && mb != 4) {
+    const int groups = 256 / col_tiles;  // row groups that keep the launch at <= ~256 workgroups
+    mb = groups >= 4 ? 1 : (groups >= 2 ? 2 : 4);
+  }
   if (mb > row_blocks) mb = row_blocks >= 4 ? 4 : (row_blocks >= 2 ? 2 : 1);
   const int gy = (row_blocks + mb - 1) / mb;
 #define MH_SK3(MODE_, NBT_, NW_, GRID_, RSTD_, MB_)                                                                        \
@@ -217,7 +226,6 @@ extern "C" int mh_gemm_skinny(const void* A, int64_t lda, const void* W, int64_t
     if (norm_eps > 0.f) MH_SK2(MODE_, NBT_, NW_, GRID_, true);                                                             \
     else MH_SK2(MODE_, NBT_, NW_, GRID_, false);                                                                           \
   } while (0)
-  const int nbt = g_skinny_nbt == 1 || g_skinny_nbt == 2 ? g_skinny_nbt : (N > 4096 ? 2 : 1);
   if (mode == MH_SKINNY_GATEUP) MH_SK(1, 2, 4, (N + 15) / 16);
   else if (nbt == 2 && N > 4096) MH_SK(0, 2, 4, (N + 31) / 32);
   else if (nbt == 2) MH_SK(0, 2, 8, (N + 31) / 32);

@@ -313,7 +313,10 @@ def rope_(qkv: torch.Tensor, cos_t: torch.Tensor, sin_t: torch.Tensor, S: int, p
 
 # ----------------------------------------------------------------------------------------- attention
 _attn_wps_set = False
-ATTN_FWD_FORM = int(os.environ.get("MH_ATTN_FWD", "2"))  # 2: transpose-read V + 3-stage ring; 1: first structure (prepared V^T copy)
+# 1: first structure (prepared V^T copy, two-stage K/V buffer); 2: second structure (V through transpose reads, three-stage
+# ring, fragments requested ahead of use).  r02 A/B at B=16 x S=4096, same box, interleaved (profiles/r02_*attn_fwd_ab*): form 1
+# 816-827 us + 54 us prep, form 2 922-977 us -- the second structure is correct (same tests) but slower, so form 1 stays.
+ATTN_FWD_FORM = int(os.environ.get("MH_ATTN_FWD", "1"))
 
 
 def attn_fwd(qkv, o, lse, B: int, S: int, H: int, scale: float):
