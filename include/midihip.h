@@ -231,7 +231,7 @@ int mh_masked_softmax(const void* logits, int64_t ldl, const int32_t* lo, const 
  * first top_k of a row are read) taken by the caller from the caller's generator (torch.Tensor.exponential_), which is
  * what keeps a seeded generator's stream identical to the reference's.  The id goes to out[b * out_stride] and, when
  * non-null, to out_b[b] and out_c[b] (all int64); the fill_rest entries after out[b * out_stride] are set to fill_id
- * (position 0 opens a fresh event row padded with pad_id).  1 <= top_k <= 64.  ban_mask (optional, [V] bytes): ids with a
+ * (position 0 opens a fresh event row padded with pad_id).  1 <= top_k <= 64.  ban_mask ([V] bytes, required -- all zero = nothing banned): ids with a
  * non-zero byte are removed from every mask (app.py:30-31,85-86 disable_channels).  The caller states the spans of the masks:
  * first_mask is zero outside [first_lo, first_hi), no table range AT THIS POSITION is longer than max_range; both at most
  * 2048 ids.                                                                                                 */

@@ -464,7 +464,7 @@ __global__ __launch_bounds__(256) void sample_top_p_k_kernel(const T* __restrict
       c = c < V ? c : V - 1;
       zraw[t] = row[c];
       fm[t] = first_mask[c];
-      bm[t] = ban_mask != nullptr ? ban_mask[c] : (uint8_t)0;  // (uniform condition)
+      bm[t] = ban_mask[c];  // (always a real mask: an optional pointer costs a branch + wait per element here)
     }
 #pragma unroll
     for (int t = 0; t < TMAX; ++t) {
@@ -527,21 +527,30 @@ __global__ __launch_bounds__(256) void sample_top_p_k_kernel(const T* __restrict
   // ---- the top_k largest candidates in the order of torch's stable descending sort (value descending, id ascending):
   // rank j -> sel_v[j], sel_i[j]
   if constexpr (TMAX <= 2) {
+    // rank = number of candidates that sort before this one.  One 64-bit key per candidate -- (probability bits, ~position):
+    // larger probability first, lower id among equal probabilities; 0 = not a candidate -- so a pair costs one unsigned
+    // compare + add-with-carry and the loop has no branches (written with || / && it compiled to four exec-mask branches per
+    // step: 64 x ~100 instructions, 7 us of the kernel's 15, r02 trace).
+    uint64_t key[TMAX];
     int rank[TMAX];
 #pragma unroll
-    for (int t = 0; t < TMAX; ++t) rank[t] = 0;
+    for (int t = 0; t < TMAX; ++t) {
+      key[t] = pv[t] >= 0.f ? ((uint64_t)__float_as_uint(pv[t]) << 32) | (uint32_t)(0xffffffffu - (uint32_t)(lane + 64 * t)) : 0ull;
+      rank[t] = 0;
+    }
     for (int sl = 0; sl < 64; ++sl) {
 #pragma unroll
       for (int u = 0; u < TMAX; ++u) {
-        const float ov = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(pv[u]), sl));
-        const int ot = sl + 64 * u;  // position of the other candidate within the range (id = l + ot)
+        const uint32_t ohi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(key[u] >> 32), sl);
+        const uint32_t olo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)key[u], sl);
+        const uint64_t ok = ((uint64_t)ohi << 32) | olo;
 #pragma unroll
-        for (int t = 0; t < TMAX; ++t) rank[t] += (ov > pv[t] || (ov == pv[t] && ot < lane + 64 * t)) ? 1 : 0;
+        for (int t = 0; t < TMAX; ++t) rank[t] += (int)(ok > key[t]);
       }
     }
 #pragma unroll
     for (int t = 0; t < TMAX; ++t)
-      if (pv[t] >= 0.f && rank[t] < top_k) {
+      if (key[t] != 0ull && rank[t] < top_k) {
         sel_v[rank[t]] = pv[t];
         sel_i[rank[t]] = l + lane + 64 * t;
       }
@@ -605,6 +614,8 @@ extern "C" int mh_sample_top_p_k(const void* logits, int64_t ldl, const uint8_t*
                                  void* stream) {
   MH_REQUIRE(B > 0 && V > 0 && temp > 0.f && pos >= 0 && pos < tab_stride && fill_rest >= 0 && fill_rest < out_stride,
              "sample_top_p_k: bad args");
+  MH_REQUIRE(first_mask != nullptr && ban_mask != nullptr && q != nullptr,
+             "sample_top_p_k: first_mask, ban_mask (V bytes each; all zero = nothing banned) and q are required");
   MH_REQUIRE(pos == 0 || (ev != nullptr && lo_tab != nullptr && hi_tab != nullptr), "sample_top_p_k: position %d needs the event ids and range tables", pos);
   MH_REQUIRE(top_k >= 1 && top_k <= SAMPLE_MAX_K && top_k <= V, "sample_top_p_k: top_k=%d outside [1, %d]", top_k,
              SAMPLE_MAX_K);

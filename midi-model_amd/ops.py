@@ -428,6 +428,7 @@ SAMPLE_MAX_K = 64
 
 
 SAMPLE_MAX_RANGE = 2048
+_ZERO_MASKS: dict = {}
 
 
 def mask_spans(first_mask: torch.Tensor, lo_tab: torch.Tensor, hi_tab: torch.Tensor):
@@ -449,6 +450,11 @@ def sample_top_p_k(logits, first_mask, lo_tab, hi_tab, ev, pos: int, q, out, V: 
     assert lo_tab.dtype == torch.int32 and lo_tab.is_contiguous() and hi_tab.is_contiguous() and ev.dtype == torch.int64
     for t in (out_b, out_c):
         assert t is None or (t.dtype == torch.int64 and t.is_contiguous() and t.numel() == B)
+    if ban_mask is None:  # (the kernel reads the mask unconditionally: nothing banned = zeros)
+        key = (logits.device, V)
+        if key not in _ZERO_MASKS:
+            _ZERO_MASKS[key] = torch.zeros(V, dtype=torch.uint8, device=logits.device)
+        ban_mask = _ZERO_MASKS[key]
     lib().call("mh_sample_top_p_k", _p(logits), _rowmajor(logits), _p(first_mask), _p(ban_mask), int(first_span[0]),
                int(first_span[1]),
                _p(lo_tab), _p(hi_tab), lo_tab.shape[1], int(max_range), _p(ev), pos, _p(q), _p(out), out.stride(0),
