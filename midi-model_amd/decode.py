@@ -97,7 +97,8 @@ class DecodeSession:
         self._off = 0          # philox offset of the next draw the reference loop would make
         self._draw_inc = 0     # philox offset consumed by one [B, V] exponential_ call
         self._noise_pending = False
-        self.noise_stream = self.noise_done = None
+        self._steps_recorded = False
+        self.noise_stream = self.noise_done = self.copy_stream = self.steps_done = self.seq_host = None
         if self.use_graphs:
             self._capture()
 
@@ -216,6 +217,9 @@ class DecodeSession:
             assert self._draw_inc > 0 and self._draw_inc * self.T == self.gen.get_offset() - o0
             self.noise_stream = torch.cuda.Stream()
             self.noise_done = torch.cuda.Event()
+            self.copy_stream = torch.cuda.Stream()
+            self.steps_done = torch.cuda.Event()
+            self.seq_host = torch.empty((self.B, self.T), dtype=torch.long).pin_memory()
         else:
             for i in range(self.T):
                 self._capture_step(i)
@@ -287,6 +291,7 @@ class DecodeSession:
             if self.g_noise is not None and self._noise_pending:
                 torch.cuda.current_stream().wait_event(self.noise_done)
             self.g_tok[i].replay()
+            self._steps_recorded = False
         else:
             self._tok_body(i, self._user_gen)
 
@@ -296,8 +301,12 @@ class DecodeSession:
         loop would be at; they overlap whatever the caller queues next on its own stream (the net step)"""
         if self.g_noise is None:
             return
-        cur = torch.cuda.current_stream()
-        self.noise_stream.wait_stream(cur)  # the token steps that read the previous draws are queued on `cur`
+        # the token steps that read the previous draws must be done first: the event recorded right behind the steps graph
+        # when there is one (NOT the whole stream: the net step queued after it is what the draws should overlap)
+        if self._steps_recorded:
+            self.noise_stream.wait_event(self.steps_done)
+        else:
+            self.noise_stream.wait_stream(torch.cuda.current_stream())
         self.gen.set_offset(self._off)
         with torch.cuda.stream(self.noise_stream):
             self.g_noise.replay()
@@ -321,14 +330,27 @@ class DecodeSession:
             return 2, True
         return (alive[0] + 1 if all(a == alive[0] for a in alive) else self.T), False
 
-    def sample_event(self):
-        """sample the T tokens of the next event from `hidden`; -> (np.ndarray [B, T] int64, all rows ended?)"""
+    def sample_event(self, then_net: bool = False):
+        """sample the T tokens of the next event from `hidden`; -> (np.ndarray [B, T] int64, all rows ended?).
+        ``then_net`` (graph form): the net step over the sampled event is queued right behind the token steps, BEFORE the host
+        waits for the tokens -- it depends on nothing the host decides -- so the device never idles through the host's
+        round trip; the tokens come back through a copy stream that waits for the token steps only.  (If every row turns out
+        to have ended, that net step was wasted work on a session about to be reset.)"""
         if self.g_steps is not None:
             if not self._noise_pending:
                 self.draw_noise()
-            torch.cuda.current_stream().wait_event(self.noise_done)
+            cur = torch.cuda.current_stream()
+            cur.wait_event(self.noise_done)
             self.g_steps.replay()
-            event = self.seq.cpu().numpy().copy()  # the one host sync per event
+            self.steps_done.record(cur)
+            self._steps_recorded = True
+            if then_net:
+                self.net_step()
+            self.copy_stream.wait_event(self.steps_done)
+            with torch.cuda.stream(self.copy_stream):
+                self.seq_host.copy_(self.seq, non_blocking=True)
+            self.copy_stream.synchronize()  # the one host sync per event
+            event = self.seq_host.numpy().copy()
             n, end_all = self.n_steps_of(event[:, 0].tolist())
             self.consumed(n)
             return event, end_all

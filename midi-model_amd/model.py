@@ -477,12 +477,17 @@ class MIDIModel(nn.Module):
                 ses.prefill(inp)  # causal forward over the prompt; hidden = last position
             while cur_len < max_len:
                 with torch.inference_mode():
-                    event, end_all = ses.sample_event()  # the event's 8 token steps (one replayed graph, one host copy)
+                    more = cur_len + 1 < max_len
+                    speculative = more and ses.g_steps is not None
+                    # the event's 8 token steps (one replayed graph, one host copy); in the graph form the net step over
+                    # the event is queued behind them before the host waits
+                    event, end_all = ses.sample_event(then_net=speculative)
                     cur_len += 1
-                    last = end_all or cur_len >= max_len
+                    last = end_all or not more
                     if not last:
                         ses.draw_noise()  # the next event's draws, on a side stream under the net step
-                        ses.net_step()    # decode the event just sampled; hidden = its net output (overlaps the consumer)
+                        if not speculative:
+                            ses.net_step()  # decode the event just sampled; hidden = its net output (overlaps the consumer)
                 yield event
                 if last:
                     break
