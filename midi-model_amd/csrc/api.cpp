@@ -27,7 +27,7 @@ static int env_int(const char* name, int dflt) {
 int g_mh_gemm_variant = env_int("MH_GEMM", 1);
 int g_mh_gemm_ablate = 0;
 extern int g_skinny_mb, g_skinny_nbt;  // gemm_skinny.hip
-extern int g_attn_fwd_wps;              // attention_mfma.hip
+extern int g_attn_fwd_wps, g_attn_fwd_qb;  // attention_mfma.hip
 
 extern "C" int mh_set_option(const char* name, int value) {
   if (strcmp(name, "gemm") == 0) {
@@ -44,6 +44,10 @@ extern "C" int mh_set_option(const char* name, int value) {
   }
   if (strcmp(name, "attn_fwd_wps") == 0) {  // waves per SIMD of the event-level attention forward (2 | 3)
     g_attn_fwd_wps = value;
+    return 0;
+  }
+  if (strcmp(name, "attn_fwd_qb") == 0) {  // query blocks (32 rows) per wave of the event-level attention forward (1 | 2)
+    g_attn_fwd_qb = value;
     return 0;
   }
   if (strcmp(name, "skinny_nbt") == 0) {  // 16-column blocks per workgroup of its plain form (0 = default)

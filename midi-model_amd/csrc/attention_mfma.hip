@@ -24,6 +24,7 @@
 // Roofline: MFMA (2.5 PFLOP/s bf16 dense), VALU co-limited.
 #include "common.h"
 
+int g_attn_fwd_qb = 1;   // mh_set_option("attn_fwd_qb", 1 | 2): query blocks per wave of the first forward structure
 int g_attn_fwd_wps = 2;  // mh_set_option("attn_fwd_wps", 2 | 3): register budget of the second forward structure (A/B runs)
 
 constexpr int HD = 64;
@@ -237,6 +238,153 @@ __global__ __launch_bounds__(256, 3) void attn_fwd_kernel(const bf16* __restrict
         *reinterpret_cast<bf16x8*>(orow + db * 32 + 16 * r8 + 8 * hi) = v;
       }
     if (hi == 0) lse[bh * Sp + qrow] = (m + log2f(lt)) * 0.6931471805599453f;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// forward, two query blocks per wave (r02): the first structure with every K / V^T fragment feeding TWO independent
+// 32-row query blocks -- half the LDS fragment reads per MFMA, a 256-row workgroup (half the K/V staging per query row),
+// and two independent softmax / MFMA streams in one basic block for the scheduler to interleave.
+// ---------------------------------------------------------------------------------------------------
+template <bool MASK>
+__device__ inline void fwdq2_tile(const char* tK, const char* tV, const bf16x8 (&qf)[2][4], f32x16 (&oacc)[2][2],
+                                  float (&m)[2], float (&l)[2], int pli, int hi, const int (&qrel)[2], bool act0, float sc) {
+  f32x16 sacc[2][2] = {{zero16(), zero16()}, {zero16(), zero16()}};
+#pragma unroll
+  for (int s = 0; s < 4; ++s)
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb) {
+      const bf16x8 kf = lds_frag(tK, kb * 32 + pli, 2 * s + hi);
+      sacc[1][kb] = mfma32(kf, qf[1][s], sacc[1][kb]);
+      if (act0) sacc[0][kb] = mfma32(kf, qf[0][s], sacc[0][kb]);
+    }
+  float alpha[2] = {1.f, 1.f};
+#pragma unroll
+  for (int qb = 0; qb < 2; ++qb) {
+    if (qb == 0 && !act0) continue;  // (wave-uniform: the earlier block has no unmasked key in this tile)
+    float mx = -INFINITY;
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        if (MASK) {
+          if (kb * 32 + reg_index(r, hi) > qrel[qb]) sacc[qb][kb][r] = -INFINITY;
+        }
+        mx = fmaxf(mx, sacc[qb][kb][r]);
+      }
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64)) * sc;
+    float mn = m[qb];
+    if (__any(mx > m[qb] + RESCALE_THR)) {  // (see fwd_tile)
+      mn = fmaxf(m[qb], mx);
+      alpha[qb] = fast_exp2(m[qb] - mn);
+#pragma unroll
+      for (int db = 0; db < 2; ++db)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) oacc[qb][db][r] *= alpha[qb];
+    }
+    float psum = 0.f;
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const float p = fast_exp2(__builtin_fmaf(sacc[qb][kb][r], sc, -mn));
+        sacc[qb][kb][r] = p;
+        psum += p;
+      }
+    l[qb] = l[qb] * alpha[qb] + psum;
+    m[qb] = mn;
+  }
+#pragma unroll
+  for (int t = 0; t < 4; ++t) {
+    const bf16x8 pf1 = pack8(sacc[1][t >> 1], 8 * (t & 1));
+    const bf16x8 pf0 = pack8(sacc[0][t >> 1], 8 * (t & 1));
+#pragma unroll
+    for (int db = 0; db < 2; ++db) {
+      const bf16x8 vf = lds_frag(tV, db * 32 + pli, 2 * t + hi);
+      oacc[1][db] = mfma32(vf, pf1, oacc[1][db]);
+      if (act0) oacc[0][db] = mfma32(vf, pf0, oacc[0][db]);
+    }
+  }
+}
+
+template <int WPS>
+__global__ __launch_bounds__(256, WPS) void attn_fwdq2_kernel(const bf16* __restrict__ qkv, const bf16* __restrict__ vt,
+                                                           bf16* __restrict__ o, float* __restrict__ lse, int S, int Sp, int H,
+                                                           float sc /* scale*log2(e) */, int BH, int nqt) {
+  __shared__ __attribute__((aligned(16))) char smem[4 * TILE64];  // [stage][K | V^T]
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  int bh_, tile_;
+  if (!attn_work(BH, nqt, bh_, tile_)) return;
+  const int64_t bh = bh_;
+  const int64_t b = bh / H;
+  const int h = (int)(bh - b * H);
+  const int64_t D = (int64_t)H * HD, D3 = 3 * D;
+  const int q0 = (nqt - 1 - tile_) * 256;  // heavy (late) query tiles first
+  const int li = lane & 31, hi = lane >> 5;
+  int qw0[2], qrow[2];
+#pragma unroll
+  for (int qb = 0; qb < 2; ++qb) {
+    qw0[qb] = q0 + wave * 64 + qb * 32;
+    qrow[qb] = qw0[qb] + li;
+  }
+  const bf16* kbase = qkv + b * S * D3 + D + (int64_t)h * HD;
+  const bf16* vtbase = vt + bh * HD * Sp;
+
+  bf16x8 qf[2][4];
+#pragma unroll
+  for (int qb = 0; qb < 2; ++qb) {
+    const int qld = (qrow[qb] < S) ? qrow[qb] : S - 1;
+    const bf16* qp = qkv + (b * S + qld) * D3 + (int64_t)h * HD + 8 * hi;
+#pragma unroll
+    for (int s = 0; s < 4; ++s) qf[qb][s] = *reinterpret_cast<const bf16x8*>(qp + 16 * s);
+  }
+  f32x16 oacc[2][2] = {{zero16(), zero16()}, {zero16(), zero16()}};
+  float m[2] = {-INFINITY, -INFINITY}, l[2] = {0.f, 0.f};
+
+  int last_q = q0 + 255;
+  if (last_q > S - 1) last_q = S - 1;
+  const int kt_last = last_q / 64;
+  const int pli = pi32(li);
+
+  stage64(kbase, D3, 0, S - 1, 0, smem, wave, lane);
+  stage64(vtbase, Sp, 0, HD - 1, 0, smem + TILE64, wave, lane);
+  __syncthreads();
+  for (int kt = 0; kt <= kt_last; ++kt) {
+    const char* cur = smem + (kt & 1) * 2 * TILE64;
+    char* nxt = smem + ((kt + 1) & 1) * 2 * TILE64;
+    if (kt + 1 <= kt_last) {
+      stage64(kbase, D3, (int64_t)(kt + 1) * 64, S - 1, 0, nxt, wave, lane);
+      stage64(vtbase, Sp, 0, HD - 1, (int64_t)(kt + 1) * 64, nxt + TILE64, wave, lane);
+    }
+    const int k0 = kt * 64;
+    if (k0 <= qw0[1] + 31) {  // wave-uniform: the later block still has unmasked keys in the tile
+      const bool act0 = k0 <= qw0[0] + 31;
+      const int qrel[2] = {qrow[0] - k0, qrow[1] - k0};
+      if (k0 + 63 > qw0[0])   // wave-uniform: the tile crosses the diagonal of one of the two blocks
+        fwdq2_tile<true>(cur, cur + TILE64, qf, oacc, m, l, pli, hi, qrel, act0, sc);
+      else
+        fwdq2_tile<false>(cur, cur + TILE64, qf, oacc, m, l, pli, hi, qrel, true, sc);
+    }
+    __syncthreads();
+  }
+#pragma unroll
+  for (int qb = 0; qb < 2; ++qb) {
+    const float lt = l[qb] + __shfl_xor(l[qb], 32, 64);
+    if (qrow[qb] < S) {
+      const float inv = 1.f / lt;
+      bf16* orow = o + (b * S + qrow[qb]) * D + (int64_t)h * HD;
+#pragma unroll
+      for (int db = 0; db < 2; ++db)
+#pragma unroll
+        for (int r8 = 0; r8 < 2; ++r8) {
+          bf16x8 v;
+#pragma unroll
+          for (int e = 0; e < 8; ++e) v[e] = (bf16)(oacc[qb][db][8 * r8 + e] * inv);
+          *reinterpret_cast<bf16x8*>(orow + db * 32 + 16 * r8 + 8 * hi) = v;
+        }
+      if (hi == 0) lse[bh * Sp + qrow[qb]] = (m[qb] + log2f(lt)) * 0.6931471805599453f;
+    }
   }
 }
 
@@ -701,6 +849,16 @@ int mh_attn_fwd_mfma(const void* qkv, const void* vt, void* o, float* lse, int64
   const int64_t Sp = (S + 63) / 64 * 64;
   const int nt = (int)((S + 127) / 128), BH = (int)(B * H);
   const unsigned grid = (unsigned)(nt * 8 * ((BH + 7) / 8));
+  if (vt != nullptr && g_attn_fwd_qb == 2) {  // two query blocks per wave (256-row workgroups)
+    const int nt2 = (int)((S + 255) / 256);
+    const unsigned g2 = (unsigned)(nt2 * 8 * ((BH + 7) / 8));
+    if (g_attn_fwd_wps == 1)
+      attn_fwdq2_kernel<1><<<g2, 256, 0, st>>>((const bf16*)qkv, (const bf16*)vt, (bf16*)o, lse, (int)S, (int)Sp, H, scale * LOG2E, BH, nt2);
+    else
+      attn_fwdq2_kernel<2><<<g2, 256, 0, st>>>((const bf16*)qkv, (const bf16*)vt, (bf16*)o, lse, (int)S, (int)Sp, H, scale * LOG2E, BH, nt2);
+    MH_LAUNCH_CHECK();
+    return MH_OK;
+  }
   if (vt == nullptr) {  // second structure: V read row-major through transpose reads, no prepared copy
     if (g_attn_fwd_wps == 3)
       attn_fwd2_kernel<3><<<grid, 256, 3 * 2 * TILE64, st>>>((const bf16*)qkv, (bf16*)o, lse, (int)S, (int)Sp, H, scale * LOG2E, BH, nt);

@@ -325,6 +325,8 @@ def attn_fwd(qkv, o, lse, B: int, S: int, H: int, scale: float):
         _attn_wps_set = True
         if "MH_ATTN_FWD_WPS" in os.environ:
             set_option("attn_fwd_wps", int(os.environ["MH_ATTN_FWD_WPS"]))
+        if "MH_ATTN_FWD_QB" in os.environ:
+            set_option("attn_fwd_qb", int(os.environ["MH_ATTN_FWD_QB"]))
     vt = None
     if qkv.dtype == torch.bfloat16 and ATTN_FWD_FORM == 1:
         Sp = round_up(S, 64)

@@ -281,15 +281,17 @@ def test_rope(ops, dtype, H, hd, S, M):
 
 
 # ------------------------------------------------------------------------------ event-level attention
-@pytest.mark.parametrize("form", [2, 1], ids=["fwd2_trV_ring3", "fwd1_preparedVT"])
+@pytest.mark.parametrize("form", [2, 1, 12, 11], ids=["fwd2_trV_ring3", "fwd1_preparedVT", "fwd1_two_qblocks_2wps", "fwd1_two_qblocks_1wps"])
 @pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("B,S,H", [(1, 1, 1), (2, 33, 3), (1, 64, 2), (2, 128, 1), (1, 200, 4), (1, 515, 2), (1, 129, 1), (2, 321, 2)])
 def test_attention_fwd_bwd(ops, monkeypatch, form, dtype, B, S, H):
     """(bf16: both forward structures -- the transpose-read / three-stage-ring kernel and the first one with its prepared
     V^T copy; fp32 runs the plain verification kernel either way)"""
-    if dtype == torch.float32 and form == 1:
+    if dtype == torch.float32 and form != 2:
         pytest.skip("fp32 has one forward kernel")
-    monkeypatch.setattr(ops, "ATTN_FWD_FORM", form)
+    monkeypatch.setattr(ops, "ATTN_FWD_FORM", 1 if form >= 10 else form)
+    ops.set_option("attn_fwd_qb", 2 if form >= 10 else 1)
+    ops.set_option("attn_fwd_wps", form - 10 if form >= 10 else 2)
     D = H * 64
     scale = 64 ** -0.5
     qkv = rnd((B * S, 3 * D), dtype, 18)
@@ -317,6 +319,8 @@ def test_attention_fwd_bwd(ops, monkeypatch, form, dtype, B, S, H):
     cmp(got, want.cpu(), dtype, k=2, what="attn bwd + rotation back")
     same = (got == want).float().mean().item()
     assert same > 0.99, f"fused rotation agrees with the separate pass on only {same:.4f} of the elements"
+    ops.set_option("attn_fwd_qb", 1)
+    ops.set_option("attn_fwd_wps", 2)
 
 
 def test_attention_mfma_vs_plain_on_device(ops):
