@@ -39,6 +39,8 @@ from .engine import KVState, RopeTable
 # One capture at a time per process, and in thread-local error mode: generators of other threads (app.py runs up to 10 on
 # one model) keep launching and allocating while a new session is being captured.
 _CAPTURE_LOCK = threading.Lock()
+_NOISE_INLINE = os.environ.get("MH_DECODE_NOISE_INLINE", "0") == "1"
+_COPY_PAGEABLE = os.environ.get("MH_DECODE_COPY_PAGEABLE", "0") == "1"
 
 
 def graphs_enabled(device: torch.device) -> bool:
@@ -303,14 +305,20 @@ class DecodeSession:
             return
         # the token steps that read the previous draws must be done first: the event recorded right behind the steps graph
         # when there is one (NOT the whole stream: the net step queued after it is what the draws should overlap)
-        if self._steps_recorded:
+        if _NOISE_INLINE:
+            pass
+        elif self._steps_recorded:
             self.noise_stream.wait_event(self.steps_done)
         else:
             self.noise_stream.wait_stream(torch.cuda.current_stream())
         self.gen.set_offset(self._off)
-        with torch.cuda.stream(self.noise_stream):
+        if _NOISE_INLINE:  # (A/B: the draws on the caller's stream, no cross-stream dependency)
             self.g_noise.replay()
-            self.noise_done.record(self.noise_stream)
+            self.noise_done.record(torch.cuda.current_stream())
+        else:
+            with torch.cuda.stream(self.noise_stream):
+                self.g_noise.replay()
+                self.noise_done.record(self.noise_stream)
         self._noise_pending = True
 
     def consumed(self, n_steps: int) -> None:
@@ -346,11 +354,17 @@ class DecodeSession:
             self._steps_recorded = True
             if then_net:
                 self.net_step()
-            self.copy_stream.wait_event(self.steps_done)
-            with torch.cuda.stream(self.copy_stream):
-                self.seq_host.copy_(self.seq, non_blocking=True)
-            self.copy_stream.synchronize()  # the one host sync per event
-            event = self.seq_host.numpy().copy()
+                self.copy_stream.wait_event(self.steps_done)
+                with torch.cuda.stream(self.copy_stream):
+                    if _COPY_PAGEABLE:  # (A/B: a blocking pageable copy on the copy stream instead of pinned + stream sync)
+                        event = self.seq.cpu().numpy().copy()
+                    else:
+                        self.seq_host.copy_(self.seq, non_blocking=True)
+                if not _COPY_PAGEABLE:
+                    self.copy_stream.synchronize()  # the one host sync per event
+                    event = self.seq_host.numpy().copy()
+            else:
+                event = self.seq.cpu().numpy().copy()  # the one host sync per event
             n, end_all = self.n_steps_of(event[:, 0].tolist())
             self.consumed(n)
             return event, end_all

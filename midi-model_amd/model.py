@@ -26,6 +26,13 @@ from .config import MIDIModelConfig, NetConfig
 from .engine import KVState, LayerTensors, RopeTable, StackSpec, StackTensors
 
 
+# MH_DECODE_SPEC=1: queue the net step of an event BEFORE the host has read its tokens (decode.DecodeSession.sample_event,
+# tokens through a copy stream).  Measured slower on the MI355X, same box, interleaved (r02, tools/gpu_r2_13.sh): 1.86 ms per
+# event against 1.70 with the plain order (token steps -> host copy -> noise graph + net step), pinned or pageable copy
+# alike -- the host's ~40 us round trip is cheaper than what the extra queue traffic costs the dependent chain.  Off.
+_SPECULATIVE_NET = os.environ.get("MH_DECODE_SPEC", "0") == "1"
+
+
 class _SessionPool:
     """Idle decode sessions of one model (buffers + captured graphs).  Copies and pickles of the model start empty."""
 
@@ -478,7 +485,7 @@ class MIDIModel(nn.Module):
             while cur_len < max_len:
                 with torch.inference_mode():
                     more = cur_len + 1 < max_len
-                    speculative = more and ses.g_steps is not None
+                    speculative = more and ses.g_steps is not None and _SPECULATIVE_NET
                     # the event's 8 token steps (one replayed graph, one host copy); in the graph form the net step over
                     # the event is queued behind them before the host waits
                     event, end_all = ses.sample_event(then_net=speculative)
