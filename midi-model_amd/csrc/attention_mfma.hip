@@ -29,6 +29,7 @@ int g_attn_fwd_wps = 2;  // mh_set_option("attn_fwd_wps", 2 | 3): register budge
 
 constexpr int HD = 64;
 constexpr int TILE64 = 64 * 128;  // bytes
+constexpr int DKV_STAGE = 4 * TILE64 + 2048;  // bytes of one stage of the dK/dV kernel (4 tiles + 1 KiB lse + 1 KiB delta)
 constexpr float LOG2E = 1.4426950408889634f;
 constexpr float RESCALE_THR = 4.0f;  // a row's reference max may lag its true max by a factor <= 2^4
 
@@ -173,7 +174,10 @@ __device__ inline void fwd_tile(const char* tK, const char* tV, const bf16x8 (&q
 __global__ __launch_bounds__(256, 3) void attn_fwd_kernel(const bf16* __restrict__ qkv, const bf16* __restrict__ vt,
                                                        bf16* __restrict__ o, float* __restrict__ lse, int S, int Sp, int H,
                                                        float sc /* scale*log2(e) */, int BH, int nqt) {
-  __shared__ __attribute__((aligned(16))) char smem[4 * TILE64];  // [stage][K | V^T]
+  // dynamic LDS, 4 tiles = [stage][K | V^T] (r02: with a static array hipcc's LDS-DMA alias tracking waits vmcnt(0) before
+  // the first fragment read of a tile, i.e. for the NEXT tile's stage requested just above it -- the double buffer then
+  // hides nothing; the barrier at the end of the iteration is where that stage has to have landed)
+  extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   int bh_, tile_;
@@ -207,6 +211,8 @@ __global__ __launch_bounds__(256, 3) void attn_fwd_kernel(const bf16* __restrict
 
   stage64(kbase, D3, 0, S - 1, 0, smem, wave, lane);
   stage64(vtbase, Sp, 0, HD - 1, 0, smem + TILE64, wave, lane);
+#pragma unroll
+  for (int s = 0; s < 4; ++s) asm volatile("" : "+v"(qf[s]));  // (see attn_bwd_dkv_kernel)
   __syncthreads();
   for (int kt = 0; kt <= kt_last; ++kt) {
     const char* cur = smem + (kt & 1) * 2 * TILE64;
@@ -647,7 +653,7 @@ __global__ __launch_bounds__(256, 3) void attn_bwd_dq_kernel(const bf16* __restr
                                                              int Sp, int H, float scale, int BH, int nqt,
                                                              const float* __restrict__ cos_t,
                                                              const float* __restrict__ sin_t) {
-  __shared__ __attribute__((aligned(16))) char smem[6 * TILE64];  // [stage][K | V | K^T]
+  extern __shared__ __attribute__((aligned(16))) char smem[];  // 6 tiles: [stage][K | V | K^T] (dynamic: see attn_fwd_kernel)
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   int bh_, tile_;
@@ -689,6 +695,11 @@ __global__ __launch_bounds__(256, 3) void attn_bwd_dq_kernel(const bf16* __restr
   stage64(kbase, D3, 0, S - 1, 0, smem, wave, lane);
   stage64(vbase, D3, 0, S - 1, 0, smem + TILE64, wave, lane);
   stage64(ktbase, Sp, 0, HD - 1, 0, smem + 2 * TILE64, wave, lane);
+#pragma unroll
+  for (int s = 0; s < 4; ++s) {  // (see attn_bwd_dkv_kernel)
+    asm volatile("" : "+v"(qf[s]));
+    asm volatile("" : "+v"(dof[s]));
+  }
   __syncthreads();
   for (int kt = 0; kt <= kt_last; ++kt) {
     const char* cur = smem + (kt & 1) * 3 * TILE64;
@@ -720,8 +731,8 @@ __global__ __launch_bounds__(256, 3) void attn_bwd_dq_kernel(const bf16* __restr
 // valid queries in the tile (S - q0, may exceed 64).
 template <bool MASK>
 __device__ inline void dkv_tile(const char* tQ, const char* tDO, const char* tQT, const char* tDOT, const bf16x8 (&kf)[4],
-                                const bf16x8 (&vf)[4], f32x16 (&dkacc)[2], f32x16 (&dvacc)[2], const float* __restrict__ lse_t,
-                                const float* __restrict__ delta_t, int pli, int hi, int krel, int qlim, float sc) {
+                                const bf16x8 (&vf)[4], f32x16 (&dkacc)[2], f32x16 (&dvacc)[2], const char* tLD, int pli, int hi,
+                                int krel, int qlim, float sc) {
 #pragma unroll
   for (int qb = 0; qb < 2; ++qb) {
     f32x16 sacc = zero16(), pacc = zero16();
@@ -730,15 +741,17 @@ __device__ inline void dkv_tile(const char* tQ, const char* tDO, const char* tQT
       sacc = mfma32(lds_frag(tQ, qb * 32 + pli, 2 * s + hi), kf[s], sacc);
       pacc = mfma32(lds_frag(tDO, qb * 32 + pli, 2 * s + hi), vf[s], pacc);
     }
-    // lse/delta are [B,H,Sp]: the two runs of 8 queries this lane-half owns are aligned 16-byte loads; entries
-    // past S are never-written padding and are discarded by the MASK select (the last tile is always MASK).
+    // lse / delta of the tile's 64 queries come from the stage (256 B each, staged with the tile by one LDS-DMA): read
+    // straight from global memory here (r01) they were 16 ordinary loads per tile whose L2 round trips sat between the
+    // S / dP MFMAs and the dS arithmetic of every query block, and -- ordinary loads beside LDS-DMA -- made hipcc drain the
+    // stage in flight.  Entries past S are never-written padding, discarded by the MASK select (the last tile is MASK).
 #pragma unroll
     for (int t = 0; t < 2; ++t) {
       const int qq = qb * 32 + 16 * t + 8 * hi;
 #pragma unroll
       for (int v4 = 0; v4 < 2; ++v4) {
-        const f32x4 a = *reinterpret_cast<const f32x4*>(lse_t + qq + 4 * v4);
-        const f32x4 d4 = *reinterpret_cast<const f32x4*>(delta_t + qq + 4 * v4);
+        const f32x4 a = *reinterpret_cast<const f32x4*>(tLD + (qq + 4 * v4) * 4);
+        const f32x4 d4 = *reinterpret_cast<const f32x4*>(tLD + 1024 + (qq + 4 * v4) * 4);
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
           const int r = 8 * t + 4 * v4 + e;
@@ -773,7 +786,8 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const bf16* __rest
                                                               bf16* __restrict__ dqkv, int S, int Sp, int H, float scale,
                                                               int BH, int nkt, const float* __restrict__ cos_t,
                                                               const float* __restrict__ sin_t) {
-  __shared__ __attribute__((aligned(16))) char smem[8 * TILE64];  // [stage][Q | dO | Q^T | dO^T]
+  constexpr int STG = DKV_STAGE;  // [Q | dO | Q^T | dO^T | lse (256 B of a KiB) | delta (256 B of a KiB)]
+  extern __shared__ __attribute__((aligned(16))) char smem[];  // 2 stages (dynamic: see attn_fwd_kernel)
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   int bh_, tile_;
@@ -814,24 +828,39 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const bf16* __rest
     stage64(dobase, D, (int64_t)qt * 64, S - 1, 0, dst + TILE64, wave, lane);
     stage64(qtbase, Sp, 0, HD - 1, (int64_t)qt * 64, dst + 2 * TILE64, wave, lane);
     stage64(dotbase, Sp, 0, HD - 1, (int64_t)qt * 64, dst + 3 * TILE64, wave, lane);
+    if (wave < 2) {  // wave 0: lse[qt*64 ..], wave 1: delta[..]: lanes 0-15 carry the 256 B, the others repeat them (the
+      // LDS-DMA writes a full KiB per wave); a wave-uniform base + a lane offset recomputed here keeps no address register
+      // alive across the tile loop (a per-lane pointer select was spilled and reloaded behind a vmcnt(0))
+      const float* base = (wave == 0 ? lse_b : delta_b) + (int64_t)qt * 64;
+      int l15 = lane & 15;
+      asm volatile("" : "+v"(l15));  // (not loop-invariant for hipcc: the address is rebuilt here, nothing stays live)
+      glds16(base + 4 * l15, dst + 4 * TILE64 + wave * 1024);
+    }
   };
   if (qt_first <= qt_last) stage_all(qt_first, smem);
+  // (register-resident operands through an empty asm: left pending, hipcc would wait vmcnt(0) at their first use inside the
+  // loop on every tile, draining the stage in flight -- see attn_fwd2_kernel)
+#pragma unroll
+  for (int s = 0; s < 4; ++s) {
+    asm volatile("" : "+v"(kf[s]));
+    asm volatile("" : "+v"(vf[s]));
+  }
   __syncthreads();
   for (int qt = qt_first; qt <= qt_last; ++qt) {
     const int st = (qt - qt_first) & 1;
-    const char* cur = smem + st * 4 * TILE64;
-    char* nxt = smem + (st ^ 1) * 4 * TILE64;
+    const char* cur = smem + st * STG;
+    char* nxt = smem + (st ^ 1) * STG;
     if (qt + 1 <= qt_last) stage_all(qt + 1, nxt);
     const int qs = qt * 64;
     if (qs + 63 >= kw0) {  // wave-uniform: some query of this tile sees this wave's keys
       // the causal mask matters when the tile's first query is below the wave's last key; the ragged tail
       // (queries past S) only exists in the last tile
       if (qs < kw0 + 31 || qs + 64 > S)
-        dkv_tile<true>(cur, cur + TILE64, cur + 2 * TILE64, cur + 3 * TILE64, kf, vf, dkacc, dvacc, lse_b + qs,
-                       delta_b + qs, pli, hi, krow - qs, S - qs, sc);
+        dkv_tile<true>(cur, cur + TILE64, cur + 2 * TILE64, cur + 3 * TILE64, kf, vf, dkacc, dvacc, cur + 4 * TILE64, pli, hi,
+                       krow - qs, S - qs, sc);
       else
-        dkv_tile<false>(cur, cur + TILE64, cur + 2 * TILE64, cur + 3 * TILE64, kf, vf, dkacc, dvacc, lse_b + qs,
-                        delta_b + qs, pli, hi, 0, 64, sc);
+        dkv_tile<false>(cur, cur + TILE64, cur + 2 * TILE64, cur + 3 * TILE64, kf, vf, dkacc, dvacc, cur + 4 * TILE64, pli, hi,
+                        0, 64, sc);
     }
     __syncthreads();
   }
@@ -867,7 +896,7 @@ int mh_attn_fwd_mfma(const void* qkv, const void* vt, void* o, float* lse, int64
     MH_LAUNCH_CHECK();
     return MH_OK;
   }
-  attn_fwd_kernel<<<grid, 256, 0, st>>>((const bf16*)qkv, (const bf16*)vt, (bf16*)o, lse, (int)S, (int)Sp, H,
+  attn_fwd_kernel<<<grid, 256, 4 * TILE64, st>>>((const bf16*)qkv, (const bf16*)vt, (bf16*)o, lse, (int)S, (int)Sp, H,
                                         scale * LOG2E, BH, nt);
   MH_LAUNCH_CHECK();
   return MH_OK;
@@ -881,10 +910,10 @@ int mh_attn_bwd_mfma(const void* qkv, const void* dout, const float* lse, const 
   const int64_t Sp = (S + 63) / 64 * 64;
   const int nt = (int)((S + 127) / 128), BH = (int)(B * H);
   const unsigned grid = (unsigned)(nt * 8 * ((BH + 7) / 8));
-  attn_bwd_dq_kernel<<<grid, 256, 0, st>>>((const bf16*)qkv, (const bf16*)dout, lse, delta, (const bf16*)kt,
+  attn_bwd_dq_kernel<<<grid, 256, 6 * TILE64, st>>>((const bf16*)qkv, (const bf16*)dout, lse, delta, (const bf16*)kt,
                                            (bf16*)dqkv, (int)S, (int)Sp, H, scale, BH, nt, cos_t, sin_t);
   MH_LAUNCH_CHECK();
-  attn_bwd_dkv_kernel<<<grid, 256, 0, st>>>((const bf16*)qkv, (const bf16*)dout, lse, delta, (const bf16*)qt,
+  attn_bwd_dkv_kernel<<<grid, 256, 2 * DKV_STAGE, st>>>((const bf16*)qkv, (const bf16*)dout, lse, delta, (const bf16*)qt,
                                             (const bf16*)dot, (bf16*)dqkv, (int)S, (int)Sp, H, scale, BH, nt, cos_t, sin_t);
   MH_LAUNCH_CHECK();
   return MH_OK;
