@@ -425,6 +425,10 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(const T* __restrict__ 
                                                           int64_t Lmax, int64_t len, float scale,
                                                           const int32_t* __restrict__ pos_dev,
                                                           const float* __restrict__ cos_t, const float* __restrict__ sin_t) {
+  // every kernel argument fetched at entry in one batch (hipcc sinks each s_load into the block that first uses it otherwise:
+  // a scalar-cache miss + wait per block on a kernel whose whole run is a few microseconds)
+  asm volatile("" ::"s"(qkv), "s"(kc), "s"(vc), "s"(o), "s"(H), "s"(Lmax), "s"(len), "s"(scale));
+  asm volatile("" ::"s"(pos_dev), "s"(cos_t), "s"(sin_t));
   if (pos_dev != nullptr) len = (int64_t)*pos_dev + 1;  // graph replay: attend to rows [0, pos]
   if (len > Lmax) len = Lmax;
   constexpr int N = Pack<T>::N;
@@ -477,17 +481,22 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(const T* __restrict__ 
   // four steps of the key loop at a time with all K / V rows requested first: one step per memory round trip was one
   // round trip per 32 keys of head_dim 64 (13 us per layer at 128 cached events, r02 trace)
   constexpr int UNR = 4;
-  for (int64_t j0 = (int64_t)wv * KPW; j0 < len; j0 += 4 * KPW * UNR) {
+  const int ilen = (int)len;                 // (<= Lmax < 2^24: 32-bit key indices and element offsets from the uniform bases)
+  const int lane_off = ch * N;
+  for (int j0 = wv * KPW; j0 < ilen; j0 += 4 * KPW * UNR) {
     Pack<T> kv[UNR], vv[UNR];
     bool ok[UNR];
 #pragma unroll
     for (int u = 0; u < UNR; ++u) {
-      const int64_t j = j0 + (int64_t)u * 4 * KPW + grp;
-      ok[u] = j < len;
-      const int64_t jj = ok[u] ? j : 0;
-      kv[u] = ld16(kb + jj * HD + ch * N);
-      vv[u] = ld16(vb + jj * HD + ch * N);
+      const int j = j0 + u * 4 * KPW + grp;
+      ok[u] = j < ilen;
+      const unsigned off = (unsigned)((ok[u] ? j : 0) * HD + lane_off);
+      kv[u] = ld16(kb + off);
+      vv[u] = ld16(vb + off);
     }
+    // all 2 UNR row loads are requested before the first dot product: without this fence hipcc started the arithmetic of
+    // the first row right behind its load and waited vmcnt(0) for it BEFORE issuing the other seven (r02 ISA)
+    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int u = 0; u < UNR; ++u) {
       float s = 0.f;

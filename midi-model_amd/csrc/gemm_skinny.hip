@@ -35,7 +35,14 @@ namespace {
 // workgroup -- blockIdx.y picks the group of MB row blocks, so MB = 1 puts a 64-row step on 4x the workgroups, each reading a
 // quarter of the activation rows (the four workgroups of a column block get consecutive blockIdx.x-major ids b, b + gridDim.x,
 // ... : on the same XCD when gridDim.x is a multiple of 8, so the weight slab they share is fetched from HBM once).
-template <int MODE, int NBT, int NW, bool RSTD, int MB>
+// BCH: chunks per wave that are requested in ONE batch (the host picks the largest of 8 / 4 / 2 / 1 dividing the wave's
+// chunk count).  r02 ISA of the first form: the chunk loop was rolled -- load W, load X, s_waitcnt vmcnt(0), MFMA, branch --
+// i.e. one memory round trip per 32-deep chunk and wave (4 in a row at K = 1024); the kernel arguments were fetched by six
+// separate s_load + wait pairs sunk into the blocks that use them; and the residual "prefetch" was converted to fp32 at once,
+// which put its wait at the top of the kernel.  Now: every argument is touched at entry (one batch of scalar loads), the
+// residual stays raw until the epilogue, and a batch's BCH x (NBT + MB) fragment loads are all requested before a
+// sched_barrier, behind which the MFMAs run.
+template <int MODE, int NBT, int NW, bool RSTD, int MB, int BCH>
 __global__ __launch_bounds__(NW * 64) void gemm_skinny_kernel(const bf16* __restrict__ A, int64_t lda,
                                                           const bf16* __restrict__ W, int64_t ldw, bf16* __restrict__ C,
                                                           int64_t ldc, const bf16* __restrict__ R, int64_t ldr, int M, int N,
@@ -45,19 +52,37 @@ __global__ __launch_bounds__(NW * 64) void gemm_skinny_kernel(const bf16* __rest
   constexpr int MR = MB * 16;  // rows of this workgroup
   __shared__ float red[NW][MR][NB + 1];
   __shared__ float ssq[RSTD ? NW : 1][MR];
+  // all kernel arguments in one batch of scalar loads at entry (hipcc otherwise sinks each s_load into the block that first
+  // uses it: a scalar-cache miss and a wait per block)
+  asm volatile("" ::"s"(A), "s"(lda), "s"(W), "s"(ldw), "s"(C), "s"(ldc), "s"(R), "s"(ldr));
+  asm volatile("" ::"s"(M), "s"(N), "s"(K), "s"(norm_eps), "s"(row_ids), "s"(res_ids));
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int fi = lane & 15, fg = lane >> 4;
-  const int nc_w = K / (32 * NW);  // chunks of 32 per wave (wave w takes chunks w, w+NW, ...)
+  const int nc_w = K / (32 * NW);  // chunks of 32 per wave (wave w takes chunks w, w+NW, ...); a multiple of BCH
   const int m0 = blockIdx.y * MR;
+
+  // indirections first (their results are addresses): A rows / residual row through the id tables
+  int64_t arow_i[MB];
+#pragma unroll
+  for (int mb = 0; mb < MB; ++mb) {
+    const int m = m0 + mb * 16 + fi;
+    arow_i[mb] = (m < M) ? m : M - 1;
+  }
+  constexpr int CPT = (MODE == 1) ? 4 : NB / 4;  // output columns per writing thread (four threads per row)
+  const int ml = threadIdx.x >> 2;               // row within the workgroup (threads < MR * 4 write)
+  const int cw0 = (threadIdx.x & 3) * CPT;
+  const bool writer = threadIdx.x < MR * 4 && m0 + ml < M;
+  int64_t rrow_i = writer ? m0 + ml : 0;
+  if (row_ids != nullptr) {  // (uniform)
+#pragma unroll
+    for (int mb = 0; mb < MB; ++mb) arow_i[mb] = row_ids[arow_i[mb]];
+  }
+  if (MODE == 0 && res_ids != nullptr) rrow_i = res_ids[rrow_i];
 
   const bf16* arow[MB];
   const bf16* wrow[NBT];
 #pragma unroll
-  for (int mb = 0; mb < MB; ++mb) {
-    const int m = m0 + mb * 16 + fi;
-    const int64_t mr = (m < M) ? m : M - 1;
-    arow[mb] = A + (row_ids != nullptr ? row_ids[mr] : mr) * lda + fg * 8;  // row_ids: A rows gathered from a table
-  }
+  for (int mb = 0; mb < MB; ++mb) arow[mb] = A + arow_i[mb] * lda + fg * 8;  // row_ids: A rows gathered from a table
 #pragma unroll
   for (int nb = 0; nb < NBT; ++nb) {
     int n, nmax;
@@ -71,31 +96,17 @@ __global__ __launch_bounds__(NW * 64) void gemm_skinny_kernel(const bf16* __rest
     wrow[nb] = W + (int64_t)(n < nmax ? n : nmax) * ldw + fg * 8;
   }
 
-  // The residual lines are requested before anything else: read after the reduction they would put a second memory round
-  // trip (~0.5 us of the ~2.7 us a launch spends in the kernel, tools/skinny_probe.hip) on the critical path.
-  constexpr int CPT = (MODE == 1) ? 4 : NB / 4;  // output columns per writing thread (four threads per row)
-  const int ml = threadIdx.x >> 2;               // row within the workgroup (threads < MR * 4 write)
-  const int cw0 = (threadIdx.x & 3) * CPT;
-  float rpre[CPT];
+  // The residual values are REQUESTED here and left raw (no conversion = no wait) until the epilogue: read after the
+  // reduction they would put a second memory round trip on the critical path (tools/skinny_probe.hip).
+  // UNCONDITIONAL (every thread, clamped address, the weight matrix standing in when there is no residual): a load inside a
+  // branch is waited for where the branch ends.
+  bf16 rraw[CPT];
+  const bool res_full = blockIdx.x * NB + cw0 + CPT <= N;  // the whole group is inside the row (always, but for a ragged last block)
+  {
+    const bool use_r = MODE == 0 && R != nullptr;
+    const bf16* rsrc = use_r ? R + rrow_i * ldr + (res_full ? blockIdx.x * NB + cw0 : 0) : W;
 #pragma unroll
-  for (int j = 0; j < CPT; ++j) rpre[j] = 0.f;
-  if constexpr (MODE == 0) {
-    if (R != nullptr && threadIdx.x < MR * 4 && m0 + ml < M) {
-      const int m = m0 + ml;
-      const int64_t rr = res_ids != nullptr ? res_ids[m] : (int64_t)m;
-      const bf16* rrow = R + rr * ldr + blockIdx.x * NB + cw0;
-      if (blockIdx.x * NB + cw0 + CPT <= N) {  // the whole group is inside the row (always, but for a ragged last block)
-        bf16 rv[CPT];
-#pragma unroll
-        for (int j = 0; j < CPT; ++j) rv[j] = rrow[j];  // unconditional: one batch of loads, no per-element branch + wait
-#pragma unroll
-        for (int j = 0; j < CPT; ++j) rpre[j] = (float)rv[j];
-      } else {
-#pragma unroll
-        for (int j = 0; j < CPT; ++j)
-          if (blockIdx.x * NB + cw0 + j < N) rpre[j] = (float)rrow[j];
-      }
-    }
+    for (int j = 0; j < CPT; ++j) rraw[j] = rsrc[j];
   }
 
   f32x4 acc[MB][NBT];
@@ -107,25 +118,31 @@ __global__ __launch_bounds__(NW * 64) void gemm_skinny_kernel(const bf16* __rest
   float ss[MB];
 #pragma unroll
   for (int mb = 0; mb < MB; ++mb) ss[mb] = 0.f;
-#pragma unroll 8
-  for (int ci = 0; ci < nc_w; ++ci) {
-    const int k = (wave + NW * ci) * 32;
-    bf16x8 wf[NBT], xf[MB];
+  for (int c0 = 0; c0 < nc_w; c0 += BCH) {
+    bf16x8 wf[BCH][NBT], xf[BCH][MB];
 #pragma unroll
-    for (int nb = 0; nb < NBT; ++nb) wf[nb] = *reinterpret_cast<const bf16x8*>(wrow[nb] + k);
+    for (int i = 0; i < BCH; ++i) {
+      const int k = (wave + NW * (c0 + i)) * 32;
 #pragma unroll
-    for (int mb = 0; mb < MB; ++mb) xf[mb] = *reinterpret_cast<const bf16x8*>(arow[mb] + k);
-    if constexpr (RSTD) {
+      for (int nb = 0; nb < NBT; ++nb) wf[i][nb] = *reinterpret_cast<const bf16x8*>(wrow[nb] + k);
 #pragma unroll
-      for (int mb = 0; mb < MB; ++mb)
-#pragma unroll
-        for (int e = 0; e < 8; ++e) ss[mb] += (float)xf[mb][e] * (float)xf[mb][e];
+      for (int mb = 0; mb < MB; ++mb) xf[i][mb] = *reinterpret_cast<const bf16x8*>(arow[mb] + k);
     }
+    __builtin_amdgcn_sched_barrier(0);  // every load of the batch is in flight before the first use
 #pragma unroll
-    for (int nb = 0; nb < NBT; ++nb)
+    for (int i = 0; i < BCH; ++i) {
+      if constexpr (RSTD) {
 #pragma unroll
-      for (int mb = 0; mb < MB; ++mb)
-        acc[mb][nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[nb], xf[mb], acc[mb][nb], 0, 0, 0);
+        for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+          for (int e = 0; e < 8; ++e) ss[mb] += (float)xf[i][mb][e] * (float)xf[i][mb][e];
+      }
+#pragma unroll
+      for (int nb = 0; nb < NBT; ++nb)
+#pragma unroll
+        for (int mb = 0; mb < MB; ++mb)
+          acc[mb][nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[i][nb], xf[i][mb], acc[mb][nb], 0, 0, 0);
+    }
   }
 
   // sum the waves' partial tiles: lane (fi, fg) of acc[mb][nb] holds row mb*16+fi, columns nb*16 + 4 fg + e
@@ -145,9 +162,8 @@ __global__ __launch_bounds__(NW * 64) void gemm_skinny_kernel(const bf16* __rest
     }
   }
   __syncthreads();
-  if (threadIdx.x >= MR * 4) return;  // four threads per row write the tile
+  if (!writer) return;  // four threads per row write the tile
   const int m = m0 + ml;
-  if (m >= M) return;
   float rs = 1.f;
   if constexpr (RSTD) {
     float t = ssq[0][ml];
@@ -177,7 +193,11 @@ __global__ __launch_bounds__(NW * 64) void gemm_skinny_kernel(const bf16* __rest
 #pragma unroll
     for (int j = 0; j < CPT; ++j) {
       const int n = blockIdx.x * NB + c0 + j;
-      if (n < N) C[(int64_t)m * ldc + n] = (bf16)(total(c0 + j) + rpre[j]);
+      if (n < N) {
+        float r = (MODE == 0 && R != nullptr) ? (float)rraw[j] : 0.f;
+        if (MODE == 0 && R != nullptr && !res_full) r = (float)R[rrow_i * ldr + n];  // (ragged last block only)
+        C[(int64_t)m * ldc + n] = (bf16)(total(c0 + j) + r);
+      }
     }
   }
 }
@@ -211,10 +231,17 @@ extern "C" int mh_gemm_skinny(const void* A, int64_t lda, const void* W, int64_t
   }
   if (mb > row_blocks) mb = row_blocks >= 4 ? 4 : (row_blocks >= 2 ? 2 : 1);
   const int gy = (row_blocks + mb - 1) / mb;
-#define MH_SK3(MODE_, NBT_, NW_, GRID_, RSTD_, MB_)                                                                        \
-  gemm_skinny_kernel<MODE_, NBT_, NW_, RSTD_, MB_><<<dim3((unsigned)(GRID_), (unsigned)gy), NW_ * 64, 0, st>>>(            \
+#define MH_SK4(MODE_, NBT_, NW_, GRID_, RSTD_, MB_, BCH_)                                                                  \
+  gemm_skinny_kernel<MODE_, NBT_, NW_, RSTD_, MB_, BCH_><<<dim3((unsigned)(GRID_), (unsigned)gy), NW_ * 64, 0, st>>>(      \
       (const bf16*)A, lda, (const bf16*)W, ldw, (bf16*)C, ldc, (const bf16*)R, ldr, (int)M, (int)N, (int)K, norm_eps,      \
       row_ids, res_ids)
+#define MH_SK3(MODE_, NBT_, NW_, GRID_, RSTD_, MB_)                                                                        \
+  do {                                                                                                                    \
+    const int ncw_ = (int)(K / (32 * NW_)); /* chunks per wave; batches of the largest of 8 / 4 / 1 that divides it */    \
+    if (ncw_ % 8 == 0 && (NBT_ + MB_) <= 4) MH_SK4(MODE_, NBT_, NW_, GRID_, RSTD_, MB_, 8);                                \
+    else if (ncw_ % 4 == 0) MH_SK4(MODE_, NBT_, NW_, GRID_, RSTD_, MB_, 4);                                                \
+    else MH_SK4(MODE_, NBT_, NW_, GRID_, RSTD_, MB_, 1);                                                                   \
+  } while (0)
 #define MH_SK2(MODE_, NBT_, NW_, GRID_, RSTD_)                                                                             \
   do {                                                                                                                    \
     if (mb == 1) MH_SK3(MODE_, NBT_, NW_, GRID_, RSTD_, 1);                                                                \
@@ -233,6 +260,7 @@ extern "C" int mh_gemm_skinny(const void* A, int64_t lda, const void* W, int64_t
 #undef MH_SK
 #undef MH_SK2
 #undef MH_SK3
+#undef MH_SK4
   MH_LAUNCH_CHECK();
   return MH_OK;
 }

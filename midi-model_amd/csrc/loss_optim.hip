@@ -439,6 +439,10 @@ __global__ __launch_bounds__(256) void sample_top_p_k_kernel(const T* __restrict
   __shared__ float sel_v[SAMPLE_MAX_K];
   __shared__ int sel_i[SAMPLE_MAX_K];
   __shared__ float part_m[4], part_s[4];
+  // (every kernel argument fetched at entry in one batch: see attn_decode_kernel)
+  asm volatile("" ::"s"(logits), "s"(ldl), "s"(first_mask), "s"(ban_mask), "s"(lo_tab), "s"(hi_tab), "s"(tab_stride), "s"(ev));
+  asm volatile("" ::"s"(pos), "s"(first_lo), "s"(first_hi), "s"(q), "s"(out), "s"(out_stride), "s"(out_b), "s"(out_c));
+  asm volatile("" ::"s"(V), "s"(temp), "s"(top_p), "s"(top_k), "s"(fill_rest), "s"(fill_id));
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int64_t b = blockIdx.x;
   const T* row = logits + b * ldl;
