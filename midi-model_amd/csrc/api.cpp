@@ -28,6 +28,7 @@ int g_mh_gemm_variant = env_int("MH_GEMM", 1);
 int g_mh_gemm_ablate = 0;
 extern int g_skinny_mb, g_skinny_nbt;  // gemm_skinny.hip
 extern int g_attn_fwd_wps, g_attn_fwd_qb;  // attention_mfma.hip
+extern int g_attn_v3, g_attn_v3_wps;      // attention_mfma3.hip
 
 extern "C" int mh_set_option(const char* name, int value) {
   if (strcmp(name, "gemm") == 0) {
@@ -48,6 +49,14 @@ extern "C" int mh_set_option(const char* name, int value) {
   }
   if (strcmp(name, "attn_fwd_qb") == 0) {  // query blocks (32 rows) per wave of the event-level attention forward (1 | 2)
     g_attn_fwd_qb = value;
+    return 0;
+  }
+  if (strcmp(name, "attn_v3") == 0) {  // third form of the event-level attention kernels: bit 0 forward, bit 1 dQ, bit 2 dK/dV
+    g_attn_v3 = value;
+    return 0;
+  }
+  if (strcmp(name, "attn_v3_wps") == 0) {  // its register budget in waves per SIMD (0 = default; A/B runs)
+    g_attn_v3_wps = value;
     return 0;
   }
   if (strcmp(name, "skinny_nbt") == 0) {  // 16-column blocks per workgroup of its plain form (0 = default)

@@ -27,91 +27,8 @@
 int g_attn_fwd_qb = 1;   // mh_set_option("attn_fwd_qb", 1 | 2): query blocks per wave of the first forward structure
 int g_attn_fwd_wps = 2;  // mh_set_option("attn_fwd_wps", 2 | 3): register budget of the second forward structure (A/B runs)
 
-constexpr int HD = 64;
-constexpr int TILE64 = 64 * 128;  // bytes
-constexpr int DKV_STAGE = 4 * TILE64 + 2048;  // bytes of one stage of the dK/dV kernel (4 tiles + 1 KiB lse + 1 KiB delta)
-constexpr float LOG2E = 1.4426950408889634f;
-constexpr float RESCALE_THR = 4.0f;  // a row's reference max may lag its true max by a factor <= 2^4
+#include "attn_mfma_common.h"
 
-__device__ inline f32x16 mfma32(const bf16x8& a, const bf16x8& b, f32x16 c) {
-  return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
-}
-__device__ inline f32x16 zero16() {
-  f32x16 z;
-#pragma unroll
-  for (int i = 0; i < 16; ++i) z[i] = 0.f;
-  return z;
-}
-__device__ inline bf16x8 lds_frag(const char* tile, int row, int chunk) {
-  return *reinterpret_cast<const bf16x8*>(tile + lds_tile_off(row, chunk));
-}
-__device__ inline bf16x8 pack8(const f32x16& v, int base) {
-  bf16x8 o;
-#pragma unroll
-  for (int e = 0; e < 8; ++e) o[e] = (bf16)v[base + e];
-  return o;
-}
-__device__ inline float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }  // raw v_exp_f32
-// register r of lane-half hi <-> reduction index (within a 32-block) 16*(r>>3) + 8*hi + (r&7)
-__device__ inline int reg_index(int r, int hi) { return 16 * (r >> 3) + 8 * hi + (r & 7); }
-
-// stage a 64-row x 64-col bf16 tile: rows row0.. (clamped to row_clamp), columns col0..col0+63
-__device__ inline void stage64(const bf16* __restrict__ base, int64_t ld, int64_t row0, int64_t row_clamp, int64_t col0,
-                               char* lds_tile, int wave, int lane) {
-  const int rsub = lane >> 3, pc = lane & 7;
-#pragma unroll
-  for (int it = 0; it < 2; ++it) {
-    const int g8 = wave + 4 * it;
-    const int r = g8 * 8 + rsub;
-    const int c = pc ^ ((r >> 1) & 7);
-    int64_t grow = row0 + r;
-    if (grow > row_clamp) grow = row_clamp;
-    glds16(base + grow * ld + col0 + c * 8, lds_tile + g8 * 1024);
-  }
-}
-
-// Store one lane's share of a 64-wide gradient row (acc[hb][16]: elements hb*32 + 16*r8 + 8*hi + e), optionally through
-// the transpose of the RoPE rotation at position `pos` (the gradient with respect to the unrotated projection): the
-// partners d and d + 32 are acc[0][.] and acc[1][.] of the same lane.  Roundings as the separate pass it replaces
-// (mh_rope with dir = -1 on the stored bf16 gradient; cos/sin rounded to bf16, modeling_llama.py:126).
-__device__ inline void store_grad_row(bf16* orow, const f32x16 (&acc)[2], float scale, int hi, const float* cos_t,
-                                      const float* sin_t, int pos) {
-#pragma unroll
-  for (int r8 = 0; r8 < 2; ++r8) {
-    bf16x8 v0, v1;
-#pragma unroll
-    for (int e = 0; e < 8; ++e) {
-      v0[e] = (bf16)(acc[0][8 * r8 + e] * scale);
-      v1[e] = (bf16)(acc[1][8 * r8 + e] * scale);
-    }
-    if (cos_t != nullptr) {
-      const int i0 = 16 * r8 + 8 * hi;
-      const f32x4 c0 = *reinterpret_cast<const f32x4*>(cos_t + pos * 32 + i0), c1 = *reinterpret_cast<const f32x4*>(cos_t + pos * 32 + i0 + 4);
-      const f32x4 s0 = *reinterpret_cast<const f32x4*>(sin_t + pos * 32 + i0), s1 = *reinterpret_cast<const f32x4*>(sin_t + pos * 32 + i0 + 4);
-#pragma unroll
-      for (int e = 0; e < 8; ++e) {
-        const float c = (float)(bf16)(e < 4 ? c0[e] : c1[e - 4]), sn = -(float)(bf16)(e < 4 ? s0[e] : s1[e - 4]);
-        const float x1 = (float)v0[e], x2 = (float)v1[e];
-        v0[e] = (bf16)(x1 * c - x2 * sn);
-        v1[e] = (bf16)(x2 * c + x1 * sn);
-      }
-    }
-    *reinterpret_cast<bf16x8*>(orow + 16 * r8 + 8 * hi) = v0;
-    *reinterpret_cast<bf16x8*>(orow + 32 + 16 * r8 + 8 * hi) = v1;
-  }
-}
-
-// Work assignment.  The dispatcher places workgroup b on XCD b % 8 (each XCD has a private 4 MiB L2), so a 1-D
-// grid is decoded as  xcd = b & 7, i = b >> 3, head = (i / ntile) * 8 + xcd, tile = i % ntile : consecutive
-// workgroups of one XCD walk the tiles of ONE (batch, head) pair, whose K/V (or Q/dO) panels then stay in that
-// XCD's L2 instead of being re-fetched (r01 PMC with the (tile, head) 2-D grid: L2 hit rate 34 % fwd, 14 % dK/dV).
-__device__ inline bool attn_work(int BH, int ntile, int& bh, int& tile) {
-  const int lin = blockIdx.x, xcd = lin & 7, i = lin >> 3;
-  const int g = i / ntile;
-  bh = g * 8 + xcd;
-  tile = i - g * ntile;
-  return bh < BH;
-}
 
 // ---------------------------------------------------------------------------------------------------
 // forward
@@ -872,9 +789,17 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const bf16* __rest
 }
 
 // ---------------------------------------------------------------------------------------------------
+extern int g_attn_v3;  // attention_mfma3.hip: the third form of the three kernels (bit 0 forward, bit 1 dQ, bit 2 dK/dV)
+int mh_attn_fwd_mfma3(const void* qkv, const void* vt, void* o, float* lse, int64_t B, int64_t S, int H, float scale,
+                      hipStream_t st);
+int mh_attn_bwd_mfma3(const void* qkv, const void* dout, const float* lse, const float* delta, const void* qt, const void* kt,
+                      const void* dot, void* dqkv, int64_t B, int64_t S, int H, float scale, const float* cos_t,
+                      const float* sin_t, int which, hipStream_t st);
+
 int mh_attn_fwd_mfma(const void* qkv, const void* vt, void* o, float* lse, int64_t B, int64_t S, int H, float scale,
                      hipStream_t st) {
   MH_REQUIRE(S < (1 << 24), "attn_fwd: sequence too long");
+  if (vt != nullptr && g_attn_fwd_qb != 2 && (g_attn_v3 & 1)) return mh_attn_fwd_mfma3(qkv, vt, o, lse, B, S, H, scale, st);
   const int64_t Sp = (S + 63) / 64 * 64;
   const int nt = (int)((S + 127) / 128), BH = (int)(B * H);
   const unsigned grid = (unsigned)(nt * 8 * ((BH + 7) / 8));
@@ -910,11 +835,19 @@ int mh_attn_bwd_mfma(const void* qkv, const void* dout, const float* lse, const 
   const int64_t Sp = (S + 63) / 64 * 64;
   const int nt = (int)((S + 127) / 128), BH = (int)(B * H);
   const unsigned grid = (unsigned)(nt * 8 * ((BH + 7) / 8));
-  attn_bwd_dq_kernel<<<grid, 256, 6 * TILE64, st>>>((const bf16*)qkv, (const bf16*)dout, lse, delta, (const bf16*)kt,
-                                           (bf16*)dqkv, (int)S, (int)Sp, H, scale, BH, nt, cos_t, sin_t);
-  MH_LAUNCH_CHECK();
-  attn_bwd_dkv_kernel<<<grid, 256, 2 * DKV_STAGE, st>>>((const bf16*)qkv, (const bf16*)dout, lse, delta, (const bf16*)qt,
-                                            (const bf16*)dot, (bf16*)dqkv, (int)S, (int)Sp, H, scale, BH, nt, cos_t, sin_t);
-  MH_LAUNCH_CHECK();
+  if (g_attn_v3 & 6) {
+    const int rc = mh_attn_bwd_mfma3(qkv, dout, lse, delta, qt, kt, dot, dqkv, B, S, H, scale, cos_t, sin_t, g_attn_v3 & 6, st);
+    if (rc != MH_OK) return rc;
+  }
+  if (!(g_attn_v3 & 2)) {
+    attn_bwd_dq_kernel<<<grid, 256, 6 * TILE64, st>>>((const bf16*)qkv, (const bf16*)dout, lse, delta, (const bf16*)kt,
+                                             (bf16*)dqkv, (int)S, (int)Sp, H, scale, BH, nt, cos_t, sin_t);
+    MH_LAUNCH_CHECK();
+  }
+  if (!(g_attn_v3 & 4)) {
+    attn_bwd_dkv_kernel<<<grid, 256, 2 * DKV_STAGE, st>>>((const bf16*)qkv, (const bf16*)dout, lse, delta, (const bf16*)qt,
+                                              (const bf16*)dot, (bf16*)dqkv, (int)S, (int)Sp, H, scale, BH, nt, cos_t, sin_t);
+    MH_LAUNCH_CHECK();
+  }
   return MH_OK;
 }

@@ -1,0 +1,603 @@
+// Event-level causal attention (head_dim 64, bf16), third form of the three MFMA kernels of attention_mfma.hip (same
+// orientation, same LDS tile format, same transposed copies, same results to rounding; selected per kernel by
+// mh_set_option("attn_v3", bits), bit 0 forward, bit 1 dQ, bit 2 dK/dV).
+//
+// What the ISA of the first form showed (r02, `hipcc -S` of attention_mfma.hip) and what changes here:
+//  * every MFMA pair sat behind its own `ds_read_b128 ; s_waitcnt lgkmcnt(0)`: 16-32 exposed LDS round trips per tile and
+//    wave (PMC: waves 32 % of their cycles in s_waitcnt).  Here the fragments of a phase are requested in ONE batch ahead of
+//    the MFMAs that use them, and the batch of the next phase goes out before the arithmetic of the current one
+//    (sched_barrier keeps hipcc from sinking the reads back to their uses); the compiler's own counted lgkmcnt waits remain.
+//  * the tile loop chose between the masked and the unmasked instantiation INSIDE the loop; the two inlined bodies got
+//    different register assignments for the loop-carried accumulators and hipcc reconciled them with 16-64 v_mov_b64 per
+//    tile (the dK/dV kernel copied all four accumulators in and out).  A wave's tiles come in a fixed order -- dK/dV: tiles
+//    before its keys (nothing to do), the one or two diagonal tiles (masked), the full tiles, a ragged last tile (masked);
+//    forward and dQ: full tiles, one diagonal tile, then tiles only its neighbours need -- so the loop is split into one
+//    loop per class, each with a single body.
+//  * the forward's uniform `if (__any(rescale))` produced a copy of the O accumulator on the common path; the test is now
+//    per lane (a row rescales when ITS maximum grew): the update is executed in place under EXEC and skipped when no lane
+//    needs it.
+//  * the row maximum crosses the two wave halves through v_permlane32_swap (VALU) instead of ds_bpermute, whose wait would
+//    also wait for the fragment batch in flight.
+// Roofline: MFMA (2.5 PFLOP/s bf16 dense), VALU co-limited at head_dim 64.
+#include "attn_mfma_common.h"
+
+int g_attn_v3 = 7;      // mh_set_option("attn_v3", bits): 1 forward, 2 dQ, 4 dK/dV
+int g_attn_v3_wps = 0;  // mh_set_option("attn_v3_wps", n): register budget (waves per SIMD) override for A/B runs, 0 = default
+
+__device__ inline bf16x8 ldsv(const char* p) { return *reinterpret_cast<const bf16x8*>(p); }
+__device__ inline float xhalf_max(float v) {  // max with the other wave half's value (lane ^ 32), VALU only
+  const int iv = __float_as_int(v);
+  const auto pr = __builtin_amdgcn_permlane32_swap(iv, iv, false, false);
+  return fmaxf(__int_as_float(pr[0]), __int_as_float(pr[1]));
+}
+
+// ---------------------------------------------------------------------------------------------------
+// forward
+// ---------------------------------------------------------------------------------------------------
+// one 64-key tile for one wave (32 query rows).  foff[s]: this lane's byte offset of fragment s inside a 32-row tile block
+// (row pi32(lane & 31), chunk 2s + hi); the second block of a tile is 4096 bytes further.  qrel = query row - first key.
+template <bool MASK>
+__device__ inline void fwd3_tile(const char* tK, const char* tV, const int (&foff)[4], const bf16x8 (&qf)[4],
+                                 f32x16 (&oacc)[2], float& m, float& l, int hi, int qrel, float sc) {
+  bf16x8 kf[2][4];
+#pragma unroll
+  for (int s = 0; s < 4; ++s)
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb) kf[kb][s] = ldsv(tK + foff[s] + kb * 4096);
+  __builtin_amdgcn_sched_barrier(0);
+  f32x16 sacc[2] = {zero16(), zero16()};
+#pragma unroll
+  for (int s = 0; s < 4; ++s)
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb) sacc[kb] = mfma32(kf[kb][s], qf[s], sacc[kb]);  // two independent accumulator chains
+  bf16x8 vf[4][2];  // the V^T fragments of the whole tile: in flight under the softmax arithmetic
+#pragma unroll
+  for (int t = 0; t < 4; ++t)
+#pragma unroll
+    for (int db = 0; db < 2; ++db) vf[t][db] = ldsv(tV + foff[t] + db * 4096);
+  __builtin_amdgcn_sched_barrier(0);
+  float mx = -INFINITY;
+#pragma unroll
+  for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      if (MASK) {
+        if (kb * 32 + reg_index(r, hi) > qrel) sacc[kb][r] = -INFINITY;
+      }
+      mx = fmaxf(mx, sacc[kb][r]);
+    }
+  mx = xhalf_max(mx) * sc;  // running max kept in scaled (log2) units
+  // A row moves its reference maximum only when its true maximum grew by more than RESCALE_THR (log2 units): until then
+  // its probabilities may reach 2^THR instead of 1, and l / O / lse stay mutually consistent (exact maths; only the bf16
+  // rounding of P sees the larger magnitudes).  Per lane, in place under EXEC (both halves of a row decide alike).
+  if (mx > m + RESCALE_THR) {
+    const float mn = fmaxf(m, mx);
+    const float alpha = fast_exp2(m - mn);
+#pragma unroll
+    for (int db = 0; db < 2; ++db)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) oacc[db][r] *= alpha;
+    l *= alpha;
+    m = mn;
+  }
+  float ps0 = 0.f, ps1 = 0.f;  // (two partial sums: half the length of the dependent add chain)
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const float p0 = fast_exp2(__builtin_fmaf(sacc[0][r], sc, -m)), p1 = fast_exp2(__builtin_fmaf(sacc[1][r], sc, -m));
+    sacc[0][r] = p0;
+    sacc[1][r] = p1;
+    ps0 += p0;
+    ps1 += p1;
+  }
+  l += ps0 + ps1;
+#pragma unroll
+  for (int t = 0; t < 4; ++t) {
+    const bf16x8 pf = pack8(sacc[t >> 1], 8 * (t & 1));
+#pragma unroll
+    for (int db = 0; db < 2; ++db) oacc[db] = mfma32(vf[t][db], pf, oacc[db]);
+  }
+}
+
+template <int WPS>
+__global__ __launch_bounds__(256, WPS) void attn_fwd3_kernel(const bf16* __restrict__ qkv, const bf16* __restrict__ vt,
+                                                          bf16* __restrict__ o, float* __restrict__ lse, int S, int Sp, int H,
+                                                          float sc /* scale*log2(e) */, int BH, int nqt) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];  // 4 tiles = [stage][K | V^T] (dynamic: see attn_fwd_kernel)
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  int bh_, tile_;
+  if (!attn_work(BH, nqt, bh_, tile_)) return;
+  const int64_t bh = bh_;
+  const int64_t b = bh / H;
+  const int h = (int)(bh - b * H);
+  const int64_t D = (int64_t)H * HD, D3 = 3 * D;
+  const int q0 = (nqt - 1 - tile_) * 128;  // heavy (late) query tiles first
+  const int qw0 = q0 + wave * 32;
+  const int li = lane & 31, hi = lane >> 5;
+  const int qrow = qw0 + li;
+  const int qld = (qrow < S) ? qrow : S - 1;
+
+  const bf16* kbase = qkv + b * S * D3 + D + (int64_t)h * HD;
+  const bf16* vtbase = vt + bh * HD * Sp;
+
+  bf16x8 qf[4];
+  {
+    const bf16* qp = qkv + (b * S + qld) * D3 + (int64_t)h * HD + 8 * hi;
+#pragma unroll
+    for (int s = 0; s < 4; ++s) qf[s] = *reinterpret_cast<const bf16x8*>(qp + 16 * s);
+  }
+  f32x16 oacc[2] = {zero16(), zero16()};
+  float m = -INFINITY, l = 0.f;
+
+  int last_q = q0 + 127;
+  if (last_q > S - 1) last_q = S - 1;
+  const int kt_last = last_q / 64;
+  // this wave's tiles, in order: n_full tiles entirely below its first row, ONE tile crossing its diagonal (64 n_full <=
+  // qw0 < 64 n_full + 64), then the tiles only the later waves of the workgroup still need
+  int n_full = qw0 >> 6;
+  if (n_full > kt_last + 1) n_full = kt_last + 1;  // (a wave whose rows all lie past S)
+  int foff[4];
+  {
+    const int pli = pi32(li);
+#pragma unroll
+    for (int s = 0; s < 4; ++s) foff[s] = lds_tile_off(pli, 2 * s + hi);
+  }
+
+  const int iD3 = (int)D3;
+  stage64u(kbase, iD3, 0, S - 1, 0, smem, wave, lane);
+  stage64u(vtbase, Sp, 0, HD - 1, 0, smem + TILE64, wave, lane);
+#pragma unroll
+  for (int s = 0; s < 4; ++s) asm volatile("" : "+v"(qf[s]));  // (see attn_bwd_dkv_kernel)
+  __syncthreads();
+  auto stage_next = [&](int kt) {
+    if (kt + 1 <= kt_last) {
+      char* nxt = smem + ((kt + 1) & 1) * 2 * TILE64;
+      stage64u(kbase, iD3, (kt + 1) * 64, S - 1, 0, nxt, wave, lane);
+      stage64u(vtbase, Sp, 0, HD - 1, (kt + 1) * 64, nxt + TILE64, wave, lane);
+    }
+  };
+  int kt = 0;
+  for (; kt < n_full; ++kt) {
+    stage_next(kt);
+    const char* cur = smem + (kt & 1) * 2 * TILE64;
+    fwd3_tile<false>(cur, cur + TILE64, foff, qf, oacc, m, l, hi, 0, sc);
+    __syncthreads();
+  }
+  if (kt <= kt_last) {
+    stage_next(kt);
+    const char* cur = smem + (kt & 1) * 2 * TILE64;
+    fwd3_tile<true>(cur, cur + TILE64, foff, qf, oacc, m, l, hi, qrow - kt * 64, sc);
+    __syncthreads();
+    ++kt;
+  }
+  for (; kt <= kt_last; ++kt) {
+    stage_next(kt);
+    __syncthreads();
+  }
+  const float lt = l + __shfl_xor(l, 32, 64);
+  if (qrow < S) {
+    const float inv = 1.f / lt;
+    bf16* orow = o + (b * S + qrow) * D + (int64_t)h * HD;
+#pragma unroll
+    for (int db = 0; db < 2; ++db)
+#pragma unroll
+      for (int r8 = 0; r8 < 2; ++r8) {
+        bf16x8 v;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = (bf16)(oacc[db][8 * r8 + e] * inv);
+        *reinterpret_cast<bf16x8*>(orow + db * 32 + 16 * r8 + 8 * hi) = v;
+      }
+    if (hi == 0) lse[bh * Sp + qrow] = (m + log2f(lt)) * 0.6931471805599453f;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// backward, dQ: block = 128 query rows, loop over key tiles
+// ---------------------------------------------------------------------------------------------------
+// one 64-key tile for one wave (32 query rows).  WIDE: the K / V fragments of both 32-key blocks go out in one batch of 16
+// (two waves per SIMD: 256 registers); otherwise block by block (three waves per SIMD).
+template <bool MASK, bool WIDE>
+__device__ inline void dq3_tile(const char* tK, const char* tV, const char* tKT, const int (&foff)[4], const bf16x8 (&qf)[4],
+                                const bf16x8 (&dof)[4], f32x16 (&dqacc)[2], int hi, int qrel, float sc, float lse2, float dl) {
+  auto softmax_grad = [&](f32x16& sacc, const f32x16& pacc, int kb) {  // S -> dS (unscaled), in place
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      float p = fast_exp2(__builtin_fmaf(sacc[r], sc, -lse2));
+      if (MASK) {
+        if (kb * 32 + reg_index(r, hi) > qrel) p = 0.f;
+      }
+      sacc[r] = p * (pacc[r] - dl);
+    }
+  };
+  if (WIDE) {
+    bf16x8 kf[2][4], vf[2][4];
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+        kf[kb][s] = ldsv(tK + foff[s] + kb * 4096);
+        vf[kb][s] = ldsv(tV + foff[s] + kb * 4096);
+      }
+    __builtin_amdgcn_sched_barrier(0);
+    f32x16 sacc[2] = {zero16(), zero16()}, pacc[2] = {zero16(), zero16()};
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+        sacc[kb] = mfma32(kf[kb][s], qf[s], sacc[kb]);
+        pacc[kb] = mfma32(vf[kb][s], dof[s], pacc[kb]);
+      }
+    bf16x8 ktf[4][2];  // K^T fragments of the whole tile: c = 2 kb + t <-> chunk 4 kb + 2 t + hi
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+#pragma unroll
+      for (int hb = 0; hb < 2; ++hb) ktf[c][hb] = ldsv(tKT + foff[c] + hb * 4096);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb) {
+      softmax_grad(sacc[kb], pacc[kb], kb);
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        const bf16x8 dsf = pack8(sacc[kb], 8 * t);
+#pragma unroll
+        for (int hb = 0; hb < 2; ++hb) dqacc[hb] = mfma32(ktf[2 * kb + t][hb], dsf, dqacc[hb]);
+      }
+    }
+  } else {
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb) {
+      bf16x8 kf[4], vf[4];
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+        kf[s] = ldsv(tK + foff[s] + kb * 4096);
+        vf[s] = ldsv(tV + foff[s] + kb * 4096);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      f32x16 sacc = zero16(), pacc = zero16();
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+        sacc = mfma32(kf[s], qf[s], sacc);
+        pacc = mfma32(vf[s], dof[s], pacc);
+      }
+      bf16x8 ktf[2][2];
+#pragma unroll
+      for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int hb = 0; hb < 2; ++hb) ktf[t][hb] = ldsv(tKT + foff[2 * kb + t] + hb * 4096);
+      __builtin_amdgcn_sched_barrier(0);
+      softmax_grad(sacc, pacc, kb);
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        const bf16x8 dsf = pack8(sacc, 8 * t);
+#pragma unroll
+        for (int hb = 0; hb < 2; ++hb) dqacc[hb] = mfma32(ktf[t][hb], dsf, dqacc[hb]);
+      }
+    }
+  }
+}
+
+template <int WPS>
+__global__ __launch_bounds__(256, WPS) void attn_bwd_dq3_kernel(const bf16* __restrict__ qkv, const bf16* __restrict__ dout,
+                                                              const float* __restrict__ lse, const float* __restrict__ delta,
+                                                              const bf16* __restrict__ kt_, bf16* __restrict__ dqkv, int S,
+                                                              int Sp, int H, float scale, int BH, int nqt,
+                                                              const float* __restrict__ cos_t,
+                                                              const float* __restrict__ sin_t) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];  // 6 tiles: [stage][K | V | K^T]
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  int bh_, tile_;
+  if (!attn_work(BH, nqt, bh_, tile_)) return;
+  const int64_t bh = bh_;
+  const int64_t b = bh / H;
+  const int h = (int)(bh - b * H);
+  const int64_t D = (int64_t)H * HD, D3 = 3 * D;
+  const int q0 = (nqt - 1 - tile_) * 128;
+  const int qw0 = q0 + wave * 32;
+  const int li = lane & 31, hi = lane >> 5;
+  const int qrow = qw0 + li;
+  const int qld = (qrow < S) ? qrow : S - 1;
+  const float sc = scale * LOG2E;
+
+  const bf16* kbase = qkv + b * S * D3 + D + (int64_t)h * HD;
+  const bf16* vbase = kbase + D;
+  const bf16* ktbase = kt_ + bh * HD * Sp;
+
+  bf16x8 qf[4], dof[4];
+  {
+    const bf16* qp = qkv + (b * S + qld) * D3 + (int64_t)h * HD + 8 * hi;
+    const bf16* dp = dout + (b * S + qld) * D + (int64_t)h * HD + 8 * hi;
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      qf[s] = *reinterpret_cast<const bf16x8*>(qp + 16 * s);
+      dof[s] = *reinterpret_cast<const bf16x8*>(dp + 16 * s);
+    }
+  }
+  float lse2 = lse[bh * Sp + qld] * LOG2E;
+  float dl = delta[bh * Sp + qld];
+  f32x16 dqacc[2] = {zero16(), zero16()};
+
+  int last_q = q0 + 127;
+  if (last_q > S - 1) last_q = S - 1;
+  const int kt_last = last_q / 64;
+  int n_full = qw0 >> 6;  // (tile classes of a wave: see attn_fwd3_kernel)
+  if (n_full > kt_last + 1) n_full = kt_last + 1;
+  int foff[4];
+  {
+    const int pli = pi32(li);
+#pragma unroll
+    for (int s = 0; s < 4; ++s) foff[s] = lds_tile_off(pli, 2 * s + hi);
+  }
+
+  const int iD3 = (int)D3;
+  stage64u(kbase, iD3, 0, S - 1, 0, smem, wave, lane);
+  stage64u(vbase, iD3, 0, S - 1, 0, smem + TILE64, wave, lane);
+  stage64u(ktbase, Sp, 0, HD - 1, 0, smem + 2 * TILE64, wave, lane);
+#pragma unroll
+  for (int s = 0; s < 4; ++s) {  // (see attn_bwd_dkv_kernel)
+    asm volatile("" : "+v"(qf[s]));
+    asm volatile("" : "+v"(dof[s]));
+  }
+  asm volatile("" : "+v"(lse2));
+  asm volatile("" : "+v"(dl));
+  __syncthreads();
+  auto stage_next = [&](int kt) {
+    if (kt + 1 <= kt_last) {
+      char* nxt = smem + ((kt + 1) & 1) * 3 * TILE64;
+      stage64u(kbase, iD3, (kt + 1) * 64, S - 1, 0, nxt, wave, lane);
+      stage64u(vbase, iD3, (kt + 1) * 64, S - 1, 0, nxt + TILE64, wave, lane);
+      stage64u(ktbase, Sp, 0, HD - 1, (kt + 1) * 64, nxt + 2 * TILE64, wave, lane);
+    }
+  };
+  constexpr bool WIDE = WPS <= 2;
+  int kt = 0;
+  for (; kt < n_full; ++kt) {
+    stage_next(kt);
+    const char* cur = smem + (kt & 1) * 3 * TILE64;
+    dq3_tile<false, WIDE>(cur, cur + TILE64, cur + 2 * TILE64, foff, qf, dof, dqacc, hi, 0, sc, lse2, dl);
+    __syncthreads();
+  }
+  if (kt <= kt_last) {
+    stage_next(kt);
+    const char* cur = smem + (kt & 1) * 3 * TILE64;
+    dq3_tile<true, WIDE>(cur, cur + TILE64, cur + 2 * TILE64, foff, qf, dof, dqacc, hi, qrow - kt * 64, sc, lse2, dl);
+    __syncthreads();
+    ++kt;
+  }
+  for (; kt <= kt_last; ++kt) {
+    stage_next(kt);
+    __syncthreads();
+  }
+  if (qrow < S) {
+    bf16* orow = dqkv + (b * S + qrow) * D3 + (int64_t)h * HD;
+    store_grad_row(orow, dqacc, scale, hi, cos_t, sin_t, qrow);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// backward, dK/dV: block = 128 key rows, loop over the query tiles that see them
+// ---------------------------------------------------------------------------------------------------
+// one 64-query tile for one wave (32 key rows).  krel = key row - first query of the tile; qlim = number of valid queries
+// in the tile (S - q0, may exceed 64).  Reads per tile: Q / dO fragments of both query blocks in one batch (16), then per
+// query block the dO^T / Q^T fragments (8) and its 32 lse / 32 delta values (8 broadcast reads of 4) ahead of the arithmetic.
+template <bool MASK>
+__device__ inline void dkv3_tile(const char* tQ, const char* tDO, const char* tQT, const char* tDOT, const char* tLD,
+                                 const int (&foff)[4], const bf16x8 (&kf)[4], const bf16x8 (&vf)[4], f32x16 (&dkacc)[2],
+                                 f32x16 (&dvacc)[2], int hi, int krel, int qlim, float sc) {
+#pragma unroll
+  for (int qb = 0; qb < 2; ++qb) {
+    bf16x8 qf[4], dof[4];  // Q / dO fragments of the query block
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      qf[s] = ldsv(tQ + foff[s] + qb * 4096);
+      dof[s] = ldsv(tDO + foff[s] + qb * 4096);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    f32x16 sacc = zero16(), pacc = zero16();
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      sacc = mfma32(qf[s], kf[s], sacc);
+      pacc = mfma32(dof[s], vf[s], pacc);
+    }
+    // The block's second half runs in two steps of 16 queries (t): the dO^T / Q^T fragments (chunk 4 qb + 2 t + hi of row
+    // block xb) and the 8 lse / 8 delta values of step t are requested one step ahead -- step 0's under the MFMAs above,
+    // step 1's under the four MFMAs of step 0 -- so that 16 + 16 registers hold them instead of 64.
+    bf16x8 dotf[2][2], qtf[2][2];  // [t][xb]
+    f32x4 la[2][2], dd[2][2];      // [t][v4]: queries qb*32 + 16 t + 8 hi + 4 v4 .. +3
+    auto request = [&](int t) {
+#pragma unroll
+      for (int xb = 0; xb < 2; ++xb) {
+        dotf[t][xb] = ldsv(tDOT + foff[2 * qb + t] + xb * 4096);
+        qtf[t][xb] = ldsv(tQT + foff[2 * qb + t] + xb * 4096);
+      }
+#pragma unroll
+      for (int v4 = 0; v4 < 2; ++v4) {
+        const int qq = qb * 32 + 16 * t + 8 * hi + 4 * v4;
+        la[t][v4] = *reinterpret_cast<const f32x4*>(tLD + qq * 4);
+        dd[t][v4] = *reinterpret_cast<const f32x4*>(tLD + 1024 + qq * 4);
+      }
+    };
+    request(0);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+#pragma unroll
+      for (int v4 = 0; v4 < 2; ++v4)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {  // S -> P, dP -> dS (unscaled), in place
+          const int r = 8 * t + 4 * v4 + e;
+          float p = fast_exp2(__builtin_fmaf(sacc[r], sc, -la[t][v4][e] * LOG2E));
+          float ds = p * (pacc[r] - dd[t][v4][e]);
+          if (MASK) {
+            const int q = qb * 32 + 16 * t + 8 * hi + 4 * v4 + e;
+            const bool ok = (q >= krel) && (q < qlim);
+            p = ok ? p : 0.f;
+            ds = ok ? ds : 0.f;
+          }
+          sacc[r] = p;
+          pacc[r] = ds;
+        }
+      const bf16x8 pf = pack8(sacc, 8 * t), dsf = pack8(pacc, 8 * t);
+      if (t == 0) request(1);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int xb = 0; xb < 2; ++xb) {
+        dvacc[xb] = mfma32(dotf[t][xb], pf, dvacc[xb]);
+        dkacc[xb] = mfma32(qtf[t][xb], dsf, dkacc[xb]);
+      }
+    }
+  }
+}
+
+__global__ __launch_bounds__(256, 2) void attn_bwd_dkv3_kernel(const bf16* __restrict__ qkv, const bf16* __restrict__ dout,
+                                                               const float* __restrict__ lse, const float* __restrict__ delta,
+                                                               const bf16* __restrict__ qt_, const bf16* __restrict__ dot_,
+                                                               bf16* __restrict__ dqkv, int S, int Sp, int H, float scale,
+                                                               int BH, int nkt, const float* __restrict__ cos_t,
+                                                               const float* __restrict__ sin_t) {
+  constexpr int STG = DKV_STAGE;  // [Q | dO | Q^T | dO^T | lse (256 B of a KiB) | delta (256 B of a KiB)]
+  extern __shared__ __attribute__((aligned(16))) char smem[];  // 2 stages
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  int bh_, tile_;
+  if (!attn_work(BH, nkt, bh_, tile_)) return;
+  const int64_t bh = bh_;
+  const int64_t b = bh / H;
+  const int h = (int)(bh - b * H);
+  const int64_t D = (int64_t)H * HD, D3 = 3 * D;
+  const int k0 = tile_ * 128;
+  const int kw0 = k0 + wave * 32;
+  const int li = lane & 31, hi = lane >> 5;
+  const int krow = kw0 + li;
+  const int kld = (krow < S) ? krow : S - 1;
+  const float sc = scale * LOG2E;
+
+  const bf16* qbase = qkv + b * S * D3 + (int64_t)h * HD;
+  const bf16* dobase = dout + b * S * D + (int64_t)h * HD;
+  const bf16* qtbase = qt_ + bh * HD * Sp;
+  const bf16* dotbase = dot_ + bh * HD * Sp;
+  const float* lse_b = lse + bh * Sp;
+  const float* delta_b = delta + bh * Sp;
+
+  bf16x8 kf[4], vf[4];
+  {
+    const bf16* kp = qkv + (b * S + kld) * D3 + D + (int64_t)h * HD + 8 * hi;
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      kf[s] = *reinterpret_cast<const bf16x8*>(kp + 16 * s);
+      vf[s] = *reinterpret_cast<const bf16x8*>(kp + D + 16 * s);
+    }
+  }
+  f32x16 dkacc[2] = {zero16(), zero16()}, dvacc[2] = {zero16(), zero16()};
+  int foff[4];
+  {
+    const int pli = pi32(li);
+#pragma unroll
+    for (int s = 0; s < 4; ++s) foff[s] = lds_tile_off(pli, 2 * s + hi);
+  }
+  const int qt_first = k0 / 64, qt_last = (S - 1) / 64;
+
+  auto stage_all = [&](int qt, char* dst) {  // (see attn_bwd_dkv_kernel)
+    stage64u(qbase, (int)D3, qt * 64, S - 1, 0, dst, wave, lane);
+    stage64u(dobase, (int)D, qt * 64, S - 1, 0, dst + TILE64, wave, lane);
+    stage64u(qtbase, Sp, 0, HD - 1, qt * 64, dst + 2 * TILE64, wave, lane);
+    stage64u(dotbase, Sp, 0, HD - 1, qt * 64, dst + 3 * TILE64, wave, lane);
+    if (wave < 2) {
+      const float* base = (wave == 0 ? lse_b : delta_b) + (int64_t)qt * 64;
+      const unsigned l15 = (unsigned)(lane & 15);
+      glds16(base + 4 * l15, dst + 4 * TILE64 + wave * 1024);
+    }
+  };
+  if (qt_first <= qt_last) stage_all(qt_first, smem);
+#pragma unroll
+  for (int s = 0; s < 4; ++s) {
+    asm volatile("" : "+v"(kf[s]));
+    asm volatile("" : "+v"(vf[s]));
+  }
+  __syncthreads();
+  // This wave's query tiles, in order: n_skip tiles entirely before its keys (nothing to compute), ONE tile crossing its
+  // diagonal (tile a = kw0 / 64; masked), the full tiles up to S / 64, and a ragged last tile (masked; S % 64 != 0).
+  // Counted loops with one body each: with the class tests inside the loop conditions hipcc rotated the loops and copied
+  // all four accumulators in and out on every tile.
+  const int nT = qt_last - qt_first + 1;
+  const int a = kw0 >> 6;
+  int n_skip = a - qt_first;
+  if (n_skip > nT) n_skip = nT;
+  const int n_mask = (a <= qt_last) ? 1 : 0;
+  int n_full = ((S >> 6) < qt_last + 1 ? (S >> 6) : qt_last + 1) - (a + 1);
+  if (n_full < 0) n_full = 0;
+  const int n_tail = nT - n_skip - n_mask - n_full;
+  int qt = qt_first;
+  auto head = [&](int q) {
+    if (q + 1 <= qt_last) stage_all(q + 1, smem + (((q - qt_first) & 1) ^ 1) * STG);
+    return smem + ((q - qt_first) & 1) * STG;
+  };
+  for (int i = 0; i < n_skip; ++i, ++qt) {
+    head(qt);
+    __syncthreads();
+  }
+  if (n_mask) {
+    const char* cur = head(qt);
+    dkv3_tile<true>(cur, cur + TILE64, cur + 2 * TILE64, cur + 3 * TILE64, cur + 4 * TILE64, foff, kf, vf, dkacc, dvacc, hi,
+                    krow - qt * 64, S - qt * 64, sc);
+    __syncthreads();
+    ++qt;
+  }
+  for (int i = 0; i < n_full; ++i, ++qt) {
+    const char* cur = head(qt);
+    dkv3_tile<false>(cur, cur + TILE64, cur + 2 * TILE64, cur + 3 * TILE64, cur + 4 * TILE64, foff, kf, vf, dkacc, dvacc, hi, 0,
+                     64, sc);
+    __syncthreads();
+  }
+  if (n_tail > 0) {
+    const char* cur = head(qt);
+    dkv3_tile<true>(cur, cur + TILE64, cur + 2 * TILE64, cur + 3 * TILE64, cur + 4 * TILE64, foff, kf, vf, dkacc, dvacc, hi,
+                    krow - qt * 64, S - qt * 64, sc);
+    __syncthreads();
+  }
+  if (krow < S) {
+    bf16* krow_out = dqkv + (b * S + krow) * D3 + D + (int64_t)h * HD;
+    store_grad_row(krow_out, dkacc, scale, hi, cos_t, sin_t, krow);
+    store_grad_row(krow_out + D, dvacc, 1.f, hi, nullptr, nullptr, 0);
+  }
+}
+
+int mh_attn_fwd_mfma3(const void* qkv, const void* vt, void* o, float* lse, int64_t B, int64_t S, int H, float scale,
+                      hipStream_t st) {
+  MH_REQUIRE(S < (1 << 24), "attn_fwd: sequence too long");
+  const int64_t Sp = (S + 63) / 64 * 64;
+  const int nt = (int)((S + 127) / 128), BH = (int)(B * H);
+  const unsigned grid = (unsigned)(nt * 8 * ((BH + 7) / 8));
+  if (g_attn_v3_wps == 2)
+    attn_fwd3_kernel<2><<<grid, 256, 4 * TILE64, st>>>((const bf16*)qkv, (const bf16*)vt, (bf16*)o, lse, (int)S, (int)Sp, H,
+                                                     scale * LOG2E, BH, nt);
+  else
+    attn_fwd3_kernel<3><<<grid, 256, 4 * TILE64, st>>>((const bf16*)qkv, (const bf16*)vt, (bf16*)o, lse, (int)S, (int)Sp, H,
+                                                     scale * LOG2E, BH, nt);
+  MH_LAUNCH_CHECK();
+  return MH_OK;
+}
+
+int mh_attn_bwd_mfma3(const void* qkv, const void* dout, const float* lse, const float* delta, const void* qt, const void* kt,
+                      const void* dot, void* dqkv, int64_t B, int64_t S, int H, float scale, const float* cos_t,
+                      const float* sin_t, int which /* bit 1: dQ, bit 2: dK/dV */, hipStream_t st) {
+  const int64_t Sp = (S + 63) / 64 * 64;
+  const int nt = (int)((S + 127) / 128), BH = (int)(B * H);
+  const unsigned grid = (unsigned)(nt * 8 * ((BH + 7) / 8));
+  if (which & 2) {
+    if (g_attn_v3_wps == 3)
+      attn_bwd_dq3_kernel<3><<<grid, 256, 6 * TILE64, st>>>((const bf16*)qkv, (const bf16*)dout, lse, delta, (const bf16*)kt,
+                                                         (bf16*)dqkv, (int)S, (int)Sp, H, scale, BH, nt, cos_t, sin_t);
+    else
+      attn_bwd_dq3_kernel<2><<<grid, 256, 6 * TILE64, st>>>((const bf16*)qkv, (const bf16*)dout, lse, delta, (const bf16*)kt,
+                                                         (bf16*)dqkv, (int)S, (int)Sp, H, scale, BH, nt, cos_t, sin_t);
+    MH_LAUNCH_CHECK();
+  }
+  if (which & 4) {
+    attn_bwd_dkv3_kernel<<<grid, 256, 2 * DKV_STAGE, st>>>((const bf16*)qkv, (const bf16*)dout, lse, delta, (const bf16*)qt,
+                                                         (const bf16*)dot, (bf16*)dqkv, (int)S, (int)Sp, H, scale, BH, nt, cos_t,
+                                                         sin_t);
+    MH_LAUNCH_CHECK();
+  }
+  return MH_OK;
+}

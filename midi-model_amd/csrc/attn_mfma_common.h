@@ -1,0 +1,108 @@
+// Helpers shared by the event-level MFMA attention kernels (attention_mfma.hip, attention_mfma3.hip): the 32x32x16
+// bf16 MFMA wrapper, the LDS-DMA tile staging, the gradient-row store with the RoPE transpose, the XCD-aware work order.
+#pragma once
+#include "common.h"
+
+constexpr int HD = 64;
+constexpr int TILE64 = 64 * 128;  // bytes
+constexpr int DKV_STAGE = 4 * TILE64 + 2048;  // bytes of one stage of the dK/dV kernel (4 tiles + 1 KiB lse + 1 KiB delta)
+constexpr float LOG2E = 1.4426950408889634f;
+constexpr float RESCALE_THR = 4.0f;  // a row's reference max may lag its true max by a factor <= 2^4
+
+__device__ inline f32x16 mfma32(const bf16x8& a, const bf16x8& b, f32x16 c) {
+  return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+}
+__device__ inline f32x16 zero16() {
+  f32x16 z;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) z[i] = 0.f;
+  return z;
+}
+__device__ inline bf16x8 lds_frag(const char* tile, int row, int chunk) {
+  return *reinterpret_cast<const bf16x8*>(tile + lds_tile_off(row, chunk));
+}
+__device__ inline bf16x8 pack8(const f32x16& v, int base) {
+  bf16x8 o;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) o[e] = (bf16)v[base + e];
+  return o;
+}
+__device__ inline float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }  // raw v_exp_f32
+// register r of lane-half hi <-> reduction index (within a 32-block) 16*(r>>3) + 8*hi + (r&7)
+__device__ inline int reg_index(int r, int hi) { return 16 * (r >> 3) + 8 * hi + (r & 7); }
+
+// stage a 64-row x 64-col bf16 tile: rows row0.. (clamped to row_clamp), columns col0..col0+63
+__device__ inline void stage64(const bf16* __restrict__ base, int64_t ld, int64_t row0, int64_t row_clamp, int64_t col0,
+                               char* lds_tile, int wave, int lane) {
+  const int rsub = lane >> 3, pc = lane & 7;
+#pragma unroll
+  for (int it = 0; it < 2; ++it) {
+    const int g8 = wave + 4 * it;
+    const int r = g8 * 8 + rsub;
+    const int c = pc ^ ((r >> 1) & 7);
+    int64_t grow = row0 + r;
+    if (grow > row_clamp) grow = row_clamp;
+    glds16(base + grow * ld + col0 + c * 8, lds_tile + g8 * 1024);
+  }
+}
+
+// The same with a wave-uniform 64-bit base and a 32-bit per-lane element offset (all operands of one (batch, head) panel
+// lie within 2^31 elements of its base): the LDS-DMA then takes its address as SGPR pair + one VGPR instead of a 64-bit
+// VGPR pair per request, which is what kept a dozen address registers alive across the tile loops of the first form.
+__device__ inline void stage64u(const bf16* __restrict__ base, int ld, int row0, int row_clamp, int col0, char* lds_tile,
+                                int wave, int lane) {
+  const int rsub = lane >> 3, pc = lane & 7;
+#pragma unroll
+  for (int it = 0; it < 2; ++it) {
+    const int g8 = wave + 4 * it;
+    const int r = g8 * 8 + rsub;
+    const int c = pc ^ ((r >> 1) & 7);
+    int grow = row0 + r;
+    grow = grow > row_clamp ? row_clamp : grow;
+    const unsigned off = (unsigned)(grow * ld + col0 + c * 8);
+    glds16(base + off, lds_tile + g8 * 1024);
+  }
+}
+
+// Store one lane's share of a 64-wide gradient row (acc[hb][16]: elements hb*32 + 16*r8 + 8*hi + e), optionally through
+// the transpose of the RoPE rotation at position `pos` (the gradient with respect to the unrotated projection): the
+// partners d and d + 32 are acc[0][.] and acc[1][.] of the same lane.  Roundings as the separate pass it replaces
+// (mh_rope with dir = -1 on the stored bf16 gradient; cos/sin rounded to bf16, modeling_llama.py:126).
+__device__ inline void store_grad_row(bf16* orow, const f32x16 (&acc)[2], float scale, int hi, const float* cos_t,
+                                      const float* sin_t, int pos) {
+#pragma unroll
+  for (int r8 = 0; r8 < 2; ++r8) {
+    bf16x8 v0, v1;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      v0[e] = (bf16)(acc[0][8 * r8 + e] * scale);
+      v1[e] = (bf16)(acc[1][8 * r8 + e] * scale);
+    }
+    if (cos_t != nullptr) {
+      const int i0 = 16 * r8 + 8 * hi;
+      const f32x4 c0 = *reinterpret_cast<const f32x4*>(cos_t + pos * 32 + i0), c1 = *reinterpret_cast<const f32x4*>(cos_t + pos * 32 + i0 + 4);
+      const f32x4 s0 = *reinterpret_cast<const f32x4*>(sin_t + pos * 32 + i0), s1 = *reinterpret_cast<const f32x4*>(sin_t + pos * 32 + i0 + 4);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const float c = (float)(bf16)(e < 4 ? c0[e] : c1[e - 4]), sn = -(float)(bf16)(e < 4 ? s0[e] : s1[e - 4]);
+        const float x1 = (float)v0[e], x2 = (float)v1[e];
+        v0[e] = (bf16)(x1 * c - x2 * sn);
+        v1[e] = (bf16)(x2 * c + x1 * sn);
+      }
+    }
+    *reinterpret_cast<bf16x8*>(orow + 16 * r8 + 8 * hi) = v0;
+    *reinterpret_cast<bf16x8*>(orow + 32 + 16 * r8 + 8 * hi) = v1;
+  }
+}
+
+// Work assignment.  The dispatcher places workgroup b on XCD b % 8 (each XCD has a private 4 MiB L2), so a 1-D
+// grid is decoded as  xcd = b & 7, i = b >> 3, head = (i / ntile) * 8 + xcd, tile = i % ntile : consecutive
+// workgroups of one XCD walk the tiles of ONE (batch, head) pair, whose K/V (or Q/dO) panels then stay in that
+// XCD's L2 instead of being re-fetched (r01 PMC with the (tile, head) 2-D grid: L2 hit rate 34 % fwd, 14 % dK/dV).
+__device__ inline bool attn_work(int BH, int ntile, int& bh, int& tile) {
+  const int lin = blockIdx.x, xcd = lin & 7, i = lin >> 3;
+  const int g = i / ntile;
+  bh = g * 8 + xcd;
+  tile = i - g * ntile;
+  return bh < BH;
+}

@@ -327,6 +327,10 @@ def attn_fwd(qkv, o, lse, B: int, S: int, H: int, scale: float):
             set_option("attn_fwd_wps", int(os.environ["MH_ATTN_FWD_WPS"]))
         if "MH_ATTN_FWD_QB" in os.environ:
             set_option("attn_fwd_qb", int(os.environ["MH_ATTN_FWD_QB"]))
+        if "MH_ATTN_V3" in os.environ:  # bits: 1 forward, 2 dQ, 4 dK/dV in the third form (attention_mfma3.hip)
+            set_option("attn_v3", int(os.environ["MH_ATTN_V3"]))
+        if "MH_ATTN_V3_WPS" in os.environ:
+            set_option("attn_v3_wps", int(os.environ["MH_ATTN_V3_WPS"]))
     vt = None
     if qkv.dtype == torch.bfloat16 and ATTN_FWD_FORM == 1:
         Sp = round_up(S, 64)

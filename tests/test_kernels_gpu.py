@@ -281,17 +281,33 @@ def test_rope(ops, dtype, H, hd, S, M):
 
 
 # ------------------------------------------------------------------------------ event-level attention
-@pytest.mark.parametrize("form", [2, 1, 12, 11], ids=["fwd2_trV_ring3", "fwd1_preparedVT", "fwd1_two_qblocks_2wps", "fwd1_two_qblocks_1wps"])
+# form -> (ops.ATTN_FWD_FORM, attn_fwd_qb, attn_fwd_wps, attn_v3 bits, attn_v3_wps)
+ATTN_FORMS = {
+    "v3": (1, 1, 2, 7, 0),                      # third form of all three kernels (the default)
+    "v3_wps2": (1, 1, 2, 7, 2),                 # ... held to two / three waves per SIMD (dQ: wide / narrow fragment batches)
+    "v3_wps3": (1, 1, 2, 7, 3),
+    "fwd1_preparedVT": (1, 1, 2, 0, 0),         # first form of all three kernels
+    "fwd2_trV_ring3": (2, 1, 2, 0, 0),
+    "fwd1_two_qblocks_2wps": (1, 2, 2, 0, 0),
+    "fwd1_two_qblocks_1wps": (1, 2, 1, 0, 0),
+}
+
+
+@pytest.mark.parametrize("form", list(ATTN_FORMS))
 @pytest.mark.parametrize("dtype", DTYPES)
-@pytest.mark.parametrize("B,S,H", [(1, 1, 1), (2, 33, 3), (1, 64, 2), (2, 128, 1), (1, 200, 4), (1, 515, 2), (1, 129, 1), (2, 321, 2)])
+@pytest.mark.parametrize("B,S,H", [(1, 1, 1), (2, 33, 3), (1, 64, 2), (2, 128, 1), (1, 200, 4), (1, 515, 2), (1, 129, 1), (2, 321, 2), (1, 96, 1), (1, 40, 1)])
 def test_attention_fwd_bwd(ops, monkeypatch, form, dtype, B, S, H):
-    """(bf16: both forward structures -- the transpose-read / three-stage-ring kernel and the first one with its prepared
-    V^T copy; fp32 runs the plain verification kernel either way)"""
-    if dtype == torch.float32 and form != 2:
+    """(bf16: every form of the MFMA kernels -- the third form (fragment batches, one loop per tile class), the first form
+    with its prepared V^T copy, the transpose-read / three-stage-ring forward, the two-query-block forward; fp32 runs the
+    plain verification kernel either way)"""
+    if dtype == torch.float32 and form != "v3":
         pytest.skip("fp32 has one forward kernel")
-    monkeypatch.setattr(ops, "ATTN_FWD_FORM", 1 if form >= 10 else form)
-    ops.set_option("attn_fwd_qb", 2 if form >= 10 else 1)
-    ops.set_option("attn_fwd_wps", form - 10 if form >= 10 else 2)
+    fwd_form, qb, wps, v3, v3_wps = ATTN_FORMS[form]
+    monkeypatch.setattr(ops, "ATTN_FWD_FORM", fwd_form)
+    ops.set_option("attn_fwd_qb", qb)
+    ops.set_option("attn_fwd_wps", wps)
+    ops.set_option("attn_v3", v3)
+    ops.set_option("attn_v3_wps", v3_wps)
     D = H * 64
     scale = 64 ** -0.5
     qkv = rnd((B * S, 3 * D), dtype, 18)
@@ -321,6 +337,8 @@ def test_attention_fwd_bwd(ops, monkeypatch, form, dtype, B, S, H):
     assert same > 0.99, f"fused rotation agrees with the separate pass on only {same:.4f} of the elements"
     ops.set_option("attn_fwd_qb", 1)
     ops.set_option("attn_fwd_wps", 2)
+    ops.set_option("attn_v3", 7)
+    ops.set_option("attn_v3_wps", 0)
 
 
 def test_attention_mfma_vs_plain_on_device(ops):
