@@ -564,7 +564,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv3_kernel(const bf16* __res
 
 int mh_attn_fwd_mfma3(const void* qkv, const void* vt, void* o, float* lse, int64_t B, int64_t S, int H, float scale,
                       hipStream_t st) {
-  MH_REQUIRE(S < (1 << 24), "attn_fwd: sequence too long");
+  MH_REQUIRE(S * 3 * H * HD < (int64_t(1) << 31), "attn_fwd: sequence too long (32-bit panel offsets)");
   const int64_t Sp = (S + 63) / 64 * 64;
   const int nt = (int)((S + 127) / 128), BH = (int)(B * H);
   const unsigned grid = (unsigned)(nt * 8 * ((BH + 7) / 8));
@@ -581,6 +581,7 @@ int mh_attn_fwd_mfma3(const void* qkv, const void* vt, void* o, float* lse, int6
 int mh_attn_bwd_mfma3(const void* qkv, const void* dout, const float* lse, const float* delta, const void* qt, const void* kt,
                       const void* dot, void* dqkv, int64_t B, int64_t S, int H, float scale, const float* cos_t,
                       const float* sin_t, int which /* bit 1: dQ, bit 2: dK/dV */, hipStream_t st) {
+  MH_REQUIRE(S * 3 * H * HD < (int64_t(1) << 31), "attn_bwd: sequence too long (32-bit panel offsets)");
   const int64_t Sp = (S + 63) / 64 * 64;
   const int nt = (int)((S + 127) / 128), BH = (int)(B * H);
   const unsigned grid = (unsigned)(nt * 8 * ((BH + 7) / 8));
