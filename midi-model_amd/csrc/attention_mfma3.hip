@@ -22,6 +22,7 @@
 #include "attn_mfma_common.h"
 
 int g_attn_v3 = 7;      // mh_set_option("attn_v3", bits): 1 forward, 2 dQ, 4 dK/dV
+int g_attn_v3_abl = 0;  // mh_set_option("attn_v3_abl", bits): forward with parts left out (timing experiments, see fwd3_tile)
 int g_attn_v3_wps = 0;  // mh_set_option("attn_v3_wps", n): register budget (waves per SIMD) override for A/B runs, 0 = default
 
 __device__ inline bf16x8 ldsv(const char* p) { return *reinterpret_cast<const bf16x8*>(p); }
@@ -36,36 +37,49 @@ __device__ inline float xhalf_max(float v) {  // max with the other wave half's 
 // ---------------------------------------------------------------------------------------------------
 // one 64-key tile for one wave (32 query rows).  foff[s]: this lane's byte offset of fragment s inside a 32-row tile block
 // (row pi32(lane & 31), chunk 2s + hi); the second block of a tile is 4096 bytes further.  qrel = query row - first key.
-template <bool MASK>
+// ABL (timing experiments only, wrong results; tools/bench_attn_forms.py): 1 no v_exp, 2 no row maximum, 4 no P V MFMAs, 8 no
+// Q K^T MFMAs, 16 no LDS fragment reads (register operands instead).
+template <bool MASK, int ABL = 0>
 __device__ inline void fwd3_tile(const char* tK, const char* tV, const int (&foff)[4], const bf16x8 (&qf)[4],
                                  f32x16 (&oacc)[2], float& m, float& l, int hi, int qrel, float sc) {
   bf16x8 kf[2][4];
 #pragma unroll
   for (int s = 0; s < 4; ++s)
 #pragma unroll
-    for (int kb = 0; kb < 2; ++kb) kf[kb][s] = ldsv(tK + foff[s] + kb * 4096);
+    for (int kb = 0; kb < 2; ++kb) kf[kb][s] = (ABL & 16) ? qf[(s + kb) & 3] : ldsv(tK + foff[s] + kb * 4096);
   __builtin_amdgcn_sched_barrier(0);
   f32x16 sacc[2] = {zero16(), zero16()};
+  if (ABL & 8) {
 #pragma unroll
-  for (int s = 0; s < 4; ++s)
+    for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
-    for (int kb = 0; kb < 2; ++kb) sacc[kb] = mfma32(kf[kb][s], qf[s], sacc[kb]);  // two independent accumulator chains
+      for (int r = 0; r < 16; ++r) sacc[kb][r] = (float)kf[kb][r & 3][r >> 2] * (float)qf[r & 3][kb];
+  } else {
+#pragma unroll
+    for (int s = 0; s < 4; ++s)
+#pragma unroll
+      for (int kb = 0; kb < 2; ++kb) sacc[kb] = mfma32(kf[kb][s], qf[s], sacc[kb]);  // two independent accumulator chains
+  }
   bf16x8 vf[4][2];  // the V^T fragments of the whole tile: in flight under the softmax arithmetic
 #pragma unroll
   for (int t = 0; t < 4; ++t)
 #pragma unroll
-    for (int db = 0; db < 2; ++db) vf[t][db] = ldsv(tV + foff[t] + db * 4096);
+    for (int db = 0; db < 2; ++db) vf[t][db] = (ABL & 16) ? qf[(t + db) & 3] : ldsv(tV + foff[t] + db * 4096);
   __builtin_amdgcn_sched_barrier(0);
   float mx = -INFINITY;
+  if (ABL & 2) {
+    mx = m > -1e30f ? m / sc : sacc[0][0];
+  } else {
 #pragma unroll
-  for (int kb = 0; kb < 2; ++kb)
+    for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      if (MASK) {
-        if (kb * 32 + reg_index(r, hi) > qrel) sacc[kb][r] = -INFINITY;
+      for (int r = 0; r < 16; ++r) {
+        if (MASK) {
+          if (kb * 32 + reg_index(r, hi) > qrel) sacc[kb][r] = -INFINITY;
+        }
+        mx = fmaxf(mx, sacc[kb][r]);
       }
-      mx = fmaxf(mx, sacc[kb][r]);
-    }
+  }
   mx = xhalf_max(mx) * sc;  // running max kept in scaled (log2) units
   // A row moves its reference maximum only when its true maximum grew by more than RESCALE_THR (log2 units): until then
   // its probabilities may reach 2^THR instead of 1, and l / O / lse stay mutually consistent (exact maths; only the bf16
@@ -83,7 +97,11 @@ __device__ inline void fwd3_tile(const char* tK, const char* tV, const int (&fof
   float ps0 = 0.f, ps1 = 0.f;  // (two partial sums: half the length of the dependent add chain)
 #pragma unroll
   for (int r = 0; r < 16; ++r) {
-    const float p0 = fast_exp2(__builtin_fmaf(sacc[0][r], sc, -m)), p1 = fast_exp2(__builtin_fmaf(sacc[1][r], sc, -m));
+    float p0 = __builtin_fmaf(sacc[0][r], sc, -m), p1 = __builtin_fmaf(sacc[1][r], sc, -m);
+    if (!(ABL & 1)) {
+      p0 = fast_exp2(p0);
+      p1 = fast_exp2(p1);
+    }
     sacc[0][r] = p0;
     sacc[1][r] = p1;
     ps0 += p0;
@@ -93,12 +111,17 @@ __device__ inline void fwd3_tile(const char* tK, const char* tV, const int (&fof
 #pragma unroll
   for (int t = 0; t < 4; ++t) {
     const bf16x8 pf = pack8(sacc[t >> 1], 8 * (t & 1));
+    if (ABL & 4) {
 #pragma unroll
-    for (int db = 0; db < 2; ++db) oacc[db] = mfma32(vf[t][db], pf, oacc[db]);
+      for (int db = 0; db < 2; ++db) oacc[db][t] += (float)pf[db] * (float)vf[t][db][0];
+    } else {
+#pragma unroll
+      for (int db = 0; db < 2; ++db) oacc[db] = mfma32(vf[t][db], pf, oacc[db]);
+    }
   }
 }
 
-template <int WPS>
+template <int WPS, int ABL = 0>
 __global__ __launch_bounds__(256, WPS) void attn_fwd3_kernel(const bf16* __restrict__ qkv, const bf16* __restrict__ vt,
                                                           bf16* __restrict__ o, float* __restrict__ lse, int S, int Sp, int H,
                                                           float sc /* scale*log2(e) */, int BH, int nqt) {
@@ -160,13 +183,13 @@ __global__ __launch_bounds__(256, WPS) void attn_fwd3_kernel(const bf16* __restr
   for (; kt < n_full; ++kt) {
     stage_next(kt);
     const char* cur = smem + (kt & 1) * 2 * TILE64;
-    fwd3_tile<false>(cur, cur + TILE64, foff, qf, oacc, m, l, hi, 0, sc);
+    fwd3_tile<false, ABL>(cur, cur + TILE64, foff, qf, oacc, m, l, hi, 0, sc);
     __syncthreads();
   }
   if (kt <= kt_last) {
     stage_next(kt);
     const char* cur = smem + (kt & 1) * 2 * TILE64;
-    fwd3_tile<true>(cur, cur + TILE64, foff, qf, oacc, m, l, hi, qrow - kt * 64, sc);
+    fwd3_tile<true, ABL>(cur, cur + TILE64, foff, qf, oacc, m, l, hi, qrow - kt * 64, sc);
     __syncthreads();
     ++kt;
   }
@@ -568,6 +591,20 @@ int mh_attn_fwd_mfma3(const void* qkv, const void* vt, void* o, float* lse, int6
   const int64_t Sp = (S + 63) / 64 * 64;
   const int nt = (int)((S + 127) / 128), BH = (int)(B * H);
   const unsigned grid = (unsigned)(nt * 8 * ((BH + 7) / 8));
+#define MH_ABL(A)                                                                                                          \
+  case A:                                                                                                                  \
+    attn_fwd3_kernel<3, A><<<grid, 256, 4 * TILE64, st>>>((const bf16*)qkv, (const bf16*)vt, (bf16*)o, lse, (int)S, (int)Sp, H, \
+                                                          scale * LOG2E, BH, nt);                                          \
+    break;
+  if (g_attn_v3_abl != 0) {
+    switch (g_attn_v3_abl) {
+      MH_ABL(1) MH_ABL(2) MH_ABL(3) MH_ABL(4) MH_ABL(8) MH_ABL(12) MH_ABL(16) MH_ABL(28) MH_ABL(31)
+      default: MH_REQUIRE(false, "attn_v3_abl: not instantiated");
+    }
+    MH_LAUNCH_CHECK();
+    return MH_OK;
+  }
+#undef MH_ABL
   if (g_attn_v3_wps == 2)
     attn_fwd3_kernel<2><<<grid, 256, 4 * TILE64, st>>>((const bf16*)qkv, (const bf16*)vt, (bf16*)o, lse, (int)S, (int)Sp, H,
                                                      scale * LOG2E, BH, nt);
