@@ -26,6 +26,21 @@ int g_attn_v3_abl = 0;  // mh_set_option("attn_v3_abl", bits): forward with part
 int g_attn_v3_wps = 0;  // mh_set_option("attn_v3_wps", n): register budget (waves per SIMD) override for A/B runs, 0 = default
 
 __device__ inline bf16x8 ldsv(const char* p) { return *reinterpret_cast<const bf16x8*>(p); }
+// eight consecutive accumulator registers -> one bf16 operand fragment, as four explicit two-element conversions (each one
+// v_cvt_pk_bf16_f32): from eight single casts hipcc assembled the dS fragments (products of v_pk_mul_f32) out of single
+// conversions, 6 v_mov + 3 v_alignbit per fragment.  (Spelling the instruction in inline asm instead is wrong: hipcc does not
+// pad the VALU-write -> MFMA-operand hazard behind an asm statement, cdna_hip_programming.md 5.7 -- NaNs on the device.)
+typedef __attribute__((ext_vector_type(2))) float f32x2;
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
+__device__ inline bf16x8 pack8_pk(const f32x16& v, int base) {
+  union {
+    bf16x8 v;
+    bf16x2 h[4];
+  } r;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) r.h[i] = __builtin_convertvector(f32x2{v[base + 2 * i], v[base + 2 * i + 1]}, bf16x2);
+  return r.v;
+}
 __device__ inline float xhalf_max(float v) {  // max with the other wave half's value (lane ^ 32), VALU only
   const int iv = __float_as_int(v);
   const auto pr = __builtin_amdgcn_permlane32_swap(iv, iv, false, false);
@@ -110,7 +125,7 @@ __device__ inline void fwd3_tile(const char* tK, const char* tV, const int (&fof
   l += ps0 + ps1;
 #pragma unroll
   for (int t = 0; t < 4; ++t) {
-    const bf16x8 pf = pack8(sacc[t >> 1], 8 * (t & 1));
+    const bf16x8 pf = pack8_pk(sacc[t >> 1], 8 * (t & 1));
     if (ABL & 4) {
 #pragma unroll
       for (int db = 0; db < 2; ++db) oacc[db][t] += (float)pf[db] * (float)vf[t][db][0];
@@ -221,15 +236,20 @@ __global__ __launch_bounds__(256, WPS) void attn_fwd3_kernel(const bf16* __restr
 // (two waves per SIMD: 256 registers); otherwise block by block (three waves per SIMD).
 template <bool MASK, bool WIDE>
 __device__ inline void dq3_tile(const char* tK, const char* tV, const char* tKT, const int (&foff)[4], const bf16x8 (&qf)[4],
-                                const bf16x8 (&dof)[4], f32x16 (&dqacc)[2], int hi, int qrel, float sc, float lse2, float dl) {
-  auto softmax_grad = [&](f32x16& sacc, const f32x16& pacc, int kb) {  // S -> dS (unscaled), in place
+                                const bf16x8 (&dof)[4] /* -dO */, f32x16 (&dqacc)[2], int hi, int qrel, float sc, float lse2,
+                                const f32x16& dlt /* the row's delta in all 16 registers */) {
+  // delta goes into the matrix pipe: the dP chain starts from C = delta and multiplies the NEGATED dO fragments, so its
+  // result is delta - dP and dS comes out negated with one multiply per element (the subtraction was 32 VALU issue slots
+  // per tile: tools/mfma_valu_probe.hip -- a SIMD issues one VALU per ~4 cycles whatever the number of waves); the kernel
+  // stores -(-dQ).
+  auto softmax_grad = [&](f32x16& sacc, const f32x16& pacc, int kb) {  // S -> -dS (unscaled), in place
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       float p = fast_exp2(__builtin_fmaf(sacc[r], sc, -lse2));
       if (MASK) {
         if (kb * 32 + reg_index(r, hi) > qrel) p = 0.f;
       }
-      sacc[r] = p * (pacc[r] - dl);
+      sacc[r] = p * pacc[r];
     }
   };
   if (WIDE) {
@@ -242,13 +262,13 @@ __device__ inline void dq3_tile(const char* tK, const char* tV, const char* tKT,
         vf[kb][s] = ldsv(tV + foff[s] + kb * 4096);
       }
     __builtin_amdgcn_sched_barrier(0);
-    f32x16 sacc[2] = {zero16(), zero16()}, pacc[2] = {zero16(), zero16()};
+    f32x16 sacc[2] = {zero16(), zero16()}, pacc[2];
 #pragma unroll
     for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
       for (int s = 0; s < 4; ++s) {
         sacc[kb] = mfma32(kf[kb][s], qf[s], sacc[kb]);
-        pacc[kb] = mfma32(vf[kb][s], dof[s], pacc[kb]);
+        pacc[kb] = mfma32(vf[kb][s], dof[s], s == 0 ? dlt : pacc[kb]);
       }
     bf16x8 ktf[4][2];  // K^T fragments of the whole tile: c = 2 kb + t <-> chunk 4 kb + 2 t + hi
 #pragma unroll
@@ -261,7 +281,7 @@ __device__ inline void dq3_tile(const char* tK, const char* tV, const char* tKT,
       softmax_grad(sacc[kb], pacc[kb], kb);
 #pragma unroll
       for (int t = 0; t < 2; ++t) {
-        const bf16x8 dsf = pack8(sacc[kb], 8 * t);
+        const bf16x8 dsf = pack8_pk(sacc[kb], 8 * t);
 #pragma unroll
         for (int hb = 0; hb < 2; ++hb) dqacc[hb] = mfma32(ktf[2 * kb + t][hb], dsf, dqacc[hb]);
       }
@@ -276,11 +296,11 @@ __device__ inline void dq3_tile(const char* tK, const char* tV, const char* tKT,
         vf[s] = ldsv(tV + foff[s] + kb * 4096);
       }
       __builtin_amdgcn_sched_barrier(0);
-      f32x16 sacc = zero16(), pacc = zero16();
+      f32x16 sacc = zero16(), pacc;
 #pragma unroll
       for (int s = 0; s < 4; ++s) {
         sacc = mfma32(kf[s], qf[s], sacc);
-        pacc = mfma32(vf[s], dof[s], pacc);
+        pacc = mfma32(vf[s], dof[s], s == 0 ? dlt : pacc);
       }
       bf16x8 ktf[2][2];
 #pragma unroll
@@ -291,7 +311,7 @@ __device__ inline void dq3_tile(const char* tK, const char* tV, const char* tKT,
       softmax_grad(sacc, pacc, kb);
 #pragma unroll
       for (int t = 0; t < 2; ++t) {
-        const bf16x8 dsf = pack8(sacc, 8 * t);
+        const bf16x8 dsf = pack8_pk(sacc, 8 * t);
 #pragma unroll
         for (int hb = 0; hb < 2; ++hb) dqacc[hb] = mfma32(ktf[t][hb], dsf, dqacc[hb]);
       }
@@ -333,11 +353,16 @@ __global__ __launch_bounds__(256, WPS) void attn_bwd_dq3_kernel(const bf16* __re
 #pragma unroll
     for (int s = 0; s < 4; ++s) {
       qf[s] = *reinterpret_cast<const bf16x8*>(qp + 16 * s);
-      dof[s] = *reinterpret_cast<const bf16x8*>(dp + 16 * s);
+      const bf16x8 d = *reinterpret_cast<const bf16x8*>(dp + 16 * s);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) dof[s][e] = -d[e];  // (see dq3_tile)
     }
   }
   float lse2 = lse[bh * Sp + qld] * LOG2E;
-  float dl = delta[bh * Sp + qld];
+  const float dl = delta[bh * Sp + qld];
+  f32x16 dlt;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) dlt[r] = dl;
   f32x16 dqacc[2] = {zero16(), zero16()};
 
   int last_q = q0 + 127;
@@ -362,7 +387,7 @@ __global__ __launch_bounds__(256, WPS) void attn_bwd_dq3_kernel(const bf16* __re
     asm volatile("" : "+v"(dof[s]));
   }
   asm volatile("" : "+v"(lse2));
-  asm volatile("" : "+v"(dl));
+  asm volatile("" : "+v"(dlt));
   __syncthreads();
   auto stage_next = [&](int kt) {
     if (kt + 1 <= kt_last) {
@@ -377,13 +402,13 @@ __global__ __launch_bounds__(256, WPS) void attn_bwd_dq3_kernel(const bf16* __re
   for (; kt < n_full; ++kt) {
     stage_next(kt);
     const char* cur = smem + (kt & 1) * 3 * TILE64;
-    dq3_tile<false, WIDE>(cur, cur + TILE64, cur + 2 * TILE64, foff, qf, dof, dqacc, hi, 0, sc, lse2, dl);
+    dq3_tile<false, WIDE>(cur, cur + TILE64, cur + 2 * TILE64, foff, qf, dof, dqacc, hi, 0, sc, lse2, dlt);
     __syncthreads();
   }
   if (kt <= kt_last) {
     stage_next(kt);
     const char* cur = smem + (kt & 1) * 3 * TILE64;
-    dq3_tile<true, WIDE>(cur, cur + TILE64, cur + 2 * TILE64, foff, qf, dof, dqacc, hi, qrow - kt * 64, sc, lse2, dl);
+    dq3_tile<true, WIDE>(cur, cur + TILE64, cur + 2 * TILE64, foff, qf, dof, dqacc, hi, qrow - kt * 64, sc, lse2, dlt);
     __syncthreads();
     ++kt;
   }
@@ -393,7 +418,7 @@ __global__ __launch_bounds__(256, WPS) void attn_bwd_dq3_kernel(const bf16* __re
   }
   if (qrow < S) {
     bf16* orow = dqkv + (b * S + qrow) * D3 + (int64_t)h * HD;
-    store_grad_row(orow, dqacc, scale, hi, cos_t, sin_t, qrow);
+    store_grad_row(orow, dqacc, -scale, hi, cos_t, sin_t, qrow);  // (the accumulator holds -dQ)
   }
 }
 
@@ -416,17 +441,28 @@ __device__ inline void dkv3_tile(const char* tQ, const char* tDO, const char* tQ
       dof[s] = ldsv(tDO + foff[s] + qb * 4096);
     }
     __builtin_amdgcn_sched_barrier(0);
-    f32x16 sacc = zero16(), pacc = zero16();
+    // delta goes into the matrix pipe (see dq3_tile): the dP chain starts from C = the block's 16 delta values as they lie
+    // in the stage (register r <-> query qb*32 + 16 (r>>3) + 8 hi + (r&7): four 16-byte reads) and multiplies the NEGATED V
+    // fragments, so it delivers delta - dP; dS and dK come out negated (the kernel stores -(-dK)), dV is untouched.
+    f32x16 pacc;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const f32x4 d4 = *reinterpret_cast<const f32x4*>(tLD + 1024 + (qb * 32 + 16 * (i >> 1) + 8 * hi + 4 * (i & 1)) * 4);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) pacc[4 * i + e] = d4[e];
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    f32x16 sacc = zero16();
 #pragma unroll
     for (int s = 0; s < 4; ++s) {
       sacc = mfma32(qf[s], kf[s], sacc);
       pacc = mfma32(dof[s], vf[s], pacc);
     }
     // The block's second half runs in two steps of 16 queries (t): the dO^T / Q^T fragments (chunk 4 qb + 2 t + hi of row
-    // block xb) and the 8 lse / 8 delta values of step t are requested one step ahead -- step 0's under the MFMAs above,
-    // step 1's under the four MFMAs of step 0 -- so that 16 + 16 registers hold them instead of 64.
+    // block xb) and the 8 lse values of step t are requested one step ahead -- step 0's under the MFMAs above, step 1's
+    // under the four MFMAs of step 0 -- so that 16 + 8 registers hold them instead of 64.
     bf16x8 dotf[2][2], qtf[2][2];  // [t][xb]
-    f32x4 la[2][2], dd[2][2];      // [t][v4]: queries qb*32 + 16 t + 8 hi + 4 v4 .. +3
+    f32x4 la[2][2];                // [t][v4]: queries qb*32 + 16 t + 8 hi + 4 v4 .. +3
     auto request = [&](int t) {
 #pragma unroll
       for (int xb = 0; xb < 2; ++xb) {
@@ -437,7 +473,6 @@ __device__ inline void dkv3_tile(const char* tQ, const char* tDO, const char* tQ
       for (int v4 = 0; v4 < 2; ++v4) {
         const int qq = qb * 32 + 16 * t + 8 * hi + 4 * v4;
         la[t][v4] = *reinterpret_cast<const f32x4*>(tLD + qq * 4);
-        dd[t][v4] = *reinterpret_cast<const f32x4*>(tLD + 1024 + qq * 4);
       }
     };
     request(0);
@@ -447,10 +482,10 @@ __device__ inline void dkv3_tile(const char* tQ, const char* tDO, const char* tQ
 #pragma unroll
       for (int v4 = 0; v4 < 2; ++v4)
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {  // S -> P, dP -> dS (unscaled), in place
+        for (int e = 0; e < 4; ++e) {  // S -> P, delta - dP -> -dS (unscaled), in place
           const int r = 8 * t + 4 * v4 + e;
           float p = fast_exp2(__builtin_fmaf(sacc[r], sc, -la[t][v4][e] * LOG2E));
-          float ds = p * (pacc[r] - dd[t][v4][e]);
+          float ds = p * pacc[r];
           if (MASK) {
             const int q = qb * 32 + 16 * t + 8 * hi + 4 * v4 + e;
             const bool ok = (q >= krel) && (q < qlim);
@@ -460,7 +495,7 @@ __device__ inline void dkv3_tile(const char* tQ, const char* tDO, const char* tQ
           sacc[r] = p;
           pacc[r] = ds;
         }
-      const bf16x8 pf = pack8(sacc, 8 * t), dsf = pack8(pacc, 8 * t);
+      const bf16x8 pf = pack8_pk(sacc, 8 * t), dsf = pack8_pk(pacc, 8 * t);
       if (t == 0) request(1);
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -508,7 +543,9 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv3_kernel(const bf16* __res
 #pragma unroll
     for (int s = 0; s < 4; ++s) {
       kf[s] = *reinterpret_cast<const bf16x8*>(kp + 16 * s);
-      vf[s] = *reinterpret_cast<const bf16x8*>(kp + D + 16 * s);
+      const bf16x8 v = *reinterpret_cast<const bf16x8*>(kp + D + 16 * s);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) vf[s][e] = -v[e];  // (see dkv3_tile)
     }
   }
   f32x16 dkacc[2] = {zero16(), zero16()}, dvacc[2] = {zero16(), zero16()};
@@ -580,7 +617,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv3_kernel(const bf16* __res
   }
   if (krow < S) {
     bf16* krow_out = dqkv + (b * S + krow) * D3 + D + (int64_t)h * HD;
-    store_grad_row(krow_out, dkacc, scale, hi, cos_t, sin_t, krow);
+    store_grad_row(krow_out, dkacc, -scale, hi, cos_t, sin_t, krow);  // (the accumulator holds -dK)
     store_grad_row(krow_out + D, dvacc, 1.f, hi, nullptr, nullptr, 0);
   }
 }
@@ -623,11 +660,11 @@ int mh_attn_bwd_mfma3(const void* qkv, const void* dout, const float* lse, const
   const int nt = (int)((S + 127) / 128), BH = (int)(B * H);
   const unsigned grid = (unsigned)(nt * 8 * ((BH + 7) / 8));
   if (which & 2) {
-    if (g_attn_v3_wps == 3)
-      attn_bwd_dq3_kernel<3><<<grid, 256, 6 * TILE64, st>>>((const bf16*)qkv, (const bf16*)dout, lse, delta, (const bf16*)kt,
+    if (g_attn_v3_wps == 2)  // (wide fragment batches at two waves per SIMD: measured 1-3 % behind the narrow form at three)
+      attn_bwd_dq3_kernel<2><<<grid, 256, 6 * TILE64, st>>>((const bf16*)qkv, (const bf16*)dout, lse, delta, (const bf16*)kt,
                                                          (bf16*)dqkv, (int)S, (int)Sp, H, scale, BH, nt, cos_t, sin_t);
     else
-      attn_bwd_dq3_kernel<2><<<grid, 256, 6 * TILE64, st>>>((const bf16*)qkv, (const bf16*)dout, lse, delta, (const bf16*)kt,
+      attn_bwd_dq3_kernel<3><<<grid, 256, 6 * TILE64, st>>>((const bf16*)qkv, (const bf16*)dout, lse, delta, (const bf16*)kt,
                                                          (bf16*)dqkv, (int)S, (int)Sp, H, scale, BH, nt, cos_t, sin_t);
     MH_LAUNCH_CHECK();
   }

@@ -341,6 +341,31 @@ def test_attention_fwd_bwd(ops, monkeypatch, form, dtype, B, S, H):
     ops.set_option("attn_v3_wps", 0)
 
 
+@pytest.mark.parametrize("v3", [7, 0], ids=["v3", "first_form"])
+def test_attention_forward_when_the_reference_has_to_move(ops, v3):
+    """Rows whose scores jump by far more than the lazy-rescale threshold between tiles (a few keys late in the sequence
+    are scaled up 8x and 24x: q.k/8 moves by tens to more than a hundred log2 units), plus a first tile of tiny scores."""
+    B, S, H = 1, 640, 2
+    D = H * 64
+    qkv = rnd((B * S, 3 * D), torch.bfloat16, 41)
+    qkv[:, :D] *= 2.0
+    for j in (70, 200, 333):
+        qkv[j, D:2 * D] *= 8.0    # big keys: q.k/8 jumps by tens (log2 units) from one tile to the next
+    qkv[590, D:2 * D] *= 24.0     # ... and by more than 128 for some rows (exp2 against the inherited reference overflows)
+    qkv[:64, D:2 * D] *= 0.01     # first tile: tiny scores
+    Sp = (S + 63) // 64 * 64
+    o_ref, lse_ref = torch.empty((B * S, D), dtype=torch.bfloat16), torch.zeros(B * H * Sp)
+    emu.attn_fwd(qkv, o_ref, lse_ref, B, S, H, 0.125)
+    ops.set_option("attn_v3", v3)
+    o, lse = torch.empty((B * S, D), dtype=torch.bfloat16, device="cuda"), torch.zeros(B * H * Sp, device="cuda")
+    ops.attn_fwd(qkv.cuda(), o, lse, B, S, H, 0.125)
+    ops.set_option("attn_v3", 7)
+    assert torch.isfinite(o.float()).all() and torch.isfinite(lse).all()
+    cmp(o, o_ref, torch.bfloat16, what="attn o (moving reference)")
+    got, want = lse.view(B, H, Sp)[:, :, :S].cpu(), lse_ref.view(B, H, Sp)[:, :, :S]
+    assert ((got - want).abs() <= 1e-4 * want.abs().clamp(min=1.0)).all(), (got - want).abs().max()
+
+
 def test_attention_mfma_vs_plain_on_device(ops):
     """bf16: the MFMA flash kernels against the thread-per-row kernels running on the same device data."""
     from midi_model_amd.lib import lib

@@ -1,0 +1,13 @@
+#!/bin/bash
+# session 2, run 5: fourth form of the attention forward -- parity tests, A/B
+cd "${GRAFT_REPO_ROOT:-/root/repo}"
+mkdir -p gpurun_out
+export TMPDIR=/tmp
+O=gpurun_out
+timeout 600 python -m pytest tests/test_kernels_gpu.py::test_attention_fwd_bwd tests/test_kernels_gpu.py::test_attention_forward_when_the_reference_has_to_move tests/test_kernels_gpu.py::test_attention_mfma_vs_plain_on_device -q -m gpu --tb=short -p no:cacheprovider > $O/s2_5_attn_tests.log 2>&1
+echo "attn tests rc=$?" >> $O/s2_5_attn_tests.log
+tail -n 25 $O/s2_5_attn_tests.log
+MH_ATTN_V3=14 timeout 600 python -m pytest tests/test_parity_long_gpu.py::test_flash_attention_at_benchmarked_length -q -m gpu --tb=short -p no:cacheprovider > $O/s2_5_attn_long.log 2>&1
+tail -n 8 $O/s2_5_attn_long.log
+MH_BENCH_ABLATE=0 timeout 300 python tools/bench_attn_forms.py 2>&1 | grep "fwd" > $O/s2_5_attn_forms.txt
+cat $O/s2_5_attn_forms.txt
