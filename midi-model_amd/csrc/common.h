@@ -56,6 +56,43 @@ template <typename T> __device__ inline T from_f(float x) { return (T)x; }
 // round an fp32 value through T (used where the reference rounds an intermediate to the activation dtype)
 template <typename T> __device__ inline float rnd(float x) { return (float)(T)x; }
 
+// ---- SiLU / sigmoid, one spelling for every kernel that needs them --------------------------------
+// sigmoid(g) = rcp(1 + exp2(-g log2 e)): v_mul, v_exp, v_add, v_rcp.  The IEEE division the plain C++ expression
+// `g / (1.f + __expf(-g))` compiles to is v_div_scale x2, v_rcp, 5 fma/mul, v_div_fmas, v_div_fixup -- eleven VALU issue
+// slots per element, which made the SwiGLU epilogues of the projection GEMMs (64 elements per lane and tile) a fifth of the
+// tile's time (r02, ISA of gemm_pp256_kernel<.., 2>).  v_rcp_f32 is accurate to 1 ulp; results are rounded to the activation
+// dtype right after.  Every kernel uses THESE functions, so fused and unfused paths agree bit for bit.
+// g -> -inf gives 0 * -inf = NaN exactly as the division did; large |g| saturate (exp2 overflow -> rcp(inf) = 0).
+__device__ inline float mh_sigmoid(float g) {
+  return __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(g * -1.4426950408889634f));
+}
+__device__ inline float mh_silu(float g) { return g * mh_sigmoid(g); }
+
+// eight fp32 -> one bf16x8 as four two-element conversions (v_cvt_pk_bf16_f32 each), and back (shift / mask)
+typedef __attribute__((ext_vector_type(2))) float f32x2;
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
+__device__ inline bf16x8 cvt8_bf16(const float (&v)[8]) {
+  union {
+    bf16x8 v;
+    bf16x2 h[4];
+  } r;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) r.h[i] = __builtin_convertvector(f32x2{v[2 * i], v[2 * i + 1]}, bf16x2);
+  return r.v;
+}
+__device__ inline void expand8_bf16(const bf16x8& b, float (&v)[8]) {
+  union {
+    bf16x8 v;
+    unsigned u[4];
+  } r;
+  r.v = b;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    v[2 * i] = __uint_as_float(r.u[i] << 16);
+    v[2 * i + 1] = __uint_as_float(r.u[i] & 0xffff0000u);
+  }
+}
+
 // ---- wave reductions --------------------------------------------------------------------------
 // All-lanes reductions.  The butterfly alone leaves every lane with the same value only if no lane's first addition is
 // contracted with the multiply that produced its operand (fma(a, b, partner) != fma(a', b', own) in the last bit, seen

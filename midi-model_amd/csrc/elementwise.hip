@@ -626,7 +626,7 @@ __global__ __launch_bounds__(256) void swiglu_fwd_kernel(const T* __restrict__ g
 #pragma unroll
     for (int e = 0; e < N; ++e) {
       const float gv = g.get(e);
-      const float s = rnd<T>(gv / (1.f + __expf(-gv)));
+      const float s = rnd<T>(mh_silu(gv));
       o.set(e, s * u.get(e));
     }
     st16(a + m * I + c, o);
@@ -646,7 +646,7 @@ __global__ __launch_bounds__(256) void swiglu_bwd_kernel(const T* __restrict__ g
 #pragma unroll
     for (int e = 0; e < N; ++e) {
       const float gv = g.get(e), dv = d.get(e);
-      const float sig = 1.f / (1.f + __expf(-gv));
+      const float sig = mh_sigmoid(gv);
       const float silu = gv * sig;
       og.set(e, dv * u.get(e) * (sig * (1.f + gv * (1.f - sig))));
       ou.set(e, dv * silu);

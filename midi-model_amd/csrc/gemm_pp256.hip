@@ -289,17 +289,21 @@ __global__ __launch_bounds__(512, 2) void gemm_pp256_kernel(const bf16* __restri
         const f32x4 hi = *reinterpret_cast<const f32x4*>(wreg + row * 256 + (((2 * c + 1) ^ (row & 15)) << 4));
         const int64_t m = m0 + grp * 128 + half * 64 + row;
         if (m >= M || !n_ok) continue;
+        // (alpha is 1 for this epilogue -- mh_gemm_dswiglu has no scale argument; conversions as two-element packs, the
+        // sigmoid through v_rcp_f32: common.h, mh_sigmoid)
         const float v[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-        bf16x8 og, ou;
+        float dv[8], g[8], u[8], dg[8], du[8];
+        expand8_bf16(cvt8_bf16(v), dv);  // d a rounded to bf16 first, as the unfused pair of launches stores it
+        expand8_bf16(gv[i], g);
+        expand8_bf16(uv[i], u);
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
-          const float dv = (float)(bf16)(alpha * v[e]);
-          const float g = (float)gv[i][e], u = (float)uv[i][e];
-          const float sig = 1.f / (1.f + __expf(-g));
-          const float silu = g * sig;
-          og[e] = (bf16)(dv * u * (sig * (1.f + g * (1.f - sig))));
-          ou[e] = (bf16)(dv * silu);
+          const float sig = mh_sigmoid(g[e]);
+          const float silu = g[e] * sig;
+          dg[e] = dv[e] * u[e] * (sig * (1.f + g[e] * (1.f - sig)));
+          du[e] = dv[e] * silu;
         }
+        const bf16x8 og = cvt8_bf16(dg), ou = cvt8_bf16(du);
         __builtin_nontemporal_store(og, reinterpret_cast<bf16x8*>(C + m * ldc + n));
         __builtin_nontemporal_store(ou, reinterpret_cast<bf16x8*>(C + m * ldc + N + n));
       }
@@ -332,17 +336,20 @@ __global__ __launch_bounds__(512, 2) void gemm_pp256_kernel(const bf16* __restri
         const f32x4 u1 = *reinterpret_cast<const f32x4*>(wreg + row * 256 + (((9 + 2 * c) ^ sw) << 4));
         const int64_t m = m0 + grp * 128 + half * 64 + row;
         if (m >= M || col >= I) continue;
+        // (alpha is 1 for this epilogue -- mh_gemm_swiglu has no scale argument.  Eleven VALU per element instead of the 28
+        // the straightforward spelling compiled to: two-element conversions, sigmoid through v_rcp_f32 -- common.h)
         const float gf[8] = {g0[0], g0[1], g0[2], g0[3], g1[0], g1[1], g1[2], g1[3]};
         const float uf[8] = {u0[0], u0[1], u0[2], u0[3], u1[0], u1[1], u1[2], u1[3]};
-        bf16x8 og, ou, oa;
+        const bf16x8 og = cvt8_bf16(gf), ou = cvt8_bf16(uf);
+        float gr[8], ur[8], sv[8], sr[8], av[8];
+        expand8_bf16(og, gr);
+        expand8_bf16(ou, ur);
 #pragma unroll
-        for (int e = 0; e < 8; ++e) {
-          og[e] = (bf16)(alpha * gf[e]);
-          ou[e] = (bf16)(alpha * uf[e]);
-          const float gv = (float)og[e];
-          const float sv = (float)(bf16)(gv / (1.f + __expf(-gv)));
-          oa[e] = (bf16)(sv * (float)ou[e]);
-        }
+        for (int e = 0; e < 8; ++e) sv[e] = mh_silu(gr[e]);
+        expand8_bf16(cvt8_bf16(sv), sr);  // round(silu(gate)), modeling_llama.py:174-176 in bf16
+#pragma unroll
+        for (int e = 0; e < 8; ++e) av[e] = sr[e] * ur[e];
+        const bf16x8 oa = cvt8_bf16(av);
         if (C != nullptr) {  // (read again by the backward only; the forward-only caller passes no buffer: 1 GB less to
           *reinterpret_cast<bf16x8*>(C + m * ldc + col) = og;      //  write per net block at batch 16 x 4096 events)
           *reinterpret_cast<bf16x8*>(C + m * ldc + I + col) = ou;

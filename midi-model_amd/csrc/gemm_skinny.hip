@@ -184,7 +184,7 @@ __global__ __launch_bounds__(NW * 64) void gemm_skinny_kernel(const bf16* __rest
       const int n = blockIdx.x * 16 + c0 + j;
       if (n < N) {
         const float g = (float)(bf16)total(c0 + j), u = (float)(bf16)total(16 + c0 + j);
-        const float s = (float)(bf16)(g / (1.f + __expf(-g)));
+        const float s = (float)(bf16)mh_silu(g);
         C[(int64_t)m * ldc + n] = (bf16)(s * u);
       }
     }

@@ -360,7 +360,11 @@ def test_swiglu_epilogues_at_benchmarked_shape():
     gr, ur = got_gu[:, :I], got_gu[:, I:]            # the kernel's own rounded gate / up
     want_a = (gr / (1 + torch.exp(-gr))).float().bfloat16().double() * ur
     e = (a[rows].float().cpu().double() - want_a).abs()
-    assert (e <= 2 * BF16_ULP * want_a.abs() + 1e-6).all(), e.max().item()
+    # SiLU goes through v_rcp_f32 (common.h mh_silu: <= 2 ulp in fp32), so within ~2e-7 (relative) of a bf16 midpoint
+    # round(silu(gate)) lands one bf16 step away from the fp64 value's rounding (seen: 1 element in 819,200); a bf16 step is
+    # up to 2^-7 relative, plus the final rounding of the product: 3 x 2^-8.
+    assert (e <= 3 * BF16_ULP * want_a.abs() + 1e-6).all(), e.max().item()
+    assert (e > 2 * BF16_ULP * want_a.abs() + 1e-6).float().mean().item() < 1e-4
     # backward: d gate|up = SwiGLU'(gu) * (dx @ wd)
     dx = _bf16_exact((M, K), 62).cuda()
     wd = _bf16_exact((K, I), 63, 0.05).cuda()
