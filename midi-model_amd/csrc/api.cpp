@@ -28,7 +28,7 @@ int g_mh_gemm_variant = env_int("MH_GEMM", 1);
 int g_mh_gemm_ablate = 0;
 extern int g_skinny_mb, g_skinny_nbt;  // gemm_skinny.hip
 extern int g_attn_fwd_wps, g_attn_fwd_qb;  // attention_mfma.hip
-extern int g_attn_v3, g_attn_v3_wps, g_attn_v3_abl;      // attention_mfma3.hip
+extern int g_attn_v3, g_attn_v3_wps;      // attention_mfma3.hip
 
 extern "C" int mh_set_option(const char* name, int value) {
   if (strcmp(name, "gemm") == 0) {
@@ -53,10 +53,6 @@ extern "C" int mh_set_option(const char* name, int value) {
   }
   if (strcmp(name, "attn_v3") == 0) {  // third form of the event-level attention kernels: bit 0 forward, bit 1 dQ, bit 2 dK/dV
     g_attn_v3 = value;
-    return 0;
-  }
-  if (strcmp(name, "attn_v3_abl") == 0) {  // forward with parts left out (timing experiments only; wrong results)
-    g_attn_v3_abl = value;
     return 0;
   }
   if (strcmp(name, "attn_v3_wps") == 0) {  // its register budget in waves per SIMD (0 = default; A/B runs)

@@ -22,7 +22,6 @@
 #include "attn_mfma_common.h"
 
 int g_attn_v3 = 7;      // mh_set_option("attn_v3", bits): 1 forward, 2 dQ, 4 dK/dV
-int g_attn_v3_abl = 0;  // mh_set_option("attn_v3_abl", bits): forward with parts left out (timing experiments, see fwd3_tile)
 int g_attn_v3_wps = 0;  // mh_set_option("attn_v3_wps", n): register budget (waves per SIMD) override for A/B runs, 0 = default
 
 __device__ inline bf16x8 ldsv(const char* p) { return *reinterpret_cast<const bf16x8*>(p); }
@@ -52,49 +51,41 @@ __device__ inline float xhalf_max(float v) {  // max with the other wave half's 
 // ---------------------------------------------------------------------------------------------------
 // one 64-key tile for one wave (32 query rows).  foff[s]: this lane's byte offset of fragment s inside a 32-row tile block
 // (row pi32(lane & 31), chunk 2s + hi); the second block of a tile is 4096 bytes further.  qrel = query row - first key.
-// ABL (timing experiments only, wrong results; tools/bench_attn_forms.py): 1 no v_exp, 2 no row maximum, 4 no P V MFMAs, 8 no
-// Q K^T MFMAs, 16 no LDS fragment reads (register operands instead).
-template <bool MASK, int ABL = 0>
+// (Where the time goes, measured by leaving parts out of this kernel -- profiles/r02_run16_attn_forms_ab_and_fwd_ablation.txt,
+// B=16, S=4096, 684 us complete: no v_exp -40, no row maximum -8, no P V MFMAs -100, no Q K^T MFMAs -68, no MFMAs -151, no
+// fragment reads -55, neither -278; staging + barriers + the sums alone 333 us.)
+template <bool MASK>
 __device__ inline void fwd3_tile(const char* tK, const char* tV, const int (&foff)[4], const bf16x8 (&qf)[4],
                                  f32x16 (&oacc)[2], float& m, float& l, int hi, int qrel, float sc) {
   bf16x8 kf[2][4];
 #pragma unroll
   for (int s = 0; s < 4; ++s)
 #pragma unroll
-    for (int kb = 0; kb < 2; ++kb) kf[kb][s] = (ABL & 16) ? qf[(s + kb) & 3] : ldsv(tK + foff[s] + kb * 4096);
+    for (int kb = 0; kb < 2; ++kb) kf[kb][s] = ldsv(tK + foff[s] + kb * 4096);
   __builtin_amdgcn_sched_barrier(0);
   f32x16 sacc[2] = {zero16(), zero16()};
-  if (ABL & 8) {
 #pragma unroll
-    for (int kb = 0; kb < 2; ++kb)
+  for (int s = 0; s < 4; ++s)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) sacc[kb][r] = (float)kf[kb][r & 3][r >> 2] * (float)qf[r & 3][kb];
-  } else {
-#pragma unroll
-    for (int s = 0; s < 4; ++s)
-#pragma unroll
-      for (int kb = 0; kb < 2; ++kb) sacc[kb] = mfma32(kf[kb][s], qf[s], sacc[kb]);  // two independent accumulator chains
-  }
-  bf16x8 vf[4][2];  // the V^T fragments of the whole tile: in flight under the softmax arithmetic
+    for (int kb = 0; kb < 2; ++kb) sacc[kb] = mfma32(kf[kb][s], qf[s], sacc[kb]);  // two independent accumulator chains
+  bf16x8 vf[4][2];  // the V^T fragments: in flight under the softmax arithmetic
 #pragma unroll
   for (int t = 0; t < 4; ++t)
 #pragma unroll
-    for (int db = 0; db < 2; ++db) vf[t][db] = (ABL & 16) ? qf[(t + db) & 3] : ldsv(tV + foff[t] + db * 4096);
+    for (int db = 0; db < 2; ++db) vf[t][db] = ldsv(tV + foff[t] + db * 4096);
   __builtin_amdgcn_sched_barrier(0);
   float mx = -INFINITY;
-  if (ABL & 2) {
-    mx = m > -1e30f ? m / sc : sacc[0][0];
-  } else {
 #pragma unroll
-    for (int kb = 0; kb < 2; ++kb)
+  for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        if (MASK) {
-          if (kb * 32 + reg_index(r, hi) > qrel) sacc[kb][r] = -INFINITY;
-        }
-        mx = fmaxf(mx, sacc[kb][r]);
+    for (int r = 0; r < 16; ++r) {
+      if (MASK) {
+        // (register r <-> key kb*32 + 16 (r>>3) + (r&7) + 8 hi: a compile-time constant against ONE lane value, qrel - 8 hi;
+        //  spelled with reg_index(r, hi) hipcc kept 32 per-lane index registers alive for the masked tile)
+        if (kb * 32 + 16 * (r >> 3) + (r & 7) > qrel - 8 * hi) sacc[kb][r] = -INFINITY;
       }
-  }
+      mx = fmaxf(mx, sacc[kb][r]);
+    }
   mx = xhalf_max(mx) * sc;  // running max kept in scaled (log2) units
   // A row moves its reference maximum only when its true maximum grew by more than RESCALE_THR (log2 units): until then
   // its probabilities may reach 2^THR instead of 1, and l / O / lse stay mutually consistent (exact maths; only the bf16
@@ -112,11 +103,7 @@ __device__ inline void fwd3_tile(const char* tK, const char* tV, const int (&fof
   float ps0 = 0.f, ps1 = 0.f;  // (two partial sums: half the length of the dependent add chain)
 #pragma unroll
   for (int r = 0; r < 16; ++r) {
-    float p0 = __builtin_fmaf(sacc[0][r], sc, -m), p1 = __builtin_fmaf(sacc[1][r], sc, -m);
-    if (!(ABL & 1)) {
-      p0 = fast_exp2(p0);
-      p1 = fast_exp2(p1);
-    }
+    const float p0 = fast_exp2(__builtin_fmaf(sacc[0][r], sc, -m)), p1 = fast_exp2(__builtin_fmaf(sacc[1][r], sc, -m));
     sacc[0][r] = p0;
     sacc[1][r] = p1;
     ps0 += p0;
@@ -126,17 +113,12 @@ __device__ inline void fwd3_tile(const char* tK, const char* tV, const int (&fof
 #pragma unroll
   for (int t = 0; t < 4; ++t) {
     const bf16x8 pf = pack8_pk(sacc[t >> 1], 8 * (t & 1));
-    if (ABL & 4) {
 #pragma unroll
-      for (int db = 0; db < 2; ++db) oacc[db][t] += (float)pf[db] * (float)vf[t][db][0];
-    } else {
-#pragma unroll
-      for (int db = 0; db < 2; ++db) oacc[db] = mfma32(vf[t][db], pf, oacc[db]);
-    }
+    for (int db = 0; db < 2; ++db) oacc[db] = mfma32(vf[t][db], pf, oacc[db]);
   }
 }
 
-template <int WPS, int ABL = 0>
+template <int WPS>
 __global__ __launch_bounds__(256, WPS) void attn_fwd3_kernel(const bf16* __restrict__ qkv, const bf16* __restrict__ vt,
                                                           bf16* __restrict__ o, float* __restrict__ lse, int S, int Sp, int H,
                                                           float sc /* scale*log2(e) */, int BH, int nqt) {
@@ -186,7 +168,8 @@ __global__ __launch_bounds__(256, WPS) void attn_fwd3_kernel(const bf16* __restr
   stage64u(vtbase, Sp, 0, HD - 1, 0, smem + TILE64, wave, lane);
 #pragma unroll
   for (int s = 0; s < 4; ++s) asm volatile("" : "+v"(qf[s]));  // (see attn_bwd_dkv_kernel)
-  __syncthreads();
+  stage_wait_all();
+    __syncthreads();
   auto stage_next = [&](int kt) {
     if (kt + 1 <= kt_last) {
       char* nxt = smem + ((kt + 1) & 1) * 2 * TILE64;
@@ -198,18 +181,21 @@ __global__ __launch_bounds__(256, WPS) void attn_fwd3_kernel(const bf16* __restr
   for (; kt < n_full; ++kt) {
     stage_next(kt);
     const char* cur = smem + (kt & 1) * 2 * TILE64;
-    fwd3_tile<false, ABL>(cur, cur + TILE64, foff, qf, oacc, m, l, hi, 0, sc);
+    fwd3_tile<false>(cur, cur + TILE64, foff, qf, oacc, m, l, hi, 0, sc);
+    stage_wait_all();
     __syncthreads();
   }
   if (kt <= kt_last) {
     stage_next(kt);
     const char* cur = smem + (kt & 1) * 2 * TILE64;
-    fwd3_tile<true, ABL>(cur, cur + TILE64, foff, qf, oacc, m, l, hi, qrow - kt * 64, sc);
+    fwd3_tile<true>(cur, cur + TILE64, foff, qf, oacc, m, l, hi, qrow - kt * 64, sc);
+    stage_wait_all();
     __syncthreads();
     ++kt;
   }
   for (; kt <= kt_last; ++kt) {
     stage_next(kt);
+    stage_wait_all();
     __syncthreads();
   }
   const float lt = l + __shfl_xor(l, 32, 64);
@@ -247,7 +233,7 @@ __device__ inline void dq3_tile(const char* tK, const char* tV, const char* tKT,
     for (int r = 0; r < 16; ++r) {
       float p = fast_exp2(__builtin_fmaf(sacc[r], sc, -lse2));
       if (MASK) {
-        if (kb * 32 + reg_index(r, hi) > qrel) p = 0.f;
+        if (kb * 32 + 16 * (r >> 3) + (r & 7) > qrel - 8 * hi) p = 0.f;  // (see fwd3_tile)
       }
       sacc[r] = p * pacc[r];
     }
@@ -388,7 +374,8 @@ __global__ __launch_bounds__(256, WPS) void attn_bwd_dq3_kernel(const bf16* __re
   }
   asm volatile("" : "+v"(lse2));
   asm volatile("" : "+v"(dlt));
-  __syncthreads();
+  stage_wait_all();
+    __syncthreads();
   auto stage_next = [&](int kt) {
     if (kt + 1 <= kt_last) {
       char* nxt = smem + ((kt + 1) & 1) * 3 * TILE64;
@@ -403,17 +390,20 @@ __global__ __launch_bounds__(256, WPS) void attn_bwd_dq3_kernel(const bf16* __re
     stage_next(kt);
     const char* cur = smem + (kt & 1) * 3 * TILE64;
     dq3_tile<false, WIDE>(cur, cur + TILE64, cur + 2 * TILE64, foff, qf, dof, dqacc, hi, 0, sc, lse2, dlt);
+    stage_wait_all();
     __syncthreads();
   }
   if (kt <= kt_last) {
     stage_next(kt);
     const char* cur = smem + (kt & 1) * 3 * TILE64;
     dq3_tile<true, WIDE>(cur, cur + TILE64, cur + 2 * TILE64, foff, qf, dof, dqacc, hi, qrow - kt * 64, sc, lse2, dlt);
+    stage_wait_all();
     __syncthreads();
     ++kt;
   }
   for (; kt <= kt_last; ++kt) {
     stage_next(kt);
+    stage_wait_all();
     __syncthreads();
   }
   if (qrow < S) {
@@ -487,8 +477,8 @@ __device__ inline void dkv3_tile(const char* tQ, const char* tDO, const char* tQ
           float p = fast_exp2(__builtin_fmaf(sacc[r], sc, -la[t][v4][e] * LOG2E));
           float ds = p * pacc[r];
           if (MASK) {
-            const int q = qb * 32 + 16 * t + 8 * hi + 4 * v4 + e;
-            const bool ok = (q >= krel) && (q < qlim);
+            const int q = qb * 32 + 16 * t + 4 * v4 + e;  // (+ 8 hi, moved to the other side: see fwd3_tile)
+            const bool ok = (q >= krel - 8 * hi) && (q < qlim - 8 * hi);
             p = ok ? p : 0.f;
             ds = ok ? ds : 0.f;
           }
@@ -564,8 +554,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv3_kernel(const bf16* __res
     stage64u(dotbase, Sp, 0, HD - 1, qt * 64, dst + 3 * TILE64, wave, lane);
     if (wave < 2) {
       const float* base = (wave == 0 ? lse_b : delta_b) + (int64_t)qt * 64;
-      const unsigned l15 = (unsigned)(lane & 15);
-      glds16(base + 4 * l15, dst + 4 * TILE64 + wave * 1024);
+      glds16_s(base, (unsigned)(lane & 15) * 16u, __builtin_amdgcn_readfirstlane(lds_u32(dst + 4 * TILE64 + wave * 1024)));
     }
   };
   if (qt_first <= qt_last) stage_all(qt_first, smem);
@@ -574,7 +563,8 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv3_kernel(const bf16* __res
     asm volatile("" : "+v"(kf[s]));
     asm volatile("" : "+v"(vf[s]));
   }
-  __syncthreads();
+  stage_wait_all();
+    __syncthreads();
   // This wave's query tiles, in order: n_skip tiles entirely before its keys (nothing to compute), ONE tile crossing its
   // diagonal (tile a = kw0 / 64; masked), the full tiles up to S / 64, and a ragged last tile (masked; S % 64 != 0).
   // Counted loops with one body each: with the class tests inside the loop conditions hipcc rotated the loops and copied
@@ -594,12 +584,14 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv3_kernel(const bf16* __res
   };
   for (int i = 0; i < n_skip; ++i, ++qt) {
     head(qt);
+    stage_wait_all();
     __syncthreads();
   }
   if (n_mask) {
     const char* cur = head(qt);
     dkv3_tile<true>(cur, cur + TILE64, cur + 2 * TILE64, cur + 3 * TILE64, cur + 4 * TILE64, foff, kf, vf, dkacc, dvacc, hi,
                     krow - qt * 64, S - qt * 64, sc);
+    stage_wait_all();
     __syncthreads();
     ++qt;
   }
@@ -607,12 +599,14 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv3_kernel(const bf16* __res
     const char* cur = head(qt);
     dkv3_tile<false>(cur, cur + TILE64, cur + 2 * TILE64, cur + 3 * TILE64, cur + 4 * TILE64, foff, kf, vf, dkacc, dvacc, hi, 0,
                      64, sc);
+    stage_wait_all();
     __syncthreads();
   }
   if (n_tail > 0) {
     const char* cur = head(qt);
     dkv3_tile<true>(cur, cur + TILE64, cur + 2 * TILE64, cur + 3 * TILE64, cur + 4 * TILE64, foff, kf, vf, dkacc, dvacc, hi,
                     krow - qt * 64, S - qt * 64, sc);
+    stage_wait_all();
     __syncthreads();
   }
   if (krow < S) {
@@ -628,20 +622,6 @@ int mh_attn_fwd_mfma3(const void* qkv, const void* vt, void* o, float* lse, int6
   const int64_t Sp = (S + 63) / 64 * 64;
   const int nt = (int)((S + 127) / 128), BH = (int)(B * H);
   const unsigned grid = (unsigned)(nt * 8 * ((BH + 7) / 8));
-#define MH_ABL(A)                                                                                                          \
-  case A:                                                                                                                  \
-    attn_fwd3_kernel<3, A><<<grid, 256, 4 * TILE64, st>>>((const bf16*)qkv, (const bf16*)vt, (bf16*)o, lse, (int)S, (int)Sp, H, \
-                                                          scale * LOG2E, BH, nt);                                          \
-    break;
-  if (g_attn_v3_abl != 0) {
-    switch (g_attn_v3_abl) {
-      MH_ABL(1) MH_ABL(2) MH_ABL(3) MH_ABL(4) MH_ABL(8) MH_ABL(12) MH_ABL(16) MH_ABL(28) MH_ABL(31)
-      default: MH_REQUIRE(false, "attn_v3_abl: not instantiated");
-    }
-    MH_LAUNCH_CHECK();
-    return MH_OK;
-  }
-#undef MH_ABL
   if (g_attn_v3_wps == 2)
     attn_fwd3_kernel<2><<<grid, 256, 4 * TILE64, st>>>((const bf16*)qkv, (const bf16*)vt, (bf16*)o, lse, (int)S, (int)Sp, H,
                                                      scale * LOG2E, BH, nt);

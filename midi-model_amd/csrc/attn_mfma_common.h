@@ -46,12 +46,28 @@ __device__ inline void stage64(const bf16* __restrict__ base, int64_t ld, int64_
   }
 }
 
-// The same with a wave-uniform 64-bit base and a 32-bit per-lane element offset (all operands of one (batch, head) panel
-// lie within 2^31 elements of its base): the LDS-DMA then takes its address as SGPR pair + one VGPR instead of a 64-bit
-// VGPR pair per request, which is what kept a dozen address registers alive across the tile loops of the first form.
+// The same with a wave-uniform 64-bit base and a 32-bit per-lane BYTE offset (all operands of one (batch, head) panel lie
+// within 2^31 bytes of its base), issued from inline asm in the SGPR-base form `global_load_lds_dwordx4 voff, s[base]`: one
+// address VGPR per request instead of a 64-bit pair, no 64-bit VALU adds in the tile loops (hipcc does not select this form
+// for the builtin; the first form kept a dozen address registers alive across the loops and re-derived each address with
+// v_lshl_add_u64).  M0 (the LDS destination) is saved and restored inside the statement (cdna_hip_programming.md 5.7).
+// hipcc does NOT count these loads: every wait on them is an explicit s_waitcnt vmcnt (stage_wait_all) before the barrier.
+__device__ inline void glds16_s(const void* __restrict__ sbase, unsigned voff, unsigned lds_dst) {
+  unsigned keep;
+  asm volatile(
+      "s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+      : "=&s"(keep)
+      : "v"(voff), "s"(sbase), "s"(lds_dst)
+      : "memory");
+}
+__device__ inline void stage_wait_all() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+__device__ inline unsigned lds_u32(const void* p) {
+  return (unsigned)(uintptr_t)(__attribute__((address_space(3))) const char*)p;
+}
 __device__ inline void stage64u(const bf16* __restrict__ base, int ld, int row0, int row_clamp, int col0, char* lds_tile,
                                 int wave, int lane) {
   const int rsub = lane >> 3, pc = lane & 7;
+  const unsigned lds0 = __builtin_amdgcn_readfirstlane(lds_u32(lds_tile));
 #pragma unroll
   for (int it = 0; it < 2; ++it) {
     const int g8 = wave + 4 * it;
@@ -59,8 +75,8 @@ __device__ inline void stage64u(const bf16* __restrict__ base, int ld, int row0,
     const int c = pc ^ ((r >> 1) & 7);
     int grow = row0 + r;
     grow = grow > row_clamp ? row_clamp : grow;
-    const unsigned off = (unsigned)(grow * ld + col0 + c * 8);
-    glds16(base + off, lds_tile + g8 * 1024);
+    const unsigned off = (unsigned)(grow * ld + col0 + c * 8) * 2u;
+    glds16_s(base, off, lds0 + g8 * 1024);
   }
 }
 

@@ -65,18 +65,6 @@ def main():
         us = timeit(lambda: lib().call("mh_attn_prep_bwd", qkv.data_ptr(), o.data_ptr(), do.data_ptr(), delta.data_ptr(), buf[0].data_ptr(),
                                        buf[1].data_ptr(), buf[2].data_ptr(), B, S, H, 1, st), iters)
         print(f"S={S} prep_bwd alone: {us:8.1f} us")
-    if os.environ.get("MH_BENCH_ABLATE", "1") == "1":  # forward with parts left out (wrong results; where the time goes)
-        ops.set_option("attn_v3", 1)
-        ops.set_option("attn_v3_wps", 3)
-        names = {0: "complete", 1: "no v_exp", 2: "no row max", 3: "no v_exp, no row max", 4: "no P V MFMAs", 8: "no Q K^T MFMAs",
-                 12: "no MFMAs", 16: "no LDS fragment reads", 28: "no MFMAs, no LDS reads (softmax arithmetic + staging only)",
-                 31: "staging, barriers and the sums only"}
-        for rnd in range(2):
-            for abl, nm in names.items():
-                ops.set_option("attn_v3_abl", abl)
-                us = timeit(lambda: ops.attn_fwd(qkv, o, lse, B, S, H, 0.125), iters)
-                print(f"S={S} fwd3 ablation {abl:2d} ({nm}): {us:8.1f} us", flush=True)
-        ops.set_option("attn_v3_abl", 0)
     ops.set_option("attn_v3", 7)
     ops.set_option("attn_v3_wps", 0)
 
