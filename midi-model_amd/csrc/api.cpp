@@ -51,7 +51,8 @@ extern "C" int mh_set_option(const char* name, int value) {
     g_attn_fwd_qb = value;
     return 0;
   }
-  if (strcmp(name, "attn_v3") == 0) {  // third form of the event-level attention kernels: bit 0 forward, bit 1 dQ, bit 2 dK/dV
+  if (strcmp(name, "attn_v3") == 0) {  // third form of the event-level attention kernels: bit 0 forward, bit 1 dQ, bit 2 dK/dV,
+                                       // bit 3 transpose reads in the backward pair (no transposed copies; needs bits 1 and 2)
     g_attn_v3 = value;
     return 0;
   }
@@ -69,6 +70,7 @@ extern "C" int mh_set_option(const char* name, int value) {
 extern "C" int mh_get_option(const char* name) {
   if (strcmp(name, "gemm") == 0) return g_mh_gemm_variant;
   if (strcmp(name, "skinny_mb") == 0) return g_skinny_mb;
+  if (strcmp(name, "attn_v3") == 0) return g_attn_v3;
   return -1;
 }
 

@@ -328,30 +328,6 @@ __global__ __launch_bounds__(256, WPS) void attn_fwdq2_kernel(const bf16* __rest
 __device__ inline void wait_vmcnt4() { asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); }
 __device__ inline void wait_vmcnt0() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 
-// The transpose reads are issued from inline asm: through the builtin hipcc puts an s_waitcnt vmcnt(0) in front of every
-// ds_read_b64_tr_b16 while an LDS-DMA is outstanding (it cannot tell the stages apart), which would drain the stage requested
-// at the top of the tile.  The asm reads are invisible to its counters, so they are waited for by hand (lgkmcnt(0) +
-// sched_barrier before the first consumer; cdna_hip_programming.md 5.7 form iii).
-typedef __attribute__((ext_vector_type(2))) unsigned int u32x2;
-template <int OFF>
-__device__ inline u32x2 ds_tr16(unsigned lds_addr) {
-  u32x2 r;
-  asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(r) : "v"(lds_addr), "i"(OFF));
-  return r;
-}
-__device__ inline unsigned lds_addr32(const char* p) {
-  return (unsigned)(uintptr_t)(__attribute__((address_space(3))) const char*)p;
-}
-__device__ inline bf16x8 join8(const u32x2& a, const u32x2& b) {
-  union {
-    bf16x8 v;
-    u32x2 h[2];
-  } u;
-  u.h[0] = a;
-  u.h[1] = b;
-  return u.v;
-}
-
 // one 64-key tile for one wave (32 query rows); koff[s] / voff[db][half]: this lane's byte offsets inside a K / V tile.
 // LDS latency is taken off the critical path by hand: all 8 K fragments are requested before the first S^T MFMA, and the 16
 // transpose reads of V are requested right after the S^T MFMAs are issued, i.e. BEFORE the softmax arithmetic that produces
@@ -789,7 +765,8 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const bf16* __rest
 }
 
 // ---------------------------------------------------------------------------------------------------
-extern int g_attn_v3;  // attention_mfma3.hip: the third form of the three kernels (bit 0 forward, bit 1 dQ, bit 2 dK/dV)
+extern int g_attn_v3;  // attention_mfma3.hip: the third form of the three kernels (bit 0 forward, bit 1 dQ, bit 2 dK/dV, bit 3
+                       // transpose reads in the backward pair instead of the prepared copies)
 int mh_attn_fwd_mfma3(const void* qkv, const void* vt, void* o, float* lse, int64_t B, int64_t S, int H, float scale,
                       hipStream_t st);
 int mh_attn_bwd_mfma3(const void* qkv, const void* dout, const float* lse, const float* delta, const void* qt, const void* kt,
@@ -830,13 +807,15 @@ int mh_attn_fwd_mfma(const void* qkv, const void* vt, void* o, float* lse, int64
 int mh_attn_bwd_mfma(const void* qkv, const void* dout, const float* lse, const float* delta, const void* qt,
                      const void* kt, const void* dot, void* dqkv, int64_t B, int64_t S, int H, float scale,
                      const float* cos_t, const float* sin_t, hipStream_t st) {
-  MH_REQUIRE(qt != nullptr && kt != nullptr && dot != nullptr, "attn_bwd(bf16): needs the transposed copies (mh_attn_prep_bwd)");
   MH_REQUIRE(S < (1 << 24), "attn_bwd: sequence too long");
+  if ((g_attn_v3 & 14) == 14)  // third form of both kernels with transpose reads: no transposed copies needed
+    return mh_attn_bwd_mfma3(qkv, dout, lse, delta, nullptr, nullptr, nullptr, dqkv, B, S, H, scale, cos_t, sin_t, 14, st);
+  MH_REQUIRE(qt != nullptr && kt != nullptr && dot != nullptr, "attn_bwd(bf16): needs the transposed copies (mh_attn_prep_bwd)");
   const int64_t Sp = (S + 63) / 64 * 64;
   const int nt = (int)((S + 127) / 128), BH = (int)(B * H);
   const unsigned grid = (unsigned)(nt * 8 * ((BH + 7) / 8));
   if (g_attn_v3 & 6) {
-    const int rc = mh_attn_bwd_mfma3(qkv, dout, lse, delta, qt, kt, dot, dqkv, B, S, H, scale, cos_t, sin_t, g_attn_v3 & 6, st);
+    const int rc = mh_attn_bwd_mfma3(qkv, dout, lse, delta, qt, kt, dot, dqkv, B, S, H, scale, cos_t, sin_t, g_attn_v3 & 14, st);
     if (rc != MH_OK) return rc;
   }
   if (!(g_attn_v3 & 2)) {

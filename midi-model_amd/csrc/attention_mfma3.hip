@@ -21,7 +21,7 @@
 // Roofline: MFMA (2.5 PFLOP/s bf16 dense), VALU co-limited at head_dim 64.
 #include "attn_mfma_common.h"
 
-int g_attn_v3 = 7;      // mh_set_option("attn_v3", bits): 1 forward, 2 dQ, 4 dK/dV
+int g_attn_v3 = 15;     // mh_set_option("attn_v3", bits): 1 forward, 2 dQ, 4 dK/dV, 8 transpose reads in dQ + dK/dV (needs 2 | 4)
 int g_attn_v3_wps = 0;  // mh_set_option("attn_v3_wps", n): register budget (waves per SIMD) override for A/B runs, 0 = default
 
 __device__ inline bf16x8 ldsv(const char* p) { return *reinterpret_cast<const bf16x8*>(p); }
@@ -218,101 +218,96 @@ __global__ __launch_bounds__(256, WPS) void attn_fwd3_kernel(const bf16* __restr
 // ---------------------------------------------------------------------------------------------------
 // backward, dQ: block = 128 query rows, loop over key tiles
 // ---------------------------------------------------------------------------------------------------
-// one 64-key tile for one wave (32 query rows).  WIDE: the K / V fragments of both 32-key blocks go out in one batch of 16
-// (two waves per SIMD: 256 registers); otherwise block by block (three waves per SIMD).
-template <bool MASK, bool WIDE>
-__device__ inline void dq3_tile(const char* tK, const char* tV, const char* tKT, const int (&foff)[4], const bf16x8 (&qf)[4],
-                                const bf16x8 (&dof)[4] /* -dO */, f32x16 (&dqacc)[2], int hi, int qrel, float sc, float lse2,
+// one 32-key block (KB) of a 64-key tile for one wave (32 query rows).  TR: the K^T fragments of dQ^T += K^T dS^T are read
+// out of the row-major K tile with ds_read_b64_tr_b16 (tkt = the LDS addresses tK + tr_frag_offsets) -- no transposed
+// [B,H,64,Sp] copy of K in HBM, a third fewer LDS-DMA requests per tile (each costs its wave 60-180 issue cycles:
+// profiles/r02_run16_attn_forms_ab_and_fwd_ablation.txt, staging + barriers alone are half of the forward).  Otherwise from
+// the prepared K^T tile (tKT).
+template <bool MASK, bool TR, int KB>
+__device__ inline void dq3_half(const char* tK, const char* tV, const char* tKT, const unsigned (&tkt)[2][2],
+                                const int (&foff)[4], const bf16x8 (&qf)[4], const bf16x8 (&dof)[4] /* -dO */,
+                                f32x16 (&dqacc)[2], int hi, int qrel, float sc, float lse2,
                                 const f32x16& dlt /* the row's delta in all 16 registers */) {
   // delta goes into the matrix pipe: the dP chain starts from C = delta and multiplies the NEGATED dO fragments, so its
   // result is delta - dP and dS comes out negated with one multiply per element (the subtraction was 32 VALU issue slots
   // per tile: tools/mfma_valu_probe.hip -- a SIMD issues one VALU per ~4 cycles whatever the number of waves); the kernel
   // stores -(-dQ).
-  auto softmax_grad = [&](f32x16& sacc, const f32x16& pacc, int kb) {  // S -> -dS (unscaled), in place
+  bf16x8 kf[4], vf[4];
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      float p = fast_exp2(__builtin_fmaf(sacc[r], sc, -lse2));
-      if (MASK) {
-        if (kb * 32 + 16 * (r >> 3) + (r & 7) > qrel - 8 * hi) p = 0.f;  // (see fwd3_tile)
+  for (int s = 0; s < 4; ++s) {
+    kf[s] = ldsv(tK + foff[s] + KB * 4096);
+    vf[s] = ldsv(tV + foff[s] + KB * 4096);
+  }
+  __builtin_amdgcn_sched_barrier(0);
+  f32x16 sacc = zero16(), pacc;
+#pragma unroll
+  for (int s = 0; s < 4; ++s) {
+    sacc = mfma32(kf[s], qf[s], sacc);
+    pacc = mfma32(vf[s], dof[s], s == 0 ? dlt : pacc);
+  }
+  bf16x8 ktf[2][2];   // [t][hb]: keys KB*32 + 16 t + 8 hi .. +7 of d-row block hb
+  u32x2 kr[2][2][2];  // the same as transpose reads: [t][hb][half]
+  if (TR) {
+#pragma unroll
+    for (int hb = 0; hb < 2; ++hb)
+#pragma unroll
+      for (int half = 0; half < 2; ++half) {
+        kr[0][hb][half] = ds_tr16<(2 * KB) * 2048>(tkt[hb][half]);
+        kr[1][hb][half] = ds_tr16<(2 * KB + 1) * 2048>(tkt[hb][half]);
       }
-      sacc[r] = p * pacc[r];
-    }
-  };
-  if (WIDE) {
-    bf16x8 kf[2][4], vf[2][4];
-#pragma unroll
-    for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-      for (int s = 0; s < 4; ++s) {
-        kf[kb][s] = ldsv(tK + foff[s] + kb * 4096);
-        vf[kb][s] = ldsv(tV + foff[s] + kb * 4096);
-      }
-    __builtin_amdgcn_sched_barrier(0);
-    f32x16 sacc[2] = {zero16(), zero16()}, pacc[2];
-#pragma unroll
-    for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-      for (int s = 0; s < 4; ++s) {
-        sacc[kb] = mfma32(kf[kb][s], qf[s], sacc[kb]);
-        pacc[kb] = mfma32(vf[kb][s], dof[s], s == 0 ? dlt : pacc[kb]);
-      }
-    bf16x8 ktf[4][2];  // K^T fragments of the whole tile: c = 2 kb + t <-> chunk 4 kb + 2 t + hi
-#pragma unroll
-    for (int c = 0; c < 4; ++c)
-#pragma unroll
-      for (int hb = 0; hb < 2; ++hb) ktf[c][hb] = ldsv(tKT + foff[c] + hb * 4096);
-    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-    for (int kb = 0; kb < 2; ++kb) {
-      softmax_grad(sacc[kb], pacc[kb], kb);
-#pragma unroll
-      for (int t = 0; t < 2; ++t) {
-        const bf16x8 dsf = pack8_pk(sacc[kb], 8 * t);
-#pragma unroll
-        for (int hb = 0; hb < 2; ++hb) dqacc[hb] = mfma32(ktf[2 * kb + t][hb], dsf, dqacc[hb]);
-      }
-    }
   } else {
 #pragma unroll
-    for (int kb = 0; kb < 2; ++kb) {
-      bf16x8 kf[4], vf[4];
+    for (int t = 0; t < 2; ++t)
 #pragma unroll
-      for (int s = 0; s < 4; ++s) {
-        kf[s] = ldsv(tK + foff[s] + kb * 4096);
-        vf[s] = ldsv(tV + foff[s] + kb * 4096);
-      }
-      __builtin_amdgcn_sched_barrier(0);
-      f32x16 sacc = zero16(), pacc;
+      for (int hb = 0; hb < 2; ++hb) ktf[t][hb] = ldsv(tKT + foff[2 * KB + t] + hb * 4096);
+  }
+  __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-      for (int s = 0; s < 4; ++s) {
-        sacc = mfma32(kf[s], qf[s], sacc);
-        pacc = mfma32(vf[s], dof[s], s == 0 ? dlt : pacc);
-      }
-      bf16x8 ktf[2][2];
-#pragma unroll
-      for (int t = 0; t < 2; ++t)
-#pragma unroll
-        for (int hb = 0; hb < 2; ++hb) ktf[t][hb] = ldsv(tKT + foff[2 * kb + t] + hb * 4096);
-      __builtin_amdgcn_sched_barrier(0);
-      softmax_grad(sacc, pacc, kb);
-#pragma unroll
-      for (int t = 0; t < 2; ++t) {
-        const bf16x8 dsf = pack8_pk(sacc, 8 * t);
-#pragma unroll
-        for (int hb = 0; hb < 2; ++hb) dqacc[hb] = mfma32(ktf[t][hb], dsf, dqacc[hb]);
-      }
+  for (int r = 0; r < 16; ++r) {  // S -> -dS (unscaled), in place
+    float p = fast_exp2(__builtin_fmaf(sacc[r], sc, -lse2));
+    if (MASK) {
+      if (KB * 32 + 16 * (r >> 3) + (r & 7) > qrel - 8 * hi) p = 0.f;  // (see fwd3_tile)
     }
+    sacc[r] = p * pacc[r];
+  }
+  const bf16x8 dsf0 = pack8_pk(sacc, 0), dsf1 = pack8_pk(sacc, 8);
+  if (TR) {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the transpose reads (asm: invisible to hipcc's counters)
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int hb = 0; hb < 2; ++hb) dqacc[hb] = mfma32(join8(kr[0][hb][0], kr[0][hb][1]), dsf0, dqacc[hb]);
+#pragma unroll
+    for (int hb = 0; hb < 2; ++hb) dqacc[hb] = mfma32(join8(kr[1][hb][0], kr[1][hb][1]), dsf1, dqacc[hb]);
+  } else {
+#pragma unroll
+    for (int hb = 0; hb < 2; ++hb) dqacc[hb] = mfma32(ktf[0][hb], dsf0, dqacc[hb]);
+#pragma unroll
+    for (int hb = 0; hb < 2; ++hb) dqacc[hb] = mfma32(ktf[1][hb], dsf1, dqacc[hb]);
   }
 }
 
-template <int WPS>
+template <bool MASK, bool TR>
+__device__ inline void dq3_tile(const char* tK, const char* tV, const char* tKT, const int (&trof)[2][2], const int (&foff)[4],
+                                const bf16x8 (&qf)[4], const bf16x8 (&dof)[4], f32x16 (&dqacc)[2], int hi, int qrel, float sc,
+                                float lse2, const f32x16& dlt) {
+  unsigned tkt[2][2];
+#pragma unroll
+  for (int hb = 0; hb < 2; ++hb)
+#pragma unroll
+    for (int half = 0; half < 2; ++half) tkt[hb][half] = lds_addr32(tK) + (unsigned)trof[hb][half];
+  dq3_half<MASK, TR, 0>(tK, tV, tKT, tkt, foff, qf, dof, dqacc, hi, qrel, sc, lse2, dlt);
+  dq3_half<MASK, TR, 1>(tK, tV, tKT, tkt, foff, qf, dof, dqacc, hi, qrel, sc, lse2, dlt);
+}
+
+template <int WPS, bool TR>
 __global__ __launch_bounds__(256, WPS) void attn_bwd_dq3_kernel(const bf16* __restrict__ qkv, const bf16* __restrict__ dout,
                                                               const float* __restrict__ lse, const float* __restrict__ delta,
                                                               const bf16* __restrict__ kt_, bf16* __restrict__ dqkv, int S,
                                                               int Sp, int H, float scale, int BH, int nqt,
                                                               const float* __restrict__ cos_t,
                                                               const float* __restrict__ sin_t) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];  // 6 tiles: [stage][K | V | K^T]
+  extern __shared__ __attribute__((aligned(16))) char smem[];  // [stage][K | V | K^T], or [stage][K | V] with transpose reads
+  constexpr int NT = TR ? 2 : 3;  // tiles per stage
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   int bh_, tile_;
@@ -330,7 +325,7 @@ __global__ __launch_bounds__(256, WPS) void attn_bwd_dq3_kernel(const bf16* __re
 
   const bf16* kbase = qkv + b * S * D3 + D + (int64_t)h * HD;
   const bf16* vbase = kbase + D;
-  const bf16* ktbase = kt_ + bh * HD * Sp;
+  const bf16* ktbase = TR ? nullptr : kt_ + bh * HD * Sp;
 
   bf16x8 qf[4], dof[4];
   {
@@ -364,9 +359,11 @@ __global__ __launch_bounds__(256, WPS) void attn_bwd_dq3_kernel(const bf16* __re
   }
 
   const int iD3 = (int)D3;
+  int trof[2][2];
+  tr_frag_offsets(lane, trof);
   stage64u(kbase, iD3, 0, S - 1, 0, smem, wave, lane);
   stage64u(vbase, iD3, 0, S - 1, 0, smem + TILE64, wave, lane);
-  stage64u(ktbase, Sp, 0, HD - 1, 0, smem + 2 * TILE64, wave, lane);
+  if (!TR) stage64u(ktbase, Sp, 0, HD - 1, 0, smem + 2 * TILE64, wave, lane);
 #pragma unroll
   for (int s = 0; s < 4; ++s) {  // (see attn_bwd_dkv_kernel)
     asm volatile("" : "+v"(qf[s]));
@@ -378,25 +375,24 @@ __global__ __launch_bounds__(256, WPS) void attn_bwd_dq3_kernel(const bf16* __re
     __syncthreads();
   auto stage_next = [&](int kt) {
     if (kt + 1 <= kt_last) {
-      char* nxt = smem + ((kt + 1) & 1) * 3 * TILE64;
+      char* nxt = smem + ((kt + 1) & 1) * NT * TILE64;
       stage64u(kbase, iD3, (kt + 1) * 64, S - 1, 0, nxt, wave, lane);
       stage64u(vbase, iD3, (kt + 1) * 64, S - 1, 0, nxt + TILE64, wave, lane);
-      stage64u(ktbase, Sp, 0, HD - 1, (kt + 1) * 64, nxt + 2 * TILE64, wave, lane);
+      if (!TR) stage64u(ktbase, Sp, 0, HD - 1, (kt + 1) * 64, nxt + 2 * TILE64, wave, lane);
     }
   };
-  constexpr bool WIDE = WPS <= 2;
   int kt = 0;
   for (; kt < n_full; ++kt) {
     stage_next(kt);
-    const char* cur = smem + (kt & 1) * 3 * TILE64;
-    dq3_tile<false, WIDE>(cur, cur + TILE64, cur + 2 * TILE64, foff, qf, dof, dqacc, hi, 0, sc, lse2, dlt);
+    const char* cur = smem + (kt & 1) * NT * TILE64;
+    dq3_tile<false, TR>(cur, cur + TILE64, cur + 2 * TILE64, trof, foff, qf, dof, dqacc, hi, 0, sc, lse2, dlt);
     stage_wait_all();
     __syncthreads();
   }
   if (kt <= kt_last) {
     stage_next(kt);
-    const char* cur = smem + (kt & 1) * 3 * TILE64;
-    dq3_tile<true, WIDE>(cur, cur + TILE64, cur + 2 * TILE64, foff, qf, dof, dqacc, hi, qrow - kt * 64, sc, lse2, dlt);
+    const char* cur = smem + (kt & 1) * NT * TILE64;
+    dq3_tile<true, TR>(cur, cur + TILE64, cur + 2 * TILE64, trof, foff, qf, dof, dqacc, hi, qrow - kt * 64, sc, lse2, dlt);
     stage_wait_all();
     __syncthreads();
     ++kt;
@@ -415,95 +411,125 @@ __global__ __launch_bounds__(256, WPS) void attn_bwd_dq3_kernel(const bf16* __re
 // ---------------------------------------------------------------------------------------------------
 // backward, dK/dV: block = 128 key rows, loop over the query tiles that see them
 // ---------------------------------------------------------------------------------------------------
-// one 64-query tile for one wave (32 key rows).  krel = key row - first query of the tile; qlim = number of valid queries
-// in the tile (S - q0, may exceed 64).  Reads per tile: Q / dO fragments of both query blocks in one batch (16), then per
-// query block the dO^T / Q^T fragments (8) and its 32 lse / 32 delta values (8 broadcast reads of 4) ahead of the arithmetic.
-template <bool MASK>
-__device__ inline void dkv3_tile(const char* tQ, const char* tDO, const char* tQT, const char* tDOT, const char* tLD,
-                                 const int (&foff)[4], const bf16x8 (&kf)[4], const bf16x8 (&vf)[4], f32x16 (&dkacc)[2],
-                                 f32x16 (&dvacc)[2], int hi, int krel, int qlim, float sc) {
+// one 32-query block (QB) of a 64-query tile for one wave (32 key rows).  krel = key row - first query of the tile; qlim =
+// number of valid queries in the tile (S - q0, may exceed 64).  TR: the dO^T / Q^T fragments of dV^T += dO^T P and
+// dK^T += Q^T dS come out of the row-major dO / Q tiles through ds_read_b64_tr_b16 (addresses tdo / tq = tile +
+// tr_frag_offsets): no transposed copies of Q and dO in HBM, 5 instead of 9 LDS-DMA requests per wave and tile.
+template <bool MASK, bool TR, int QB>
+__device__ inline void dkv3_half(const char* tQ, const char* tDO, const char* tQT, const char* tDOT, const char* tLD,
+                                 const unsigned (&tq)[2][2], const unsigned (&tdo)[2][2], const int (&foff)[4],
+                                 const bf16x8 (&kf)[4], const bf16x8 (&vf)[4] /* -V */, f32x16 (&dkacc)[2], f32x16 (&dvacc)[2],
+                                 int hi, int krel, int qlim, float sc) {
+  bf16x8 qf[4], dof[4];  // Q / dO fragments of the query block
 #pragma unroll
-  for (int qb = 0; qb < 2; ++qb) {
-    bf16x8 qf[4], dof[4];  // Q / dO fragments of the query block
+  for (int s = 0; s < 4; ++s) {
+    qf[s] = ldsv(tQ + foff[s] + QB * 4096);
+    dof[s] = ldsv(tDO + foff[s] + QB * 4096);
+  }
+  __builtin_amdgcn_sched_barrier(0);
+  // delta goes into the matrix pipe (see dq3_half): the dP chain starts from C = the block's 16 delta values as they lie
+  // in the stage (register r <-> query QB*32 + 16 (r>>3) + 8 hi + (r&7): four 16-byte reads) and multiplies the NEGATED V
+  // fragments, so it delivers delta - dP; dS and dK come out negated (the kernel stores -(-dK)), dV is untouched.
+  f32x16 pacc;
 #pragma unroll
-    for (int s = 0; s < 4; ++s) {
-      qf[s] = ldsv(tQ + foff[s] + qb * 4096);
-      dof[s] = ldsv(tDO + foff[s] + qb * 4096);
-    }
-    __builtin_amdgcn_sched_barrier(0);
-    // delta goes into the matrix pipe (see dq3_tile): the dP chain starts from C = the block's 16 delta values as they lie
-    // in the stage (register r <-> query qb*32 + 16 (r>>3) + 8 hi + (r&7): four 16-byte reads) and multiplies the NEGATED V
-    // fragments, so it delivers delta - dP; dS and dK come out negated (the kernel stores -(-dK)), dV is untouched.
-    f32x16 pacc;
+  for (int i = 0; i < 4; ++i) {
+    const f32x4 d4 = *reinterpret_cast<const f32x4*>(tLD + 1024 + (QB * 32 + 16 * (i >> 1) + 8 * hi + 4 * (i & 1)) * 4);
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const f32x4 d4 = *reinterpret_cast<const f32x4*>(tLD + 1024 + (qb * 32 + 16 * (i >> 1) + 8 * hi + 4 * (i & 1)) * 4);
+    for (int e = 0; e < 4; ++e) pacc[4 * i + e] = d4[e];
+  }
+  __builtin_amdgcn_sched_barrier(0);
+  f32x16 sacc = zero16();
 #pragma unroll
-      for (int e = 0; e < 4; ++e) pacc[4 * i + e] = d4[e];
-    }
-    __builtin_amdgcn_sched_barrier(0);
-    f32x16 sacc = zero16();
+  for (int s = 0; s < 4; ++s) {
+    sacc = mfma32(qf[s], kf[s], sacc);
+    pacc = mfma32(dof[s], vf[s], pacc);
+  }
+  // The block's second half runs in two steps of 16 queries (t): the dO^T / Q^T fragments (queries QB*32 + 16 t + 8 hi .. +7
+  // of row block xb) and the 8 lse values of step t are requested one step ahead -- step 0's under the MFMAs above, step
+  // 1's under the four MFMAs of step 0 -- so that 16 + 8 registers hold them instead of 64.
+  bf16x8 dotf[2][2], qtf[2][2];            // [t][xb]
+  u32x2 dor[2][2][2], qr[2][2][2];         // the same as transpose reads: [t][xb][half]
+  f32x4 la[2][2];                          // [t][v4]: queries QB*32 + 16 t + 8 hi + 4 v4 .. +3
+#define MH_DKV_REQUEST(T)                                                                      \
+  {                                                                                            \
+    if (TR) {                                                                                  \
+      _Pragma("unroll") for (int xb = 0; xb < 2; ++xb) _Pragma("unroll") for (int half = 0; half < 2; ++half) { \
+        dor[T][xb][half] = ds_tr16<(2 * QB + (T)) * 2048>(tdo[xb][half]);                      \
+        qr[T][xb][half] = ds_tr16<(2 * QB + (T)) * 2048>(tq[xb][half]);                        \
+      }                                                                                        \
+    } else {                                                                                   \
+      _Pragma("unroll") for (int xb = 0; xb < 2; ++xb) {                                       \
+        dotf[T][xb] = ldsv(tDOT + foff[2 * QB + (T)] + xb * 4096);                             \
+        qtf[T][xb] = ldsv(tQT + foff[2 * QB + (T)] + xb * 4096);                               \
+      }                                                                                        \
+    }                                                                                          \
+    _Pragma("unroll") for (int v4 = 0; v4 < 2; ++v4)                                           \
+        la[T][v4] = *reinterpret_cast<const f32x4*>(tLD + (QB * 32 + 16 * (T) + 8 * hi + 4 * v4) * 4); \
+  }
+  MH_DKV_REQUEST(0)
+  __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-    for (int s = 0; s < 4; ++s) {
-      sacc = mfma32(qf[s], kf[s], sacc);
-      pacc = mfma32(dof[s], vf[s], pacc);
-    }
-    // The block's second half runs in two steps of 16 queries (t): the dO^T / Q^T fragments (chunk 4 qb + 2 t + hi of row
-    // block xb) and the 8 lse values of step t are requested one step ahead -- step 0's under the MFMAs above, step 1's
-    // under the four MFMAs of step 0 -- so that 16 + 8 registers hold them instead of 64.
-    bf16x8 dotf[2][2], qtf[2][2];  // [t][xb]
-    f32x4 la[2][2];                // [t][v4]: queries qb*32 + 16 t + 8 hi + 4 v4 .. +3
-    auto request = [&](int t) {
+  for (int t = 0; t < 2; ++t) {
 #pragma unroll
-      for (int xb = 0; xb < 2; ++xb) {
-        dotf[t][xb] = ldsv(tDOT + foff[2 * qb + t] + xb * 4096);
-        qtf[t][xb] = ldsv(tQT + foff[2 * qb + t] + xb * 4096);
-      }
+    for (int v4 = 0; v4 < 2; ++v4)
 #pragma unroll
-      for (int v4 = 0; v4 < 2; ++v4) {
-        const int qq = qb * 32 + 16 * t + 8 * hi + 4 * v4;
-        la[t][v4] = *reinterpret_cast<const f32x4*>(tLD + qq * 4);
-      }
-    };
-    request(0);
-    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-    for (int t = 0; t < 2; ++t) {
-#pragma unroll
-      for (int v4 = 0; v4 < 2; ++v4)
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {  // S -> P, delta - dP -> -dS (unscaled), in place
-          const int r = 8 * t + 4 * v4 + e;
-          float p = fast_exp2(__builtin_fmaf(sacc[r], sc, -la[t][v4][e] * LOG2E));
-          float ds = p * pacc[r];
-          if (MASK) {
-            const int q = qb * 32 + 16 * t + 4 * v4 + e;  // (+ 8 hi, moved to the other side: see fwd3_tile)
-            const bool ok = (q >= krel - 8 * hi) && (q < qlim - 8 * hi);
-            p = ok ? p : 0.f;
-            ds = ok ? ds : 0.f;
-          }
-          sacc[r] = p;
-          pacc[r] = ds;
+      for (int e = 0; e < 4; ++e) {  // S -> P, delta - dP -> -dS (unscaled), in place
+        const int r = 8 * t + 4 * v4 + e;
+        float p = fast_exp2(__builtin_fmaf(sacc[r], sc, -la[t][v4][e] * LOG2E));
+        float ds = p * pacc[r];
+        if (MASK) {
+          const int q = QB * 32 + 16 * t + 4 * v4 + e;  // (+ 8 hi, moved to the other side: see fwd3_tile)
+          const bool ok = (q >= krel - 8 * hi) && (q < qlim - 8 * hi);
+          p = ok ? p : 0.f;
+          ds = ok ? ds : 0.f;
         }
-      const bf16x8 pf = pack8_pk(sacc, 8 * t), dsf = pack8_pk(pacc, 8 * t);
-      if (t == 0) request(1);
-      __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-      for (int xb = 0; xb < 2; ++xb) {
-        dvacc[xb] = mfma32(dotf[t][xb], pf, dvacc[xb]);
-        dkacc[xb] = mfma32(qtf[t][xb], dsf, dkacc[xb]);
+        sacc[r] = p;
+        pacc[r] = ds;
       }
+    const bf16x8 pf = pack8_pk(sacc, 8 * t), dsf = pack8_pk(pacc, 8 * t);
+    if (t == 0) {
+      MH_DKV_REQUEST(1)
+      // (step 0's transpose reads were issued ahead of its lse reads, which the arithmetic above has waited for -- LDS
+      // returns in order; the counted wait only states it: step 1's 8 + 2 requests may stay in flight)
+      if (TR) asm volatile("s_waitcnt lgkmcnt(10)" ::: "memory");
+    } else if (TR) {
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int xb = 0; xb < 2; ++xb) {
+      dvacc[xb] = mfma32(TR ? join8(dor[t][xb][0], dor[t][xb][1]) : dotf[t][xb], pf, dvacc[xb]);
+      dkacc[xb] = mfma32(TR ? join8(qr[t][xb][0], qr[t][xb][1]) : qtf[t][xb], dsf, dkacc[xb]);
     }
   }
+#undef MH_DKV_REQUEST
 }
 
+template <bool MASK, bool TR>
+__device__ inline void dkv3_tile(const char* tQ, const char* tDO, const char* tQT, const char* tDOT, const char* tLD,
+                                 const int (&trof)[2][2], const int (&foff)[4], const bf16x8 (&kf)[4], const bf16x8 (&vf)[4],
+                                 f32x16 (&dkacc)[2], f32x16 (&dvacc)[2], int hi, int krel, int qlim, float sc) {
+  unsigned tq[2][2], tdo[2][2];
+#pragma unroll
+  for (int xb = 0; xb < 2; ++xb)
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+      tq[xb][half] = lds_addr32(tQ) + (unsigned)trof[xb][half];
+      tdo[xb][half] = lds_addr32(tDO) + (unsigned)trof[xb][half];
+    }
+  dkv3_half<MASK, TR, 0>(tQ, tDO, tQT, tDOT, tLD, tq, tdo, foff, kf, vf, dkacc, dvacc, hi, krel, qlim, sc);
+  dkv3_half<MASK, TR, 1>(tQ, tDO, tQT, tDOT, tLD, tq, tdo, foff, kf, vf, dkacc, dvacc, hi, krel, qlim, sc);
+}
+
+template <bool TR>
 __global__ __launch_bounds__(256, 2) void attn_bwd_dkv3_kernel(const bf16* __restrict__ qkv, const bf16* __restrict__ dout,
                                                                const float* __restrict__ lse, const float* __restrict__ delta,
                                                                const bf16* __restrict__ qt_, const bf16* __restrict__ dot_,
                                                                bf16* __restrict__ dqkv, int S, int Sp, int H, float scale,
                                                                int BH, int nkt, const float* __restrict__ cos_t,
                                                                const float* __restrict__ sin_t) {
-  constexpr int STG = DKV_STAGE;  // [Q | dO | Q^T | dO^T | lse (256 B of a KiB) | delta (256 B of a KiB)]
+  // one stage: [Q | dO | Q^T | dO^T | lse (256 B of a KiB) | delta (256 B of a KiB)], with transpose reads [Q | dO | lse | delta]
+  constexpr int NT = TR ? 2 : 4, STG = NT * TILE64 + 2048;
   extern __shared__ __attribute__((aligned(16))) char smem[];  // 2 stages
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -522,8 +548,8 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv3_kernel(const bf16* __res
 
   const bf16* qbase = qkv + b * S * D3 + (int64_t)h * HD;
   const bf16* dobase = dout + b * S * D + (int64_t)h * HD;
-  const bf16* qtbase = qt_ + bh * HD * Sp;
-  const bf16* dotbase = dot_ + bh * HD * Sp;
+  const bf16* qtbase = TR ? nullptr : qt_ + bh * HD * Sp;
+  const bf16* dotbase = TR ? nullptr : dot_ + bh * HD * Sp;
   const float* lse_b = lse + bh * Sp;
   const float* delta_b = delta + bh * Sp;
 
@@ -550,13 +576,17 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv3_kernel(const bf16* __res
   auto stage_all = [&](int qt, char* dst) {  // (see attn_bwd_dkv_kernel)
     stage64u(qbase, (int)D3, qt * 64, S - 1, 0, dst, wave, lane);
     stage64u(dobase, (int)D, qt * 64, S - 1, 0, dst + TILE64, wave, lane);
-    stage64u(qtbase, Sp, 0, HD - 1, qt * 64, dst + 2 * TILE64, wave, lane);
-    stage64u(dotbase, Sp, 0, HD - 1, qt * 64, dst + 3 * TILE64, wave, lane);
+    if (!TR) {
+      stage64u(qtbase, Sp, 0, HD - 1, qt * 64, dst + 2 * TILE64, wave, lane);
+      stage64u(dotbase, Sp, 0, HD - 1, qt * 64, dst + 3 * TILE64, wave, lane);
+    }
     if (wave < 2) {
       const float* base = (wave == 0 ? lse_b : delta_b) + (int64_t)qt * 64;
-      glds16_s(base, (unsigned)(lane & 15) * 16u, __builtin_amdgcn_readfirstlane(lds_u32(dst + 4 * TILE64 + wave * 1024)));
+      glds16_s(base, (unsigned)(lane & 15) * 16u, __builtin_amdgcn_readfirstlane(lds_u32(dst + NT * TILE64 + wave * 1024)));
     }
   };
+  int trof[2][2];
+  tr_frag_offsets(lane, trof);
   if (qt_first <= qt_last) stage_all(qt_first, smem);
 #pragma unroll
   for (int s = 0; s < 4; ++s) {
@@ -589,7 +619,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv3_kernel(const bf16* __res
   }
   if (n_mask) {
     const char* cur = head(qt);
-    dkv3_tile<true>(cur, cur + TILE64, cur + 2 * TILE64, cur + 3 * TILE64, cur + 4 * TILE64, foff, kf, vf, dkacc, dvacc, hi,
+    dkv3_tile<true, TR>(cur, cur + TILE64, cur + 2 * TILE64, cur + 3 * TILE64, cur + NT * TILE64, trof, foff, kf, vf, dkacc, dvacc, hi,
                     krow - qt * 64, S - qt * 64, sc);
     stage_wait_all();
     __syncthreads();
@@ -597,14 +627,14 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv3_kernel(const bf16* __res
   }
   for (int i = 0; i < n_full; ++i, ++qt) {
     const char* cur = head(qt);
-    dkv3_tile<false>(cur, cur + TILE64, cur + 2 * TILE64, cur + 3 * TILE64, cur + 4 * TILE64, foff, kf, vf, dkacc, dvacc, hi, 0,
+    dkv3_tile<false, TR>(cur, cur + TILE64, cur + 2 * TILE64, cur + 3 * TILE64, cur + NT * TILE64, trof, foff, kf, vf, dkacc, dvacc, hi, 0,
                      64, sc);
     stage_wait_all();
     __syncthreads();
   }
   if (n_tail > 0) {
     const char* cur = head(qt);
-    dkv3_tile<true>(cur, cur + TILE64, cur + 2 * TILE64, cur + 3 * TILE64, cur + 4 * TILE64, foff, kf, vf, dkacc, dvacc, hi,
+    dkv3_tile<true, TR>(cur, cur + TILE64, cur + 2 * TILE64, cur + 3 * TILE64, cur + NT * TILE64, trof, foff, kf, vf, dkacc, dvacc, hi,
                     krow - qt * 64, S - qt * 64, sc);
     stage_wait_all();
     __syncthreads();
@@ -634,24 +664,36 @@ int mh_attn_fwd_mfma3(const void* qkv, const void* vt, void* o, float* lse, int6
 
 int mh_attn_bwd_mfma3(const void* qkv, const void* dout, const float* lse, const float* delta, const void* qt, const void* kt,
                       const void* dot, void* dqkv, int64_t B, int64_t S, int H, float scale, const float* cos_t,
-                      const float* sin_t, int which /* bit 1: dQ, bit 2: dK/dV */, hipStream_t st) {
+                      const float* sin_t, int which /* bit 1: dQ, bit 2: dK/dV, bit 3: transpose reads (no qt / kt / dot) */,
+                      hipStream_t st) {
   MH_REQUIRE(S * 3 * H * HD < (int64_t(1) << 31), "attn_bwd: sequence too long (32-bit panel offsets)");
+  const bool tr = (which & 8) != 0;
+  MH_REQUIRE(tr || (qt != nullptr && kt != nullptr && dot != nullptr), "attn_bwd(bf16): needs the transposed copies (mh_attn_prep_bwd)");
   const int64_t Sp = (S + 63) / 64 * 64;
   const int nt = (int)((S + 127) / 128), BH = (int)(B * H);
   const unsigned grid = (unsigned)(nt * 8 * ((BH + 7) / 8));
+#define MH_DQ(WPS, TR_)                                                                                                     \
+  attn_bwd_dq3_kernel<WPS, TR_><<<grid, 256, (TR_ ? 4 : 6) * TILE64, st>>>((const bf16*)qkv, (const bf16*)dout, lse, delta,     \
+                                                                        (const bf16*)kt, (bf16*)dqkv, (int)S, (int)Sp, H, scale, \
+                                                                        BH, nt, cos_t, sin_t)
   if (which & 2) {
-    if (g_attn_v3_wps == 2)  // (wide fragment batches at two waves per SIMD: measured 1-3 % behind the narrow form at three)
-      attn_bwd_dq3_kernel<2><<<grid, 256, 6 * TILE64, st>>>((const bf16*)qkv, (const bf16*)dout, lse, delta, (const bf16*)kt,
-                                                         (bf16*)dqkv, (int)S, (int)Sp, H, scale, BH, nt, cos_t, sin_t);
-    else
-      attn_bwd_dq3_kernel<3><<<grid, 256, 6 * TILE64, st>>>((const bf16*)qkv, (const bf16*)dout, lse, delta, (const bf16*)kt,
-                                                         (bf16*)dqkv, (int)S, (int)Sp, H, scale, BH, nt, cos_t, sin_t);
+    if (g_attn_v3_wps == 2) {
+      if (tr) MH_DQ(2, true); else MH_DQ(2, false);
+    } else {
+      if (tr) MH_DQ(3, true); else MH_DQ(3, false);
+    }
     MH_LAUNCH_CHECK();
   }
+#undef MH_DQ
   if (which & 4) {
-    attn_bwd_dkv3_kernel<<<grid, 256, 2 * DKV_STAGE, st>>>((const bf16*)qkv, (const bf16*)dout, lse, delta, (const bf16*)qt,
-                                                         (const bf16*)dot, (bf16*)dqkv, (int)S, (int)Sp, H, scale, BH, nt, cos_t,
-                                                         sin_t);
+    if (tr)
+      attn_bwd_dkv3_kernel<true><<<grid, 256, 2 * (2 * TILE64 + 2048), st>>>((const bf16*)qkv, (const bf16*)dout, lse, delta, nullptr,
+                                                                           nullptr, (bf16*)dqkv, (int)S, (int)Sp, H, scale, BH, nt,
+                                                                           cos_t, sin_t);
+    else
+      attn_bwd_dkv3_kernel<false><<<grid, 256, 2 * DKV_STAGE, st>>>((const bf16*)qkv, (const bf16*)dout, lse, delta, (const bf16*)qt,
+                                                                  (const bf16*)dot, (bf16*)dqkv, (int)S, (int)Sp, H, scale, BH, nt,
+                                                                  cos_t, sin_t);
     MH_LAUNCH_CHECK();
   }
   return MH_OK;

@@ -861,7 +861,7 @@ extern "C" int mh_attn_prep_bwd(const void* qkv, const void* o, const void* dout
   if (g > 16384) g = 16384;
   DISPATCH_T(dtype, (attn_delta_kernel<T><<<(int)g, 256, 0, st>>>((const T*)o, (const T*)dout, delta, B, S, H)));
   MH_LAUNCH_CHECK();
-  if (dtype != MH_BF16) return MH_OK;
+  if (dtype != MH_BF16 || qt == nullptr) return MH_OK;  // (no buffers: the backward reads its transposed operands itself)
   const int64_t D = (int64_t)H * 64;
   int rc;
   if ((rc = transpose_heads<bf16>((const bf16*)qkv, 3 * D, 0, (bf16*)qt, B, S, H, st)) != MH_OK) return rc;

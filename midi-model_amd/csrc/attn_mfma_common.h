@@ -80,6 +80,48 @@ __device__ inline void stage64u(const bf16* __restrict__ base, int ld, int row0,
   }
 }
 
+// The transpose reads are issued from inline asm: through the builtin hipcc puts an s_waitcnt vmcnt(0) in front of every
+// ds_read_b64_tr_b16 while an LDS-DMA is outstanding (it cannot tell the stages apart), which would drain the stage requested
+// at the top of the tile.  The asm reads are invisible to its counters, so they are waited for by hand (lgkmcnt(0) +
+// sched_barrier before the first consumer; cdna_hip_programming.md 5.7 form iii).
+typedef __attribute__((ext_vector_type(2))) unsigned int u32x2;
+template <int OFF>
+__device__ inline u32x2 ds_tr16(unsigned lds_addr) {
+  u32x2 r;
+  asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(r) : "v"(lds_addr), "i"(OFF));
+  return r;
+}
+__device__ inline unsigned lds_addr32(const char* p) {
+  return (unsigned)(uintptr_t)(__attribute__((address_space(3))) const char*)p;
+}
+__device__ inline bf16x8 join8(const u32x2& a, const u32x2& b) {
+  union {
+    bf16x8 v;
+    u32x2 h[2];
+  } u;
+  u.h[0] = a;
+  u.h[1] = b;
+  return u.v;
+}
+
+// Per-lane byte offsets for reading a TRANSPOSED 32x32x16 operand fragment out of a row-major 64-row tile (rows = the
+// contraction index, 128-byte swizzled rows) with ds_read_b64_tr_b16: a 16-lane group reads a [4 rows][16 columns] block and
+// lane i of the group receives column i (4 rows); supplier p of group g points at row 8 hi + 4 half + (p >> 2), columns
+// xb*32 + 16 (g&1) + 8 (p&1) + 4 ((p>>1)&1) .. +3, which hands output lane i column xb*32 + pi32(16 (g&1) + i) -- the row
+// permutation the accumulator layout wants.  Two reads (half = 0, 1) make one 8-deep fragment; the 16-row step t of the
+// contraction is the immediate t * 2048 (it leaves the swizzle term (row >> 1) & 7 unchanged).
+__device__ inline void tr_frag_offsets(int lane, int (&voff)[2][2]) {
+  const int p = lane & 15, gb = (lane >> 4) & 1, hi = lane >> 5;
+#pragma unroll
+  for (int xb = 0; xb < 2; ++xb)
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+      const int row = 8 * hi + 4 * half + (p >> 2);
+      const int col = xb * 32 + 16 * gb + 8 * (p & 1) + 4 * ((p >> 1) & 1);
+      voff[xb][half] = lds_tile_off(row, col >> 3) + (col & 7) * 2;
+    }
+}
+
 // Store one lane's share of a 64-wide gradient row (acc[hb][16]: elements hb*32 + 16*r8 + 8*hi + e), optionally through
 // the transpose of the RoPE rotation at position `pos` (the gradient with respect to the unrotated projection): the
 // partners d and d + 32 are acc[0][.] and acc[1][.] of the same lane.  Roundings as the separate pass it replaces

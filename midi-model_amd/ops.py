@@ -48,12 +48,17 @@ def round_up(x: int, m: int) -> int:
 _gemm_variant = None
 
 
+_attn_v3 = None  # cached mh_get_option("attn_v3"): which forms of the event-level attention kernels run (attn_bwd)
+
+
 def set_option(name: str, value: int) -> None:
     """runtime kernel selection (see mh_set_option in include/midihip.h)"""
-    global _gemm_variant
+    global _gemm_variant, _attn_v3
     lib().call("mh_set_option", name.encode(), int(value))
     if name == "gemm":
         _gemm_variant = int(value)
+    if name == "attn_v3":
+        _attn_v3 = int(value)
 
 
 def get_option(name: str) -> int:
@@ -342,10 +347,15 @@ def attn_fwd(qkv, o, lse, B: int, S: int, H: int, scale: float):
 
 def attn_bwd(qkv, o, dout, lse, dqkv, B: int, S: int, H: int, scale: float, cos_t=None, sin_t=None):
     """cos_t/sin_t: return the gradient with respect to the UNROTATED q, k (see mh_attn_bwd)"""
+    global _attn_v3
+    if _attn_v3 is None:
+        _attn_v3 = get_option("attn_v3")
     Sp = round_up(S, 64)
     delta = torch.empty((B * H * Sp,), dtype=torch.float32, device=qkv.device)
     qt = kt = dot = None
-    if qkv.dtype == torch.bfloat16:
+    # (third form with transpose reads, the default: dQ and dK/dV take Q^T, K^T, dO^T out of the row-major tiles in LDS --
+    #  no [B,H,64,Sp] copies, mh_attn_prep_bwd only computes delta)
+    if qkv.dtype == torch.bfloat16 and (_attn_v3 & 14) != 14:
         n = B * H * 64 * Sp
         buf = torch.empty((3, n), dtype=qkv.dtype, device=qkv.device)
         qt, kt, dot = buf[0], buf[1], buf[2]

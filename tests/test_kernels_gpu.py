@@ -283,7 +283,9 @@ def test_rope(ops, dtype, H, hd, S, M):
 # ------------------------------------------------------------------------------ event-level attention
 # form -> (ops.ATTN_FWD_FORM, attn_fwd_qb, attn_fwd_wps, attn_v3 bits, attn_v3_wps)
 ATTN_FORMS = {
-    "v3": (1, 1, 2, 7, 0),                      # third form of all three kernels (the default)
+    "v3_tr": (1, 1, 2, 15, 0),                  # third form of all three kernels, backward with transpose reads (the default)
+    "v3_tr_wps2": (1, 1, 2, 15, 2),
+    "v3": (1, 1, 2, 7, 0),                      # ... backward from the prepared transposed copies
     "v3_wps2": (1, 1, 2, 7, 2),                 # ... held to two / three waves per SIMD (dQ: wide / narrow fragment batches)
     "v3_wps3": (1, 1, 2, 7, 3),
     "fwd1_preparedVT": (1, 1, 2, 0, 0),         # first form of all three kernels
@@ -300,7 +302,7 @@ def test_attention_fwd_bwd(ops, monkeypatch, form, dtype, B, S, H):
     """(bf16: every form of the MFMA kernels -- the third form (fragment batches, one loop per tile class), the first form
     with its prepared V^T copy, the transpose-read / three-stage-ring forward, the two-query-block forward; fp32 runs the
     plain verification kernel either way)"""
-    if dtype == torch.float32 and form != "v3":
+    if dtype == torch.float32 and form != "v3_tr":
         pytest.skip("fp32 has one forward kernel")
     fwd_form, qb, wps, v3, v3_wps = ATTN_FORMS[form]
     monkeypatch.setattr(ops, "ATTN_FWD_FORM", fwd_form)
@@ -337,7 +339,7 @@ def test_attention_fwd_bwd(ops, monkeypatch, form, dtype, B, S, H):
     assert same > 0.99, f"fused rotation agrees with the separate pass on only {same:.4f} of the elements"
     ops.set_option("attn_fwd_qb", 1)
     ops.set_option("attn_fwd_wps", 2)
-    ops.set_option("attn_v3", 7)
+    ops.set_option("attn_v3", 15)
     ops.set_option("attn_v3_wps", 0)
 
 
@@ -359,7 +361,7 @@ def test_attention_forward_when_the_reference_has_to_move(ops, v3):
     ops.set_option("attn_v3", v3)
     o, lse = torch.empty((B * S, D), dtype=torch.bfloat16, device="cuda"), torch.zeros(B * H * Sp, device="cuda")
     ops.attn_fwd(qkv.cuda(), o, lse, B, S, H, 0.125)
-    ops.set_option("attn_v3", 7)
+    ops.set_option("attn_v3", 15)
     assert torch.isfinite(o.float()).all() and torch.isfinite(lse).all()
     cmp(o, o_ref, torch.bfloat16, what="attn o (moving reference)")
     got, want = lse.view(B, H, Sp)[:, :, :S].cpu(), lse_ref.view(B, H, Sp)[:, :, :S]
