@@ -776,7 +776,8 @@ int mh_attn_bwd_mfma3(const void* qkv, const void* dout, const float* lse, const
 int mh_attn_fwd_mfma(const void* qkv, const void* vt, void* o, float* lse, int64_t B, int64_t S, int H, float scale,
                      hipStream_t st) {
   MH_REQUIRE(S < (1 << 24), "attn_fwd: sequence too long");
-  if (vt != nullptr && g_attn_fwd_qb != 2 && (g_attn_v3 & 1)) return mh_attn_fwd_mfma3(qkv, vt, o, lse, B, S, H, scale, st);
+  if (g_attn_fwd_qb != 2 && (g_attn_v3 & 1) && (vt != nullptr || (g_attn_v3 & 16)))  // (vt == NULL + bit 4: V through transpose reads)
+    return mh_attn_fwd_mfma3(qkv, vt, o, lse, B, S, H, scale, st);
   const int64_t Sp = (S + 63) / 64 * 64;
   const int nt = (int)((S + 127) / 128), BH = (int)(B * H);
   const unsigned grid = (unsigned)(nt * 8 * ((BH + 7) / 8));

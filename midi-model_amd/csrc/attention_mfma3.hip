@@ -21,7 +21,8 @@
 // Roofline: MFMA (2.5 PFLOP/s bf16 dense), VALU co-limited at head_dim 64.
 #include "attn_mfma_common.h"
 
-int g_attn_v3 = 15;     // mh_set_option("attn_v3", bits): 1 forward, 2 dQ, 4 dK/dV, 8 transpose reads in dQ + dK/dV (needs 2 | 4)
+int g_attn_v3 = 31;     // mh_set_option("attn_v3", bits): 1 forward, 2 dQ, 4 dK/dV, 8 transpose reads in dQ + dK/dV (needs 2 | 4),
+                        // 16 transpose reads in the forward (needs 1; the caller then passes no V^T copy)
 int g_attn_v3_wps = 0;  // mh_set_option("attn_v3_wps", n): register budget (waves per SIMD) override for A/B runs, 0 = default
 
 __device__ inline bf16x8 ldsv(const char* p) { return *reinterpret_cast<const bf16x8*>(p); }
@@ -54,9 +55,10 @@ __device__ inline float xhalf_max(float v) {  // max with the other wave half's 
 // (Where the time goes, measured by leaving parts out of this kernel -- profiles/r02_run16_attn_forms_ab_and_fwd_ablation.txt,
 // B=16, S=4096, 684 us complete: no v_exp -40, no row maximum -8, no P V MFMAs -100, no Q K^T MFMAs -68, no MFMAs -151, no
 // fragment reads -55, neither -278; staging + barriers + the sums alone 333 us.)
-template <bool MASK>
-__device__ inline void fwd3_tile(const char* tK, const char* tV, const int (&foff)[4], const bf16x8 (&qf)[4],
-                                 f32x16 (&oacc)[2], float& m, float& l, int hi, int qrel, float sc) {
+// TR: tV is the row-major V tile [key][d] and the V^T fragments are transpose reads (no prepared [B,H,64,Sp] copy of V).
+template <bool MASK, bool TR>
+__device__ inline void fwd3_tile(const char* tK, const char* tV, const int (&trof)[2][2], const int (&foff)[4],
+                                 const bf16x8 (&qf)[4], f32x16 (&oacc)[2], float& m, float& l, int hi, int qrel, float sc) {
   bf16x8 kf[2][4];
 #pragma unroll
   for (int s = 0; s < 4; ++s)
@@ -68,11 +70,29 @@ __device__ inline void fwd3_tile(const char* tK, const char* tV, const int (&fof
   for (int s = 0; s < 4; ++s)
 #pragma unroll
     for (int kb = 0; kb < 2; ++kb) sacc[kb] = mfma32(kf[kb][s], qf[s], sacc[kb]);  // two independent accumulator chains
-  bf16x8 vf[4][2];  // the V^T fragments: in flight under the softmax arithmetic
+  bf16x8 vf[4][2];    // the V^T fragments: in flight under the softmax arithmetic
+  u32x2 vr[4][2][2];  // the same as transpose reads: [t][db][half]
+  if (TR) {
+    unsigned tv[2][2];
 #pragma unroll
-  for (int t = 0; t < 4; ++t)
+    for (int db = 0; db < 2; ++db)
 #pragma unroll
-    for (int db = 0; db < 2; ++db) vf[t][db] = ldsv(tV + foff[t] + db * 4096);
+      for (int half = 0; half < 2; ++half) tv[db][half] = lds_addr32(tV) + (unsigned)trof[db][half];
+#pragma unroll
+    for (int db = 0; db < 2; ++db)
+#pragma unroll
+      for (int half = 0; half < 2; ++half) {
+        vr[0][db][half] = ds_tr16<0>(tv[db][half]);
+        vr[1][db][half] = ds_tr16<2048>(tv[db][half]);
+        vr[2][db][half] = ds_tr16<4096>(tv[db][half]);
+        vr[3][db][half] = ds_tr16<6144>(tv[db][half]);
+      }
+  } else {
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+      for (int db = 0; db < 2; ++db) vf[t][db] = ldsv(tV + foff[t] + db * 4096);
+  }
   __builtin_amdgcn_sched_barrier(0);
   float mx = -INFINITY;
 #pragma unroll
@@ -110,15 +130,20 @@ __device__ inline void fwd3_tile(const char* tK, const char* tV, const int (&fof
     ps1 += p1;
   }
   l += ps0 + ps1;
+  bf16x8 pf[4];
 #pragma unroll
-  for (int t = 0; t < 4; ++t) {
-    const bf16x8 pf = pack8_pk(sacc[t >> 1], 8 * (t & 1));
-#pragma unroll
-    for (int db = 0; db < 2; ++db) oacc[db] = mfma32(vf[t][db], pf, oacc[db]);
+  for (int t = 0; t < 4; ++t) pf[t] = pack8_pk(sacc[t >> 1], 8 * (t & 1));
+  if (TR) {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the transpose reads (asm: invisible to hipcc's counters)
+    __builtin_amdgcn_sched_barrier(0);
   }
+#pragma unroll
+  for (int t = 0; t < 4; ++t)
+#pragma unroll
+    for (int db = 0; db < 2; ++db) oacc[db] = mfma32(TR ? join8(vr[t][db][0], vr[t][db][1]) : vf[t][db], pf[t], oacc[db]);
 }
 
-template <int WPS>
+template <int WPS, bool TR>
 __global__ __launch_bounds__(256, WPS) void attn_fwd3_kernel(const bf16* __restrict__ qkv, const bf16* __restrict__ vt,
                                                           bf16* __restrict__ o, float* __restrict__ lse, int S, int Sp, int H,
                                                           float sc /* scale*log2(e) */, int BH, int nqt) {
@@ -138,7 +163,7 @@ __global__ __launch_bounds__(256, WPS) void attn_fwd3_kernel(const bf16* __restr
   const int qld = (qrow < S) ? qrow : S - 1;
 
   const bf16* kbase = qkv + b * S * D3 + D + (int64_t)h * HD;
-  const bf16* vtbase = vt + bh * HD * Sp;
+  const bf16* vtbase = TR ? kbase + D : vt + bh * HD * Sp;  // (TR: V row-major, straight out of the fused qkv rows)
 
   bf16x8 qf[4];
   {
@@ -165,7 +190,10 @@ __global__ __launch_bounds__(256, WPS) void attn_fwd3_kernel(const bf16* __restr
 
   const int iD3 = (int)D3;
   stage64u(kbase, iD3, 0, S - 1, 0, smem, wave, lane);
-  stage64u(vtbase, Sp, 0, HD - 1, 0, smem + TILE64, wave, lane);
+  int trof[2][2];
+  tr_frag_offsets(lane, trof);
+  if (TR) stage64u(vtbase, iD3, 0, S - 1, 0, smem + TILE64, wave, lane);
+  else stage64u(vtbase, Sp, 0, HD - 1, 0, smem + TILE64, wave, lane);
 #pragma unroll
   for (int s = 0; s < 4; ++s) asm volatile("" : "+v"(qf[s]));  // (see attn_bwd_dkv_kernel)
   stage_wait_all();
@@ -174,21 +202,22 @@ __global__ __launch_bounds__(256, WPS) void attn_fwd3_kernel(const bf16* __restr
     if (kt + 1 <= kt_last) {
       char* nxt = smem + ((kt + 1) & 1) * 2 * TILE64;
       stage64u(kbase, iD3, (kt + 1) * 64, S - 1, 0, nxt, wave, lane);
-      stage64u(vtbase, Sp, 0, HD - 1, (kt + 1) * 64, nxt + TILE64, wave, lane);
+      if (TR) stage64u(vtbase, iD3, (kt + 1) * 64, S - 1, 0, nxt + TILE64, wave, lane);
+      else stage64u(vtbase, Sp, 0, HD - 1, (kt + 1) * 64, nxt + TILE64, wave, lane);
     }
   };
   int kt = 0;
   for (; kt < n_full; ++kt) {
     stage_next(kt);
     const char* cur = smem + (kt & 1) * 2 * TILE64;
-    fwd3_tile<false>(cur, cur + TILE64, foff, qf, oacc, m, l, hi, 0, sc);
+    fwd3_tile<false, TR>(cur, cur + TILE64, trof, foff, qf, oacc, m, l, hi, 0, sc);
     stage_wait_all();
     __syncthreads();
   }
   if (kt <= kt_last) {
     stage_next(kt);
     const char* cur = smem + (kt & 1) * 2 * TILE64;
-    fwd3_tile<true>(cur, cur + TILE64, foff, qf, oacc, m, l, hi, qrow - kt * 64, sc);
+    fwd3_tile<true, TR>(cur, cur + TILE64, trof, foff, qf, oacc, m, l, hi, qrow - kt * 64, sc);
     stage_wait_all();
     __syncthreads();
     ++kt;
@@ -652,12 +681,18 @@ int mh_attn_fwd_mfma3(const void* qkv, const void* vt, void* o, float* lse, int6
   const int64_t Sp = (S + 63) / 64 * 64;
   const int nt = (int)((S + 127) / 128), BH = (int)(B * H);
   const unsigned grid = (unsigned)(nt * 8 * ((BH + 7) / 8));
-  if (g_attn_v3_wps == 2)
-    attn_fwd3_kernel<2><<<grid, 256, 4 * TILE64, st>>>((const bf16*)qkv, (const bf16*)vt, (bf16*)o, lse, (int)S, (int)Sp, H,
-                                                     scale * LOG2E, BH, nt);
-  else
-    attn_fwd3_kernel<3><<<grid, 256, 4 * TILE64, st>>>((const bf16*)qkv, (const bf16*)vt, (bf16*)o, lse, (int)S, (int)Sp, H,
-                                                     scale * LOG2E, BH, nt);
+#define MH_FWD(WPS, TR_)                                                                                                    \
+  attn_fwd3_kernel<WPS, TR_><<<grid, 256, 4 * TILE64, st>>>((const bf16*)qkv, (const bf16*)vt, (bf16*)o, lse, (int)S, (int)Sp, H, \
+                                                          scale * LOG2E, BH, nt)
+  const bool tr = (vt == nullptr);  // no prepared V^T copy: transpose reads
+  // (register budget: with transpose reads the 256-register build measured 1-2 % ahead, with the prepared copy the
+  //  168-register one; both fit three waves per SIMD -- profiles/r02_run18_attn_forms_ab.txt)
+  if (tr) {
+    if (g_attn_v3_wps == 3) MH_FWD(3, true); else MH_FWD(2, true);
+  } else {
+    if (g_attn_v3_wps == 2) MH_FWD(2, false); else MH_FWD(3, false);
+  }
+#undef MH_FWD
   MH_LAUNCH_CHECK();
   return MH_OK;
 }

@@ -336,8 +336,12 @@ def attn_fwd(qkv, o, lse, B: int, S: int, H: int, scale: float):
             set_option("attn_v3", int(os.environ["MH_ATTN_V3"]))
         if "MH_ATTN_V3_WPS" in os.environ:
             set_option("attn_v3_wps", int(os.environ["MH_ATTN_V3_WPS"]))
+    global _attn_v3
+    if _attn_v3 is None:
+        _attn_v3 = get_option("attn_v3")
     vt = None
-    if qkv.dtype == torch.bfloat16 and ATTN_FWD_FORM == 1:
+    # (attn_v3 bits 0 + 4: third form with V through transpose reads -- no prepared V^T copy)
+    if qkv.dtype == torch.bfloat16 and ATTN_FWD_FORM == 1 and (_attn_v3 & 17) != 17:
         Sp = round_up(S, 64)
         vt = torch.empty((B * H * 64 * Sp,), dtype=qkv.dtype, device=qkv.device)
         lib().call("mh_attn_prep_fwd", _p(qkv), _p(vt), B, S, H, dt(qkv), _stream())

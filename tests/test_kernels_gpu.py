@@ -283,7 +283,9 @@ def test_rope(ops, dtype, H, hd, S, M):
 # ------------------------------------------------------------------------------ event-level attention
 # form -> (ops.ATTN_FWD_FORM, attn_fwd_qb, attn_fwd_wps, attn_v3 bits, attn_v3_wps)
 ATTN_FORMS = {
-    "v3_tr": (1, 1, 2, 15, 0),                  # third form of all three kernels, backward with transpose reads (the default)
+    "v3_tr_all": (1, 1, 2, 31, 0),              # third form of all three kernels, transpose reads in all of them (no copies)
+    "v3_tr_all_wps2": (1, 1, 2, 31, 2),
+    "v3_tr": (1, 1, 2, 15, 0),                  # ... forward from the prepared V^T copy
     "v3_tr_wps2": (1, 1, 2, 15, 2),
     "v3": (1, 1, 2, 7, 0),                      # ... backward from the prepared transposed copies
     "v3_wps2": (1, 1, 2, 7, 2),                 # ... held to two / three waves per SIMD (dQ: wide / narrow fragment batches)
@@ -302,7 +304,7 @@ def test_attention_fwd_bwd(ops, monkeypatch, form, dtype, B, S, H):
     """(bf16: every form of the MFMA kernels -- the third form (fragment batches, one loop per tile class), the first form
     with its prepared V^T copy, the transpose-read / three-stage-ring forward, the two-query-block forward; fp32 runs the
     plain verification kernel either way)"""
-    if dtype == torch.float32 and form != "v3_tr":
+    if dtype == torch.float32 and form != "v3_tr_all":
         pytest.skip("fp32 has one forward kernel")
     fwd_form, qb, wps, v3, v3_wps = ATTN_FORMS[form]
     monkeypatch.setattr(ops, "ATTN_FWD_FORM", fwd_form)
@@ -339,11 +341,11 @@ def test_attention_fwd_bwd(ops, monkeypatch, form, dtype, B, S, H):
     assert same > 0.99, f"fused rotation agrees with the separate pass on only {same:.4f} of the elements"
     ops.set_option("attn_fwd_qb", 1)
     ops.set_option("attn_fwd_wps", 2)
-    ops.set_option("attn_v3", 15)
+    ops.set_option("attn_v3", 31)
     ops.set_option("attn_v3_wps", 0)
 
 
-@pytest.mark.parametrize("v3", [7, 0], ids=["v3", "first_form"])
+@pytest.mark.parametrize("v3", [31, 7, 0], ids=["v3_tr", "v3", "first_form"])
 def test_attention_forward_when_the_reference_has_to_move(ops, v3):
     """Rows whose scores jump by far more than the lazy-rescale threshold between tiles (a few keys late in the sequence
     are scaled up 8x and 24x: q.k/8 moves by tens to more than a hundred log2 units), plus a first tile of tiny scores."""
@@ -361,7 +363,7 @@ def test_attention_forward_when_the_reference_has_to_move(ops, v3):
     ops.set_option("attn_v3", v3)
     o, lse = torch.empty((B * S, D), dtype=torch.bfloat16, device="cuda"), torch.zeros(B * H * Sp, device="cuda")
     ops.attn_fwd(qkv.cuda(), o, lse, B, S, H, 0.125)
-    ops.set_option("attn_v3", 15)
+    ops.set_option("attn_v3", 31)
     assert torch.isfinite(o.float()).all() and torch.isfinite(lse).all()
     cmp(o, o_ref, torch.bfloat16, what="attn o (moving reference)")
     got, want = lse.view(B, H, Sp)[:, :, :S].cpu(), lse_ref.view(B, H, Sp)[:, :, :S]
