@@ -299,8 +299,8 @@ def measure_block(args, B: int, S: int, steps: int, warmup: int, dist=None):
     del model
     torch.cuda.empty_cache()
     return {
-        "what": "one net block forward (LlamaDecoderLayer.forward, TF modeling_llama.py:295-324): RMSNorm, q|k|v, RoPE, causal "
-                "flash attention, o + residual, RMSNorm, gate|up + SwiGLU, down + residual",
+        "what": "one net block forward (LlamaDecoderLayer.forward, TF modeling_llama.py:295-324): RMSNorm, q|k|v + RoPE (projection "
+                "epilogue), causal flash attention, o + residual, RMSNorm, gate|up + SwiGLU (projection epilogue), down + residual",
         "form": "training forward (activations kept for the backward)" if args.block_save else "forward only (prefill / validation: gate|up not stored)",
         "batch": B, "seq_len": S, "dtype": args.dtype, "ms_per_block": 1e3 * dt / steps, "events_per_s": B * S * steps / dt,
         "flops_per_event": block_flops_per_event(S, spec.D, spec.I),

@@ -63,6 +63,14 @@ int mh_gemm(const void* A, int64_t lda, int transA, const void* B, int64_t ldb, 
  * bf16, production GEMM kernel only (option "gemm" != 0), I % 128 == 0; fails loudly otherwise. */
 int mh_gemm_swiglu(const void* A, int64_t lda, const void* W, int64_t ldw, void* GU, int64_t ldgu, void* ACT,
                    int64_t ldact, int64_t M, int64_t I, int64_t K, int dtype, void* stream);
+/* q|k|v projection with the rotary embedding as its epilogue (LlamaAttention.forward: q_proj / k_proj / v_proj, then
+ * apply_rotary_pos_emb on q and k, modeling_llama.py:151-169, 243-260): C[M, N = 3 * heads * 64] = A[M,K] * W[N,K]^T rounded
+ * to bf16, then the q and k heads rotated at position pos0 + m % S.  `table` = bf16 [npos][96]: cos(32) | -sin(32) | +sin(32)
+ * of pos * theta^(-2i/64), i.e. cos / sin already cast to the activation dtype as the reference does (modeling_llama.py:126).
+ * Same results as mh_gemm followed by mh_rope, without the extra pass over q and k.  bf16, production GEMM kernel only
+ * (option "gemm" != 0), head_dim 64; fails loudly otherwise. */
+int mh_gemm_rope(const void* A, int64_t lda, const void* W, int64_t ldw, void* C, int64_t ldc, const void* table,
+                 int64_t npos, int64_t S, int64_t pos0, int head_dim, int64_t M, int64_t N, int64_t K, int dtype, void* stream);
 /* down_proj dgrad with the SwiGLU backward as its epilogue (LlamaMLP backward, modeling_llama.py:174-176):
  *   d a = A[M,K] * B[K,I] (B contraction-major, as mh_gemm with transB), rounded to the activation dtype, then
  *   DGU[:, :I] = d a * up * silu'(gate),  DGU[:, I:] = d a * silu(gate)     with GU = gate|up of the forward [M, 2I].

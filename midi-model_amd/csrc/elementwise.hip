@@ -593,8 +593,8 @@ __global__ __launch_bounds__(256) void rope_kernel(T* __restrict__ qkv, const fl
     for (int e = 0; e < N; ++e) {
       const float c = rnd<T>(cp[e]), s = dir * rnd<T>(sp[e]);
       const float x1 = a.get(e), x2 = b.get(e);
-      oa.set(e, x1 * c - x2 * s);
-      ob.set(e, x2 * c + x1 * s);
+      oa.set(e, __builtin_fmaf(x1, c, -(x2 * s)));  // (spelled out: mh_gemm_rope's epilogue forms the same products)
+      ob.set(e, __builtin_fmaf(x2, c, x1 * s));
     }
     st16(p1, oa);
     st16(p2, ob);

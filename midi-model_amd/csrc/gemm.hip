@@ -347,6 +347,23 @@ extern "C" int mh_gemm_swiglu(const void* A, int64_t lda, const void* W, int64_t
   return mh_gemm_pp256_swiglu_bf16(A, lda, W, ldw, GU, ldgu, ACT, ldact, M, I, K, (hipStream_t)stream);
 }
 
+int mh_gemm_pp256_rope_bf16(const void* A, int64_t lda, const void* W, int64_t ldw, void* C, int64_t ldc, const void* table,
+                            int64_t S, int64_t pos0, int64_t M, int64_t N, int64_t K, hipStream_t st);
+
+extern "C" int mh_gemm_rope(const void* A, int64_t lda, const void* W, int64_t ldw, void* C, int64_t ldc, const void* table,
+                            int64_t npos, int64_t S, int64_t pos0, int head_dim, int64_t M, int64_t N, int64_t K, int dtype,
+                            void* stream) {
+  MH_REQUIRE(dtype == MH_BF16 && g_mh_gemm_variant != 0,
+             "gemm_rope: served by the production bf16 kernel only (use mh_gemm + mh_rope otherwise)");
+  MH_REQUIRE(M > 0 && K > 0 && N > 0 && N % 192 == 0 && head_dim == 64,
+             "gemm_rope: bad shape M=%ld N=%ld K=%ld head_dim=%d (N = 3 * heads * 64)", (long)M, (long)N, (long)K, head_dim);
+  MH_REQUIRE(S > 0 && pos0 >= 0 && pos0 + (S < M ? S : M) <= npos && npos < (int64_t(1) << 31), "gemm_rope: table too short");
+  MH_REQUIRE(lda % 8 == 0 && ldw % 8 == 0 && ldc % 8 == 0 && lda >= K && ldw >= K && ldc >= N,
+             "gemm_rope: leading dimensions must be multiples of 8 elements and cover the rows");
+  MH_REQUIRE((((uintptr_t)A | (uintptr_t)W | (uintptr_t)C | (uintptr_t)table) & 15) == 0, "gemm_rope: 16-byte alignment");
+  return mh_gemm_pp256_rope_bf16(A, lda, W, ldw, C, ldc, table, S, pos0, M, N, K, (hipStream_t)stream);
+}
+
 extern "C" int mh_gemm_dswiglu(const void* A, int64_t lda, const void* B, int64_t ldb, const void* GU, int64_t ldgu,
                                void* DGU, int64_t lddgu, int64_t M, int64_t I, int64_t K, int dtype, void* stream) {
   MH_REQUIRE(dtype == MH_BF16 && g_mh_gemm_variant != 0,

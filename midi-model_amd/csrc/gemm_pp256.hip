@@ -359,6 +359,72 @@ __global__ __launch_bounds__(512, 2) void gemm_pp256_kernel(const bf16* __restri
     }
     return;
   }
+  if constexpr (EPI == 3) {
+    // q|k|v projection with the rotary embedding as its epilogue (mh_gemm_rope; LlamaAttention.forward + apply_rotary_pos_emb,
+    // modeling_llama.py:151-169, 243-260): C = [q | k | v] rows of N = 3 D columns, heads of 64.  A wave's 64 columns are ONE
+    // head, so the rotation partner of column d (d +- 32) sits in the same LDS row of the wave's whole-line turn.  R is the
+    // table [pos][cos(32) | -sin(32) | +sin(32)] in bf16 (the reference casts cos / sin to the activation dtype,
+    // modeling_llama.py:126), ldr = S | pos0 << 32, position of row m = pos0 + m % S.  The projection is rounded to bf16
+    // before the rotation, as the unfused pair of launches (mh_gemm, mh_rope) stores it in between; products as mh_rope's.
+    // alpha is 1.  The v heads take the plain path.
+    char* wreg = smem + wave * 16384;
+    const int lrow = lane >> 3, c = lane & 7;
+    const int64_t n = n0 + wn * 64 + c * 8;
+    const bool rot = (n0 + wn * 64) < 2 * (N / 3);  // (wave-uniform)
+    const bf16* tab = R;
+    const int S_ = (int)(ldr & 0xffffffff), pos0 = (int)(ldr >> 32);
+    const int fo = (c & 3) * 8, so = (c < 4 ? 32 : 64) + fo;
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+      bf16x8 cv[8], sv[8];  // this half's table lines, requested before the turn
+      if (rot) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          const int64_t m = m0 + grp * 128 + half * 64 + i * 8 + lrow;
+          const int64_t pos = pos0 + (m < M ? m : M - 1) % S_;
+          cv[i] = *reinterpret_cast<const bf16x8*>(tab + pos * 96 + fo);
+          sv[i] = *reinterpret_cast<const bf16x8*>(tab + pos * 96 + so);
+        }
+      }
+#pragma unroll
+      for (int fmh = 0; fmh < 4; ++fmh)
+#pragma unroll
+        for (int fn = 0; fn < 4; ++fn) {
+          const int row = fmh * 16 + fi, ch = fn * 4 + fg;
+          const f32x4 a4 = acc[fn][half * 4 + fmh];
+          // rounded to bf16 here, once per element (both the owner and the partner lane read it back)
+          const bf16x2 lo = __builtin_convertvector(f32x2{a4[0], a4[1]}, bf16x2), hi2 = __builtin_convertvector(f32x2{a4[2], a4[3]}, bf16x2);
+          f32x4 r4;
+          r4[0] = (float)lo[0];
+          r4[1] = (float)lo[1];
+          r4[2] = (float)hi2[0];
+          r4[3] = (float)hi2[1];
+          *reinterpret_cast<f32x4*>(wreg + row * 256 + ((ch ^ (row & 15)) << 4)) = r4;
+        }
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {  // 8 rows x 128 B per instruction
+        const int row = i * 8 + lrow;
+        const f32x4 lo = *reinterpret_cast<const f32x4*>(wreg + row * 256 + (((2 * c) ^ (row & 15)) << 4));
+        const f32x4 hi = *reinterpret_cast<const f32x4*>(wreg + row * 256 + (((2 * c + 1) ^ (row & 15)) << 4));
+        const int64_t m = m0 + grp * 128 + half * 64 + row;
+        float v[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+        if (rot) {
+          const int pc = c ^ 4;
+          const f32x4 plo = *reinterpret_cast<const f32x4*>(wreg + row * 256 + (((2 * pc) ^ (row & 15)) << 4));
+          const f32x4 phi = *reinterpret_cast<const f32x4*>(wreg + row * 256 + (((2 * pc + 1) ^ (row & 15)) << 4));
+          const float pv[8] = {plo[0], plo[1], plo[2], plo[3], phi[0], phi[1], phi[2], phi[3]};
+          float cf[8], sf[8];
+          expand8_bf16(cv[i], cf);
+          expand8_bf16(sv[i], sf);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) v[e] = __builtin_fmaf(v[e], cf[e], pv[e] * sf[e]);
+        }
+        if (m >= M || n + 8 > N) continue;
+        __builtin_nontemporal_store(cvt8_bf16(v), reinterpret_cast<bf16x8*>(C + m * ldc + n));
+      }
+    }
+    return;
+  }
   const bool use_r = (R != nullptr && beta != 0.f);
   const bool line_ok = !partial && (ldc & 7) == 0 && ((uintptr_t)C & 15) == 0 &&
                        (!use_r || ((ldr & 7) == 0 && ((uintptr_t)R & 15) == 0));
@@ -528,6 +594,12 @@ int mh_gemm_pp256_bf16(const void* A, int64_t lda, int ta, const void* B, int64_
 int mh_gemm_pp256_swiglu_bf16(const void* A, int64_t lda, const void* W, int64_t ldw, void* GU, int64_t ldgu, void* ACT,
                               int64_t ldact, int64_t M, int64_t I, int64_t K, hipStream_t st) {
   return launch_one<false, false, 0, 2>(A, lda, W, ldw, GU, ldgu, ACT, ldact, M, 2 * I, K, 1.f, 0.f, 1, nullptr, st);
+}
+
+// [q | k | v] = A * W^T with the rotary embedding applied to the q and k heads in the epilogue; gemm.hip validates
+int mh_gemm_pp256_rope_bf16(const void* A, int64_t lda, const void* W, int64_t ldw, void* C, int64_t ldc, const void* table,
+                            int64_t S, int64_t pos0, int64_t M, int64_t N, int64_t K, hipStream_t st) {
+  return launch_one<false, false, 0, 3>(A, lda, W, ldw, C, ldc, table, S | (pos0 << 32), M, N, K, 1.f, 0.f, 1, nullptr, st);
 }
 
 // d gate | d up = SwiGLU'(gate|up) applied to A * B^T (A row-major [M,K], B contraction-major [K,I]); gemm.hip validates

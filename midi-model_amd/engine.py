@@ -60,6 +60,7 @@ class RopeTable:
     def __init__(self, hd: int, theta: float, device, npos: int = 0):
         self.hd, self.theta, self.device = hd, theta, device
         self.cos = self.sin = None
+        self._fused = None
         self.n = 0
         if npos:
             self.ensure(npos)
@@ -73,6 +74,14 @@ class RopeTable:
         self.cos = ang.cos().contiguous().to(self.device)
         self.sin = ang.sin().contiguous().to(self.device)
         self.n = npos
+        self._fused = None
+
+    def fused(self) -> torch.Tensor:
+        """bf16 [npos, 96] = cos | -sin | +sin (head_dim 64): the table of mh_gemm_rope's epilogue"""
+        if self._fused is None or self._fused.shape[0] != self.n:
+            c, s = self.cos.to(torch.bfloat16), self.sin.to(torch.bfloat16)
+            self._fused = torch.cat([c, -s, s], dim=1).contiguous()
+        return self._fused
 
 
 def _empty(shape, like: torch.Tensor, dtype=None):
@@ -109,12 +118,16 @@ def layer_forward(spec: StackSpec, lw: LayerTensors, x: torch.Tensor, nseq: int,
     rstd1 = _empty((M,), x, torch.float32)
     ops.rmsnorm_fwd(x, lw.n1, h1, rstd1, spec.eps)
     qkv = _empty((M, 3 * D), x)
-    ops.gemm_nt(h1, lw.wqkv, qkv)
     # token-level stack: RoPE is applied inside the attention kernels (q,k of a (sequence, head) are in registers
-    # there anyway), so qkv stays unrotated -- except for a prefill, whose K rows go to the cache rotated
+    # there anyway), so qkv stays unrotated -- except for a prefill, whose K rows go to the cache rotated.
+    # event-level stack (heads of 64): RoPE rides on the q|k|v projection's epilogue.
     rope_in_attn = spec.kind != "event" and kv_out is None
-    if not rope_in_attn:
-        ops.rope_(qkv, rope.cos, rope.sin, slen, 0, H, spec.hd, +1)
+    if not rope_in_attn and ops.rope_fused_ok(h1, spec.hd):
+        ops.gemm_rope(h1, lw.wqkv, qkv, rope.fused(), slen, 0, spec.hd)
+    else:
+        ops.gemm_nt(h1, lw.wqkv, qkv)
+        if not rope_in_attn:
+            ops.rope_(qkv, rope.cos, rope.sin, slen, 0, H, spec.hd, +1)
     o = _empty((M, D), x)
     lse = None
     if spec.kind == "event":

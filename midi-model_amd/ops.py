@@ -136,7 +136,29 @@ def gemm_nt(a: torch.Tensor, b: torch.Tensor, out: torch.Tensor, *, K: Optional[
     return out
 
 
-_FUSE = int(os.environ.get("MH_FUSE_EPILOGUES", "3"))  # bit 0: SwiGLU forward, bit 1: SwiGLU backward in the GEMM epilogue (A/B runs)
+_FUSE = int(os.environ.get("MH_FUSE_EPILOGUES", "7"))  # GEMM epilogues: bit 0 SwiGLU forward, bit 1 SwiGLU backward, bit 2 RoPE (A/B runs)
+
+
+def rope_fused_ok(x: torch.Tensor, hd: int) -> bool:
+    """whether mh_gemm_rope serves the q|k|v projection + RoPE of the event-level stack (else mh_gemm, then mh_rope)"""
+    return x.dtype == torch.bfloat16 and hd == 64 and get_option("gemm") != 0 and (_FUSE & 4) != 0
+
+
+def gemm_rope(x: torch.Tensor, wqkv: torch.Tensor, qkv: torch.Tensor, table: torch.Tensor, S: int, pos0: int, hd: int):
+    """qkv = x @ wqkv^T with q and k rotated in the projection's epilogue (table: RopeTable.fused())"""
+    M, K = x.shape
+    N = wqkv.shape[0]
+    assert qkv.shape == (M, N) and wqkv.shape[1] == K and table.dtype == torch.bfloat16 and table.shape[1] == 96
+    prof = gemm_profile
+    if prof is not None:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+    lib().call("mh_gemm_rope", _p(x), _rowmajor(x), _p(wqkv), _rowmajor(wqkv), _p(qkv), _rowmajor(qkv), _p(table),
+               table.shape[0], S, pos0, hd, M, N, K, dt(x), _stream())
+    if prof is not None:
+        e1.record()
+        prof.append((e0, e1, 2.0 * M * N * K, (M, N, K, 1, 0, 0, "+rope")))
+    return qkv
 
 
 def swiglu_fused_ok(x: torch.Tensor, I: int) -> bool:

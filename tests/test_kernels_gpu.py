@@ -169,6 +169,28 @@ def test_gemm_swiglu(ops, M, I, K):
     cmp(a, ar, dt, k=max(2.0, K / 128), what="gemm_swiglu activation vs emulation")
 
 
+@pytest.mark.parametrize("B,S,H,K", [(1, 256, 4, 64), (2, 150, 2, 256), (3, 100, 16, 1024), (1, 77, 1, 264), (2, 2048, 16, 1024)])
+def test_gemm_rope(ops, B, S, H, K):
+    """q|k|v projection with the rotary embedding as its epilogue == mh_gemm followed by mh_rope (bit for bit), and the
+    emulation within the bf16 bound"""
+    from midi_model_amd.engine import RopeTable
+    dt = torch.bfloat16
+    M, D = B * S, H * 64
+    x, w = rnd((M, K), dt, 71, 0.5), rnd((3 * D, K), dt, 72, 0.5)
+    tab = RopeTable(64, 10000.0, "cuda", S)
+    assert ops.rope_fused_ok(x.cuda(), 64)
+    fused = torch.full((M, 3 * D), 7.0, dtype=dt, device="cuda")
+    ops.gemm_rope(x.cuda(), w.cuda(), fused, tab.fused(), S, 0, 64)
+    two = torch.empty((M, 3 * D), dtype=dt, device="cuda")
+    ops.gemm_nt(x.cuda(), w.cuda(), two, splitk=1)
+    plain = two.clone()
+    ops.rope_(two, tab.cos, tab.sin, S, 0, H, 64, +1)
+    assert torch.equal(fused[:, 2 * D:], plain[:, 2 * D:]), "v differs from the plain projection"
+    assert torch.equal(fused, two), f"fused differs from mh_gemm + mh_rope: {(fused.float() - two.float()).abs().max().item()}"
+    ref = emu.rope_(plain.cpu().clone(), tab.cos.cpu(), tab.sin.cpu(), S, 0, H, 64, +1)
+    cmp(fused, ref, dt, what="gemm_rope vs emulation")
+
+
 @pytest.mark.parametrize("M,I,K", [(256, 256, 64), (300, 520, 1024), (1000, 4096, 1024), (77, 1024, 264)])
 def test_gemm_dswiglu(ops, M, I, K):
     """down_proj dgrad with the SwiGLU backward as its epilogue == mh_gemm followed by mh_swiglu_bwd"""
