@@ -55,6 +55,17 @@ def gemm_swiglu(x, wgu, gu, a):
     return swiglu_fwd(gu, a)
 
 
+def rope_fused_ok(x, hd):
+    return x.dtype == torch.bfloat16 and hd == 64
+
+
+def gemm_rope(x, wqkv, qkv, table, S, pos0, hd):
+    """table: bf16 [npos, 96] = cos | -sin | +sin (RopeTable.fused)"""
+    gemm_nt(x, wqkv, qkv)
+    H = wqkv.shape[0] // (3 * hd)
+    return rope_(qkv, table[:, :32].float(), table[:, 64:96].float(), S, pos0, H, hd, +1)
+
+
 def dswiglu_ok(dx, I):
     return dx.dtype == torch.bfloat16 and I % 8 == 0
 
