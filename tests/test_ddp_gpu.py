@@ -1,0 +1,92 @@
+"""The data-parallel step's GPU branch on real HIP tensors and kernels: two ranks sharing the one GPU of the test box,
+``gloo`` as the transport (RCCL refuses two ranks on one device; the reducer is backend-agnostic: the same bucket launches on
+the communication stream, the same async work handles, the same stream waits).  What the CPU test (test_abi_and_ddp.py)
+checks through the fake backend is checked here on the device: gradients stay local inside an accumulation window, the window's
+close ships the flat buffer in buckets while the backward is still running, both ranks end with the SAME averaged gradient
+(= the mean of what each computes alone), the same updated weights, and averaged validation metrics."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+import midi_model_amd as mm
+
+pytestmark = pytest.mark.gpu
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _worker(rank, world, port, out_dir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    import torch.distributed as dist
+    from conftest import load_oracle
+    from midi_model_amd.train import TrainMIDIModel
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    orc = load_oracle()
+    tok = mm.MIDITokenizerV2()
+    cfg = mm.MIDIModelConfig.get_config("v2", True, 4, 4, 256, 512)
+    shp = orc.Shape(n_layer=4, n_head=4, n_embd=256, n_inner=512, vocab=tok.vocab_size)
+    sd = orc.make_state_dict(shp, seed=1)
+    dev = torch.device("cuda", 0)
+    batches = [orc.synthetic_events(tok, 2, 33, seed=100 + 10 * mb + rank).to(dev) for mb in range(2)]
+    # what this rank computes alone over its window (no exchange): a second model whose reducer is switched off
+    alone = TrainMIDIModel(cfg, lr=1e-2, warmup=0, accumulate_grad_batches=2).to(dev, torch.bfloat16)
+    alone.load_state_dict(sd)
+    alone._reducer_for_step = lambda: None
+    for b in batches:
+        alone.training_step(b)
+    g_alone = alone.grad_buffer().float().cpu().numpy()
+
+    model = TrainMIDIModel(cfg, lr=1e-2, warmup=0, accumulate_grad_batches=2, bucket_mb=1).to(dev, torch.bfloat16)
+    if rank == 0:
+        model.load_state_dict(sd)
+    model.configure_optimizers()
+    model.broadcast_parameters(0)  # rank 1 started from different random weights
+    l0 = model.training_step(batches[0])          # inside the window: no exchange
+    g_local = model.grad_buffer().float().cpu().numpy()
+    l1 = model.training_step(batches[1])          # closes the window: bucketed all-reduce on the communication stream
+    red = model._reducer
+    assert red is not None and red.comm_stream is not None and len(red.works) > 0, "the reducer's GPU branch did not run"
+    n_buckets = len(red.launched)
+    red.profile = True
+    red.finish()
+    (ev0, ev1, nbytes, nlaunch), = red.stats
+    assert nbytes == model._flat.numel() * model._flat.element_size() and n_buckets <= nlaunch <= n_buckets + 1
+    torch.cuda.synchronize()
+    exposed_ms = ev0.elapsed_time(ev1)            # HIP events around the wait for the communication stream
+    g_avg = model.grad_buffer().float().cpu().numpy()
+    model.optimizer_step()
+    vloss, vacc = model.validation_step(batches[0])
+    torch.cuda.synchronize()
+    np.savez(os.path.join(out_dir, f"rank{rank}.npz"), g_alone=g_alone, g_local=g_local, g_avg=g_avg,
+             flat=model._flat.detach().float().cpu().numpy(), n_buckets=n_buckets, vloss=vloss.float().cpu().numpy(),
+             vacc=float(vacc), losses=np.array([l0.item(), l1.item()]), exposed_ms=exposed_ms)
+    dist.destroy_process_group()
+
+
+def test_ddp_world2_on_the_device(tmp_path):
+    import torch.multiprocessing as mp
+    port = _free_port()
+    mp.spawn(_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    r0, r1 = np.load(tmp_path / "rank0.npz"), np.load(tmp_path / "rank1.npz")
+    assert not np.allclose(r0["g_local"], r1["g_local"])            # inside the window gradients stayed local
+    np.testing.assert_array_equal(r0["g_avg"], r1["g_avg"])          # after it both ranks hold the same bits
+    assert int(r0["n_buckets"]) >= 3, "the flat buffer must have gone out in several 1 MB+ buckets"
+    expect = (r0["g_alone"] + r1["g_alone"]) / 2                      # the mean of what each rank computes alone
+    err = np.abs(r0["g_avg"] - expect)
+    scale = np.sqrt(np.mean(expect ** 2))
+    assert err.max() <= 2 ** -7 * np.abs(expect).max() + 1e-3 * scale, (err.max(), scale)   # bf16: pre-division + sum roundings
+    assert np.sqrt(np.mean(err ** 2)) < 5e-3 * scale
+    np.testing.assert_array_equal(r0["flat"], r1["flat"])            # identical weights after broadcast + identical update
+    np.testing.assert_allclose(r0["vloss"], r1["vloss"], rtol=0, atol=0)
+    assert r0["vacc"] == r1["vacc"]
+    assert np.isfinite(r0["losses"]).all() and np.isfinite(r1["losses"]).all() and float(r0["exposed_ms"]) >= 0.0
