@@ -27,7 +27,6 @@ static int env_int(const char* name, int dflt) {
 int g_mh_gemm_variant = env_int("MH_GEMM", 1);
 int g_mh_gemm_ablate = 0;
 extern int g_skinny_mb, g_skinny_nbt;  // gemm_skinny.hip
-extern int g_attn_fwd_wps, g_attn_fwd_qb;  // attention_mfma.hip
 extern int g_attn_v3, g_attn_v3_wps;      // attention_mfma3.hip
 
 extern "C" int mh_set_option(const char* name, int value) {
@@ -41,14 +40,6 @@ extern "C" int mh_set_option(const char* name, int value) {
   }
   if (strcmp(name, "skinny_mb") == 0) {  // 16-row blocks of the activation per workgroup of mh_gemm_skinny (0 = default)
     g_skinny_mb = value;
-    return 0;
-  }
-  if (strcmp(name, "attn_fwd_wps") == 0) {  // waves per SIMD of the event-level attention forward (2 | 3)
-    g_attn_fwd_wps = value;
-    return 0;
-  }
-  if (strcmp(name, "attn_fwd_qb") == 0) {  // query blocks (32 rows) per wave of the event-level attention forward (1 | 2)
-    g_attn_fwd_qb = value;
     return 0;
   }
   if (strcmp(name, "attn_v3") == 0) {  // third form of the event-level attention kernels: bit 0 forward, bit 1 dQ, bit 2 dK/dV,

@@ -1,4 +1,7 @@
-// Event-level causal attention (head_dim 64, bf16) on the matrix cores: flash forward + two-kernel backward.
+// Event-level causal attention (head_dim 64, bf16) on the matrix cores: flash forward + two-kernel backward -- the FIRST
+// form of the three kernels (r01), kept as the A/B baseline of the third form (attention_mfma3.hip, the default;
+// mh_set_option("attn_v3", 0) selects this one) and as an independent second implementation for the tests.  This file also
+// holds the dispatch of mh_attn_fwd / mh_attn_bwd between the forms.
 //
 // Orientation (all three kernels): the MFMA output tile always has the softmax ROW index on the lane axis
 // (lane&31) and the reduction index in registers, so running max / sum / lse / delta are lane-local and
@@ -11,8 +14,8 @@
 // bit-2/3 swap pi32() makes registers 8t..8t+7 a contiguous run of 8 reduction indices = one operand
 // fragment of the following MFMA (common.h).
 // Operands whose reduction index is NOT the contiguous one in qkv (V^T, Q^T, K^T, dO^T) are read from
-// transposed copies [B,H,64,Sp] written by the prep kernels (first structure; to be replaced by
-// ds_read_b64_tr_b16 staging).  All tiles are 64 rows x 128 B in the swizzled LDS format of common.h and
+// transposed copies [B,H,64,Sp] written by the prep kernels (the third form reads them out of the row-major
+// tiles with ds_read_b64_tr_b16 instead).  All tiles are 64 rows x 128 B in the swizzled LDS format of common.h and
 // arrive by global_load_lds (double buffered, one barrier per tile).
 //
 // VALU budget.  At head_dim 64 a 64-key tile is only 16 MFMAs (512 cycles/wave) against 2048 softmax
@@ -22,13 +25,7 @@
 // math is 32-bit and tile-relative, the scale is folded into one fma feeding a raw v_exp_f32, and row maxima
 // are taken on the unscaled scores.
 // Roofline: MFMA (2.5 PFLOP/s bf16 dense), VALU co-limited.
-#include "common.h"
-
-int g_attn_fwd_qb = 1;   // mh_set_option("attn_fwd_qb", 1 | 2): query blocks per wave of the first forward structure
-int g_attn_fwd_wps = 2;  // mh_set_option("attn_fwd_wps", 2 | 3): register budget of the second forward structure (A/B runs)
-
 #include "attn_mfma_common.h"
-
 
 // ---------------------------------------------------------------------------------------------------
 // forward
@@ -146,349 +143,6 @@ __global__ __launch_bounds__(256, 3) void attn_fwd_kernel(const bf16* __restrict
         fwd_tile<false>(cur, cur + TILE64, qf, oacc, m, l, pli, hi, 0, sc);
     }
     __syncthreads();
-  }
-  const float lt = l + __shfl_xor(l, 32, 64);
-  if (qrow < S) {
-    const float inv = 1.f / lt;
-    bf16* orow = o + (b * S + qrow) * D + (int64_t)h * HD;
-#pragma unroll
-    for (int db = 0; db < 2; ++db)
-#pragma unroll
-      for (int r8 = 0; r8 < 2; ++r8) {
-        bf16x8 v;
-#pragma unroll
-        for (int e = 0; e < 8; ++e) v[e] = (bf16)(oacc[db][8 * r8 + e] * inv);
-        *reinterpret_cast<bf16x8*>(orow + db * 32 + 16 * r8 + 8 * hi) = v;
-      }
-    if (hi == 0) lse[bh * Sp + qrow] = (m + log2f(lt)) * 0.6931471805599453f;
-  }
-}
-
-// ---------------------------------------------------------------------------------------------------
-// forward, two query blocks per wave (r02): the first structure with every K / V^T fragment feeding TWO independent
-// 32-row query blocks -- half the LDS fragment reads per MFMA, a 256-row workgroup (half the K/V staging per query row),
-// and two independent softmax / MFMA streams in one basic block for the scheduler to interleave.
-// ---------------------------------------------------------------------------------------------------
-template <bool MASK>
-__device__ inline void fwdq2_tile(const char* tK, const char* tV, const bf16x8 (&qf)[2][4], f32x16 (&oacc)[2][2],
-                                  float (&m)[2], float (&l)[2], int pli, int hi, const int (&qrel)[2], bool act0, float sc) {
-  f32x16 sacc[2][2] = {{zero16(), zero16()}, {zero16(), zero16()}};
-#pragma unroll
-  for (int s = 0; s < 4; ++s)
-#pragma unroll
-    for (int kb = 0; kb < 2; ++kb) {
-      const bf16x8 kf = lds_frag(tK, kb * 32 + pli, 2 * s + hi);
-      sacc[1][kb] = mfma32(kf, qf[1][s], sacc[1][kb]);
-      if (act0) sacc[0][kb] = mfma32(kf, qf[0][s], sacc[0][kb]);
-    }
-  float alpha[2] = {1.f, 1.f};
-#pragma unroll
-  for (int qb = 0; qb < 2; ++qb) {
-    if (qb == 0 && !act0) continue;  // (wave-uniform: the earlier block has no unmasked key in this tile)
-    float mx = -INFINITY;
-#pragma unroll
-    for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        if (MASK) {
-          if (kb * 32 + reg_index(r, hi) > qrel[qb]) sacc[qb][kb][r] = -INFINITY;
-        }
-        mx = fmaxf(mx, sacc[qb][kb][r]);
-      }
-    mx = fmaxf(mx, __shfl_xor(mx, 32, 64)) * sc;
-    float mn = m[qb];
-    if (__any(mx > m[qb] + RESCALE_THR)) {  // (see fwd_tile)
-      mn = fmaxf(m[qb], mx);
-      alpha[qb] = fast_exp2(m[qb] - mn);
-#pragma unroll
-      for (int db = 0; db < 2; ++db)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) oacc[qb][db][r] *= alpha[qb];
-    }
-    float psum = 0.f;
-#pragma unroll
-    for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const float p = fast_exp2(__builtin_fmaf(sacc[qb][kb][r], sc, -mn));
-        sacc[qb][kb][r] = p;
-        psum += p;
-      }
-    l[qb] = l[qb] * alpha[qb] + psum;
-    m[qb] = mn;
-  }
-#pragma unroll
-  for (int t = 0; t < 4; ++t) {
-    const bf16x8 pf1 = pack8(sacc[1][t >> 1], 8 * (t & 1));
-    const bf16x8 pf0 = pack8(sacc[0][t >> 1], 8 * (t & 1));
-#pragma unroll
-    for (int db = 0; db < 2; ++db) {
-      const bf16x8 vf = lds_frag(tV, db * 32 + pli, 2 * t + hi);
-      oacc[1][db] = mfma32(vf, pf1, oacc[1][db]);
-      if (act0) oacc[0][db] = mfma32(vf, pf0, oacc[0][db]);
-    }
-  }
-}
-
-template <int WPS>
-__global__ __launch_bounds__(256, WPS) void attn_fwdq2_kernel(const bf16* __restrict__ qkv, const bf16* __restrict__ vt,
-                                                           bf16* __restrict__ o, float* __restrict__ lse, int S, int Sp, int H,
-                                                           float sc /* scale*log2(e) */, int BH, int nqt) {
-  __shared__ __attribute__((aligned(16))) char smem[4 * TILE64];  // [stage][K | V^T]
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  int bh_, tile_;
-  if (!attn_work(BH, nqt, bh_, tile_)) return;
-  const int64_t bh = bh_;
-  const int64_t b = bh / H;
-  const int h = (int)(bh - b * H);
-  const int64_t D = (int64_t)H * HD, D3 = 3 * D;
-  const int q0 = (nqt - 1 - tile_) * 256;  // heavy (late) query tiles first
-  const int li = lane & 31, hi = lane >> 5;
-  int qw0[2], qrow[2];
-#pragma unroll
-  for (int qb = 0; qb < 2; ++qb) {
-    qw0[qb] = q0 + wave * 64 + qb * 32;
-    qrow[qb] = qw0[qb] + li;
-  }
-  const bf16* kbase = qkv + b * S * D3 + D + (int64_t)h * HD;
-  const bf16* vtbase = vt + bh * HD * Sp;
-
-  bf16x8 qf[2][4];
-#pragma unroll
-  for (int qb = 0; qb < 2; ++qb) {
-    const int qld = (qrow[qb] < S) ? qrow[qb] : S - 1;
-    const bf16* qp = qkv + (b * S + qld) * D3 + (int64_t)h * HD + 8 * hi;
-#pragma unroll
-    for (int s = 0; s < 4; ++s) qf[qb][s] = *reinterpret_cast<const bf16x8*>(qp + 16 * s);
-  }
-  f32x16 oacc[2][2] = {{zero16(), zero16()}, {zero16(), zero16()}};
-  float m[2] = {-INFINITY, -INFINITY}, l[2] = {0.f, 0.f};
-
-  int last_q = q0 + 255;
-  if (last_q > S - 1) last_q = S - 1;
-  const int kt_last = last_q / 64;
-  const int pli = pi32(li);
-
-  stage64(kbase, D3, 0, S - 1, 0, smem, wave, lane);
-  stage64(vtbase, Sp, 0, HD - 1, 0, smem + TILE64, wave, lane);
-  __syncthreads();
-  for (int kt = 0; kt <= kt_last; ++kt) {
-    const char* cur = smem + (kt & 1) * 2 * TILE64;
-    char* nxt = smem + ((kt + 1) & 1) * 2 * TILE64;
-    if (kt + 1 <= kt_last) {
-      stage64(kbase, D3, (int64_t)(kt + 1) * 64, S - 1, 0, nxt, wave, lane);
-      stage64(vtbase, Sp, 0, HD - 1, (int64_t)(kt + 1) * 64, nxt + TILE64, wave, lane);
-    }
-    const int k0 = kt * 64;
-    if (k0 <= qw0[1] + 31) {  // wave-uniform: the later block still has unmasked keys in the tile
-      const bool act0 = k0 <= qw0[0] + 31;
-      const int qrel[2] = {qrow[0] - k0, qrow[1] - k0};
-      if (k0 + 63 > qw0[0])   // wave-uniform: the tile crosses the diagonal of one of the two blocks
-        fwdq2_tile<true>(cur, cur + TILE64, qf, oacc, m, l, pli, hi, qrel, act0, sc);
-      else
-        fwdq2_tile<false>(cur, cur + TILE64, qf, oacc, m, l, pli, hi, qrel, true, sc);
-    }
-    __syncthreads();
-  }
-#pragma unroll
-  for (int qb = 0; qb < 2; ++qb) {
-    const float lt = l[qb] + __shfl_xor(l[qb], 32, 64);
-    if (qrow[qb] < S) {
-      const float inv = 1.f / lt;
-      bf16* orow = o + (b * S + qrow[qb]) * D + (int64_t)h * HD;
-#pragma unroll
-      for (int db = 0; db < 2; ++db)
-#pragma unroll
-        for (int r8 = 0; r8 < 2; ++r8) {
-          bf16x8 v;
-#pragma unroll
-          for (int e = 0; e < 8; ++e) v[e] = (bf16)(oacc[qb][db][8 * r8 + e] * inv);
-          *reinterpret_cast<bf16x8*>(orow + db * 32 + 16 * r8 + 8 * hi) = v;
-        }
-      if (hi == 0) lse[bh * Sp + qrow[qb]] = (m[qb] + log2f(lt)) * 0.6931471805599453f;
-    }
-  }
-}
-
-// ---------------------------------------------------------------------------------------------------
-// forward, second structure (r02): no transposed V copy, three-stage K/V ring
-// ---------------------------------------------------------------------------------------------------
-// * V is staged row-major [key][d] exactly like K (straight out of the fused qkv rows) and the V^T operand fragments of
-//   O^T += V^T P^T are assembled by ds_read_b64_tr_b16: within a 16-lane group lane p supplies 4 contiguous d of key row
-//   p>>2 and output lane i receives element i&3 of supplier 4j + (i>>2) for j = 0..3 (semantics pinned by tools/probe.hip,
-//   profiles/r01_probe_gfx950_semantics.txt), i.e. 4 consecutive keys of ONE d.  Supplier p of lane group g therefore
-//   points at V[key0 + (p>>2)][db*32 + 16*(g&1) + 8*(p&1) + 4*((p>>1)&1)], which hands output lane i the d index
-//   db*32 + pi32(16*(g&1) + i) the accumulator layout wants; two reads (keys +0..3, +4..7) make one 8-key fragment.
-//   The mh_attn_prep_fwd pass and its [B,H,64,Sp] buffer (55 us per layer at B=16, S=4096) are gone.
-// * K/V tiles live in a ring of three 16 KiB stages filled two tiles ahead by global_load_lds; a wave waits with a COUNTED
-//   s_waitcnt vmcnt (the stage one tile ahead stays in flight) and the workgroup meets at one raw s_barrier per tile
-//   (__syncthreads would drain the queue: cdna_hip_programming.md 5, "Pipelining across barriers").
-// * every LDS address of the tile loop is a per-lane constant + the stage base + an immediate.
-__device__ inline void wait_vmcnt4() { asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); }
-__device__ inline void wait_vmcnt0() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
-
-// one 64-key tile for one wave (32 query rows); koff[s] / voff[db][half]: this lane's byte offsets inside a K / V tile.
-// LDS latency is taken off the critical path by hand: all 8 K fragments are requested before the first S^T MFMA, and the 16
-// transpose reads of V are requested right after the S^T MFMAs are issued, i.e. BEFORE the softmax arithmetic that produces
-// P -- they do not depend on it -- so O^T += V^T P^T starts with its operands in registers (the first form interleaved a
-// pair of fragment reads with each MFMA and waited for them there: ~100 cycles of LDS latency in front of every second MFMA).
-template <bool MASK>
-__device__ inline void fwd2_tile(const char* tK, const char* tV, const int (&koff)[4], const int (&voff)[2][2],
-                                 const bf16x8 (&qf)[4], f32x16 (&oacc)[2], float& m, float& l, int hi, int qrel, float sc) {
-  bf16x8 kf[2][4];
-#pragma unroll
-  for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-    for (int s = 0; s < 4; ++s) kf[kb][s] = *reinterpret_cast<const bf16x8*>(tK + koff[s] + kb * 4096);
-  f32x16 sacc[2] = {zero16(), zero16()};
-#pragma unroll
-  for (int s = 0; s < 4; ++s)
-#pragma unroll
-    for (int kb = 0; kb < 2; ++kb) sacc[kb] = mfma32(kf[kb][s], qf[s], sacc[kb]);  // two independent accumulator chains
-  // V^T fragments of the whole tile, in flight under the softmax below
-  unsigned va[2][2];
-#pragma unroll
-  for (int db = 0; db < 2; ++db)
-#pragma unroll
-    for (int half = 0; half < 2; ++half) va[db][half] = lds_addr32(tV) + (unsigned)voff[db][half];
-  u32x2 vr[4][2][2];
-#define MH_VREADS(T)                          \
-  vr[T][0][0] = ds_tr16<(T) * 2048>(va[0][0]); \
-  vr[T][0][1] = ds_tr16<(T) * 2048>(va[0][1]); \
-  vr[T][1][0] = ds_tr16<(T) * 2048>(va[1][0]); \
-  vr[T][1][1] = ds_tr16<(T) * 2048>(va[1][1]);
-  MH_VREADS(0) MH_VREADS(1) MH_VREADS(2) MH_VREADS(3)
-#undef MH_VREADS
-  float mx = -INFINITY;
-#pragma unroll
-  for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      if (MASK) {
-        if (kb * 32 + reg_index(r, hi) > qrel) sacc[kb][r] = -INFINITY;
-      }
-      mx = fmaxf(mx, sacc[kb][r]);
-    }
-  {  // the other half-wave's maximum through v_permlane32_swap (VALU): __shfl_xor is a ds_bpermute, whose lgkmcnt wait
-     // would also wait for the transpose reads just requested
-    const int ix = __float_as_int(mx);
-    const auto pr = __builtin_amdgcn_permlane32_swap(ix, ix, false, false);
-    mx = fmaxf(__int_as_float(pr[0]), __int_as_float(pr[1])) * sc;  // running max kept in scaled (log2) units
-  }
-  float mn = m, alpha = 1.f;
-  if (__any(mx > m + RESCALE_THR)) {  // (see fwd_tile)
-    mn = fmaxf(m, mx);
-    alpha = fast_exp2(m - mn);
-#pragma unroll
-    for (int db = 0; db < 2; ++db)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) oacc[db][r] *= alpha;
-  }
-  float psum0 = 0.f, psum1 = 0.f;  // (two partial sums: half the length of the dependent add chain)
-#pragma unroll
-  for (int r = 0; r < 16; ++r) {
-    const float p0 = fast_exp2(__builtin_fmaf(sacc[0][r], sc, -mn)), p1 = fast_exp2(__builtin_fmaf(sacc[1][r], sc, -mn));
-    sacc[0][r] = p0;
-    sacc[1][r] = p1;
-    psum0 += p0;
-    psum1 += p1;
-  }
-  l = l * alpha + (psum0 + psum1);
-  m = mn;
-  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the V^T fragments (asm reads: invisible to hipcc's counters)
-  __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-  for (int t = 0; t < 4; ++t) {
-    const bf16x8 pf = pack8(sacc[t >> 1], 8 * (t & 1));
-#pragma unroll
-    for (int db = 0; db < 2; ++db) oacc[db] = mfma32(join8(vr[t][db][0], vr[t][db][1]), pf, oacc[db]);
-  }
-}
-
-template <int WPS>  // waves per SIMD the register allocation is held to (3: 168 VGPRs, 2: 256)
-__global__ __launch_bounds__(256, WPS) void attn_fwd2_kernel(const bf16* __restrict__ qkv, bf16* __restrict__ o,
-                                                          float* __restrict__ lse, int S, int Sp, int H,
-                                                          float sc /* scale*log2(e) */, int BH, int nqt) {
-  // dynamic LDS (3 stages x [K | V] x 8 KiB = 48 KiB): with a static __shared__ array hipcc's LDS-DMA alias tracking puts
-  // an s_waitcnt vmcnt(0) in front of the first fragment read of every tile, which drains the stage just requested
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  int bh_, tile_;
-  if (!attn_work(BH, nqt, bh_, tile_)) return;
-  const int64_t bh = bh_;
-  const int64_t b = bh / H;
-  const int h = (int)(bh - b * H);
-  const int64_t D = (int64_t)H * HD, D3 = 3 * D;
-  const int q0 = (nqt - 1 - tile_) * 128;  // heavy (late) query tiles first
-  const int qw0 = q0 + wave * 32;
-  const int li = lane & 31, hi = lane >> 5;
-  const int qrow = qw0 + li;
-  const int qld = (qrow < S) ? qrow : S - 1;
-
-  const bf16* kbase = qkv + b * S * D3 + D + (int64_t)h * HD;
-  const bf16* vbase = kbase + D;
-
-  bf16x8 qf[4];
-  {
-    const bf16* qp = qkv + (b * S + qld) * D3 + (int64_t)h * HD + 8 * hi;
-#pragma unroll
-    for (int s = 0; s < 4; ++s) qf[s] = *reinterpret_cast<const bf16x8*>(qp + 16 * s);
-  }
-  f32x16 oacc[2] = {zero16(), zero16()};
-  float m = -INFINITY, l = 0.f;
-
-  int last_q = q0 + 127;
-  if (last_q > S - 1) last_q = S - 1;
-  const int kt_last = last_q / 64;
-  const int pli = pi32(li);
-  int koff[4], voff[2][2];
-#pragma unroll
-  for (int s = 0; s < 4; ++s) koff[s] = lds_tile_off(pli, 2 * s + hi);
-  {
-    const int p = lane & 15, gb = (lane >> 4) & 1;
-#pragma unroll
-    for (int db = 0; db < 2; ++db)
-#pragma unroll
-      for (int half = 0; half < 2; ++half) {
-        const int row = 8 * hi + 4 * half + (p >> 2);                             // (+ 16 t: immediate t * 2048)
-        const int col = db * 32 + 16 * gb + 8 * (p & 1) + 4 * ((p >> 1) & 1);
-        voff[db][half] = lds_tile_off(row, col >> 3) + (col & 7) * 2;
-      }
-  }
-
-  // prologue: stages 0 and 1 in flight
-  stage64(kbase, D3, 0, S - 1, 0, smem, wave, lane);
-  stage64(vbase, D3, 0, S - 1, 0, smem + TILE64, wave, lane);
-  if (kt_last >= 1) {
-    stage64(kbase, D3, 64, S - 1, 0, smem + 2 * TILE64, wave, lane);
-    stage64(vbase, D3, 64, S - 1, 0, smem + 3 * TILE64, wave, lane);
-  }
-  // The Q fragments are ordinary register loads: left pending, their first use inside the loop would make hipcc wait
-  // vmcnt(0) THERE on every tile (it cannot count across the LDS-DMA of the loop).  Passing them through an empty asm here
-  // puts that wait in front of the loop once.
-#pragma unroll
-  for (int s = 0; s < 4; ++s) asm volatile("" : "+v"(qf[s]));
-  int cur = 0;  // ring slot of tile kt
-  for (int kt = 0; kt <= kt_last; ++kt) {
-    if (kt + 1 <= kt_last) wait_vmcnt4(); else wait_vmcnt0();   // tile kt has landed (tile kt+1 may still be in flight)
-    __builtin_amdgcn_s_barrier();                               // ... for every wave, and everyone is done with tile kt-1
-    if (kt + 2 <= kt_last) {                                    // refill the slot of tile kt-1
-      int nx = cur + 2;
-      if (nx >= 3) nx -= 3;
-      stage64(kbase, D3, (int64_t)(kt + 2) * 64, S - 1, 0, smem + nx * 2 * TILE64, wave, lane);
-      stage64(vbase, D3, (int64_t)(kt + 2) * 64, S - 1, 0, smem + nx * 2 * TILE64 + TILE64, wave, lane);
-    }
-    const char* tK = smem + cur * 2 * TILE64;
-    const int k0 = kt * 64;
-    if (k0 <= qw0 + 31) {  // wave-uniform: this wave still has unmasked keys in the tile
-      if (k0 + 63 > qw0)   // wave-uniform: the tile crosses this wave's diagonal
-        fwd2_tile<true>(tK, tK + TILE64, koff, voff, qf, oacc, m, l, hi, qrow - k0, sc);
-      else
-        fwd2_tile<false>(tK, tK + TILE64, koff, voff, qf, oacc, m, l, hi, 0, sc);
-    }
-    cur = (cur == 2) ? 0 : cur + 1;
   }
   const float lt = l + __shfl_xor(l, 32, 64);
   if (qrow < S) {
@@ -776,29 +430,12 @@ int mh_attn_bwd_mfma3(const void* qkv, const void* dout, const float* lse, const
 int mh_attn_fwd_mfma(const void* qkv, const void* vt, void* o, float* lse, int64_t B, int64_t S, int H, float scale,
                      hipStream_t st) {
   MH_REQUIRE(S < (1 << 24), "attn_fwd: sequence too long");
-  if (g_attn_fwd_qb != 2 && (g_attn_v3 & 1) && (vt != nullptr || (g_attn_v3 & 16)))  // (vt == NULL + bit 4: V through transpose reads)
+  if ((g_attn_v3 & 1) && (vt != nullptr || (g_attn_v3 & 16)))  // (vt == NULL + bit 4: V through transpose reads)
     return mh_attn_fwd_mfma3(qkv, vt, o, lse, B, S, H, scale, st);
+  MH_REQUIRE(vt != nullptr, "attn_fwd(bf16): the first form needs the transposed V copy (mh_attn_prep_fwd)");
   const int64_t Sp = (S + 63) / 64 * 64;
   const int nt = (int)((S + 127) / 128), BH = (int)(B * H);
   const unsigned grid = (unsigned)(nt * 8 * ((BH + 7) / 8));
-  if (vt != nullptr && g_attn_fwd_qb == 2) {  // two query blocks per wave (256-row workgroups)
-    const int nt2 = (int)((S + 255) / 256);
-    const unsigned g2 = (unsigned)(nt2 * 8 * ((BH + 7) / 8));
-    if (g_attn_fwd_wps == 1)
-      attn_fwdq2_kernel<1><<<g2, 256, 0, st>>>((const bf16*)qkv, (const bf16*)vt, (bf16*)o, lse, (int)S, (int)Sp, H, scale * LOG2E, BH, nt2);
-    else
-      attn_fwdq2_kernel<2><<<g2, 256, 0, st>>>((const bf16*)qkv, (const bf16*)vt, (bf16*)o, lse, (int)S, (int)Sp, H, scale * LOG2E, BH, nt2);
-    MH_LAUNCH_CHECK();
-    return MH_OK;
-  }
-  if (vt == nullptr) {  // second structure: V read row-major through transpose reads, no prepared copy
-    if (g_attn_fwd_wps == 3)
-      attn_fwd2_kernel<3><<<grid, 256, 3 * 2 * TILE64, st>>>((const bf16*)qkv, (bf16*)o, lse, (int)S, (int)Sp, H, scale * LOG2E, BH, nt);
-    else
-      attn_fwd2_kernel<2><<<grid, 256, 3 * 2 * TILE64, st>>>((const bf16*)qkv, (bf16*)o, lse, (int)S, (int)Sp, H, scale * LOG2E, BH, nt);
-    MH_LAUNCH_CHECK();
-    return MH_OK;
-  }
   attn_fwd_kernel<<<grid, 256, 4 * TILE64, st>>>((const bf16*)qkv, (const bf16*)vt, (bf16*)o, lse, (int)S, (int)Sp, H,
                                         scale * LOG2E, BH, nt);
   MH_LAUNCH_CHECK();

@@ -339,31 +339,24 @@ def rope_(qkv: torch.Tensor, cos_t: torch.Tensor, sin_t: torch.Tensor, S: int, p
 
 
 # ----------------------------------------------------------------------------------------- attention
-_attn_wps_set = False
-# 1: first structure (prepared V^T copy, two-stage K/V buffer); 2: second structure (V through transpose reads, three-stage
-# ring, fragments requested ahead of use).  r02 A/B at B=16 x S=4096, same box, interleaved (profiles/r02_*attn_fwd_ab*): form 1
-# 816-827 us + 54 us prep, form 2 922-977 us -- the second structure is correct (same tests) but slower, so form 1 stays.
-ATTN_FWD_FORM = int(os.environ.get("MH_ATTN_FWD", "1"))
+_attn_env_read = False
 
 
 def attn_fwd(qkv, o, lse, B: int, S: int, H: int, scale: float):
-    global _attn_wps_set
-    if not _attn_wps_set:  # (A/B runs: MH_ATTN_FWD_WPS = 2 | 3)
-        _attn_wps_set = True
-        if "MH_ATTN_FWD_WPS" in os.environ:
-            set_option("attn_fwd_wps", int(os.environ["MH_ATTN_FWD_WPS"]))
-        if "MH_ATTN_FWD_QB" in os.environ:
-            set_option("attn_fwd_qb", int(os.environ["MH_ATTN_FWD_QB"]))
-        if "MH_ATTN_V3" in os.environ:  # bits: 1 forward, 2 dQ, 4 dK/dV in the third form (attention_mfma3.hip)
+    """Event-level causal flash attention.  bf16: the third form of the MFMA kernels (attention_mfma3.hip) reads V^T out of
+    the row-major V tile with transpose reads; only the first form (mh_set_option("attn_v3", 0), kept for A/B runs) needs
+    the prepared [B,H,64,Sp] copy.  fp32: the plain verification kernel."""
+    global _attn_env_read, _attn_v3
+    if not _attn_env_read:  # (A/B runs: MH_ATTN_V3 = bits 1 forward, 2 dQ, 4 dK/dV, 8 / 16 transpose reads; MH_ATTN_V3_WPS)
+        _attn_env_read = True
+        if "MH_ATTN_V3" in os.environ:
             set_option("attn_v3", int(os.environ["MH_ATTN_V3"]))
         if "MH_ATTN_V3_WPS" in os.environ:
             set_option("attn_v3_wps", int(os.environ["MH_ATTN_V3_WPS"]))
-    global _attn_v3
     if _attn_v3 is None:
         _attn_v3 = get_option("attn_v3")
     vt = None
-    # (attn_v3 bits 0 + 4: third form with V through transpose reads -- no prepared V^T copy)
-    if qkv.dtype == torch.bfloat16 and ATTN_FWD_FORM == 1 and (_attn_v3 & 17) != 17:
+    if qkv.dtype == torch.bfloat16 and (_attn_v3 & 17) != 17:
         Sp = round_up(S, 64)
         vt = torch.empty((B * H * 64 * Sp,), dtype=qkv.dtype, device=qkv.device)
         lib().call("mh_attn_prep_fwd", _p(qkv), _p(vt), B, S, H, dt(qkv), _stream())

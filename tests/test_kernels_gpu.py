@@ -303,35 +303,26 @@ def test_rope(ops, dtype, H, hd, S, M):
 
 
 # ------------------------------------------------------------------------------ event-level attention
-# form -> (ops.ATTN_FWD_FORM, attn_fwd_qb, attn_fwd_wps, attn_v3 bits, attn_v3_wps)
+# form -> (attn_v3 bits, attn_v3_wps)
 ATTN_FORMS = {
-    "v3_tr_all": (1, 1, 2, 31, 0),              # third form of all three kernels, transpose reads in all of them (no copies)
-    "v3_tr_all_wps2": (1, 1, 2, 31, 2),
-    "v3_tr": (1, 1, 2, 15, 0),                  # ... forward from the prepared V^T copy
-    "v3_tr_wps2": (1, 1, 2, 15, 2),
-    "v3": (1, 1, 2, 7, 0),                      # ... backward from the prepared transposed copies
-    "v3_wps2": (1, 1, 2, 7, 2),                 # ... held to two / three waves per SIMD (dQ: wide / narrow fragment batches)
-    "v3_wps3": (1, 1, 2, 7, 3),
-    "fwd1_preparedVT": (1, 1, 2, 0, 0),         # first form of all three kernels
-    "fwd2_trV_ring3": (2, 1, 2, 0, 0),
-    "fwd1_two_qblocks_2wps": (1, 2, 2, 0, 0),
-    "fwd1_two_qblocks_1wps": (1, 2, 1, 0, 0),
+    "v3_tr_all": (31, 0),        # third form of all three kernels, transposed operands by transpose reads (the default)
+    "v3_tr_all_wps2": (31, 2),   # ... held to two / three waves per SIMD
+    "v3_tr_all_wps3": (31, 3),
+    "v3_tr": (15, 0),            # ... forward from the prepared V^T copy
+    "v3": (7, 0),                # ... all three from prepared transposed copies
+    "first_form": (0, 0),        # attention_mfma.hip
 }
 
 
 @pytest.mark.parametrize("form", list(ATTN_FORMS))
 @pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("B,S,H", [(1, 1, 1), (2, 33, 3), (1, 64, 2), (2, 128, 1), (1, 200, 4), (1, 515, 2), (1, 129, 1), (2, 321, 2), (1, 96, 1), (1, 40, 1)])
-def test_attention_fwd_bwd(ops, monkeypatch, form, dtype, B, S, H):
-    """(bf16: every form of the MFMA kernels -- the third form (fragment batches, one loop per tile class), the first form
-    with its prepared V^T copy, the transpose-read / three-stage-ring forward, the two-query-block forward; fp32 runs the
-    plain verification kernel either way)"""
+def test_attention_fwd_bwd(ops, form, dtype, B, S, H):
+    """(bf16: every form of the MFMA kernels -- the third form (fragment batches, one loop per tile class, transpose reads)
+    with and without prepared transposed copies, and the first form; fp32 runs the plain verification kernel either way)"""
     if dtype == torch.float32 and form != "v3_tr_all":
         pytest.skip("fp32 has one forward kernel")
-    fwd_form, qb, wps, v3, v3_wps = ATTN_FORMS[form]
-    monkeypatch.setattr(ops, "ATTN_FWD_FORM", fwd_form)
-    ops.set_option("attn_fwd_qb", qb)
-    ops.set_option("attn_fwd_wps", wps)
+    v3, v3_wps = ATTN_FORMS[form]
     ops.set_option("attn_v3", v3)
     ops.set_option("attn_v3_wps", v3_wps)
     D = H * 64
@@ -361,8 +352,6 @@ def test_attention_fwd_bwd(ops, monkeypatch, form, dtype, B, S, H):
     cmp(got, want.cpu(), dtype, k=2, what="attn bwd + rotation back")
     same = (got == want).float().mean().item()
     assert same > 0.99, f"fused rotation agrees with the separate pass on only {same:.4f} of the elements"
-    ops.set_option("attn_fwd_qb", 1)
-    ops.set_option("attn_fwd_wps", 2)
     ops.set_option("attn_v3", 31)
     ops.set_option("attn_v3_wps", 0)
 
