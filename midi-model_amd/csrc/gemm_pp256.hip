@@ -264,17 +264,25 @@ __global__ __launch_bounds__(512, 2) void gemm_pp256_kernel(const bf16* __restri
     const int lrow = lane >> 3, c = lane & 7;
     const int64_t n = n0 + wn * 64 + c * 8;
     const bool n_ok = (n + 8 <= N);
-#pragma unroll
-    for (int half = 0; half < 2; ++half) {
-      bf16x8 gv[8], uv[8];
+    // gate / up lines: the first half's are requested before its turn, the second half's right after the first half's
+    // fragments have left the accumulator registers (r02: requested only when its own turn came, their latency was exposed
+    // a second time per tile)
+    bf16x8 gq[2][8], uq[2][8];
+    auto request = [&](int half) {
 #pragma unroll
       for (int i = 0; i < 8; ++i) {
         const int64_t m = m0 + grp * 128 + half * 64 + i * 8 + lrow;
         if (m < M && n_ok) {
-          gv[i] = *reinterpret_cast<const bf16x8*>(R + m * ldr + n);
-          uv[i] = *reinterpret_cast<const bf16x8*>(R + m * ldr + N + n);
+          gq[half][i] = *reinterpret_cast<const bf16x8*>(R + m * ldr + n);
+          uq[half][i] = *reinterpret_cast<const bf16x8*>(R + m * ldr + N + n);
         }
       }
+    };
+    request(0);
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+      const bf16x8 (&gv)[8] = gq[half];
+      const bf16x8 (&uv)[8] = uq[half];
 #pragma unroll
       for (int fmh = 0; fmh < 4; ++fmh)
 #pragma unroll
@@ -282,6 +290,7 @@ __global__ __launch_bounds__(512, 2) void gemm_pp256_kernel(const bf16* __restri
           const int row = fmh * 16 + fi, ch = fn * 4 + fg;
           *reinterpret_cast<f32x4*>(wreg + row * 256 + ((ch ^ (row & 15)) << 4)) = acc[fn][half * 4 + fmh];
         }
+      if (half == 0) request(1);
 #pragma unroll
       for (int i = 0; i < 8; ++i) {
         const int row = i * 8 + lrow;
@@ -374,18 +383,23 @@ __global__ __launch_bounds__(512, 2) void gemm_pp256_kernel(const bf16* __restri
     const bf16* tab = R;
     const int S_ = (int)(ldr & 0xffffffff), pos0 = (int)(ldr >> 32);
     const int fo = (c & 3) * 8, so = (c < 4 ? 32 : 64) + fo;
-#pragma unroll
-    for (int half = 0; half < 2; ++half) {
-      bf16x8 cv[8], sv[8];  // this half's table lines, requested before the turn
+    bf16x8 cq[2][8], sq[2][8];  // the table lines of a 64-row half: the first half's requested before its turn, the second
+    auto request = [&](int half) {  // half's as soon as the first half's fragments have left the accumulator registers
       if (rot) {
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
           const int64_t m = m0 + grp * 128 + half * 64 + i * 8 + lrow;
           const int64_t pos = pos0 + (m < M ? m : M - 1) % S_;
-          cv[i] = *reinterpret_cast<const bf16x8*>(tab + pos * 96 + fo);
-          sv[i] = *reinterpret_cast<const bf16x8*>(tab + pos * 96 + so);
+          cq[half][i] = *reinterpret_cast<const bf16x8*>(tab + pos * 96 + fo);
+          sq[half][i] = *reinterpret_cast<const bf16x8*>(tab + pos * 96 + so);
         }
       }
+    };
+    request(0);
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+      const bf16x8 (&cv)[8] = cq[half];
+      const bf16x8 (&sv)[8] = sq[half];
 #pragma unroll
       for (int fmh = 0; fmh < 4; ++fmh)
 #pragma unroll
@@ -401,6 +415,7 @@ __global__ __launch_bounds__(512, 2) void gemm_pp256_kernel(const bf16* __restri
           r4[3] = (float)hi2[1];
           *reinterpret_cast<f32x4*>(wreg + row * 256 + ((ch ^ (row & 15)) << 4)) = r4;
         }
+      if (half == 0) request(1);
 #pragma unroll
       for (int i = 0; i < 8; ++i) {  // 8 rows x 128 B per instruction
         const int row = i * 8 + lrow;
