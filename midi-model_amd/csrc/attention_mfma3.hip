@@ -1,6 +1,7 @@
-// Event-level causal attention (head_dim 64, bf16), third form of the three MFMA kernels of attention_mfma.hip (same
-// orientation, same LDS tile format, same transposed copies, same results to rounding; selected per kernel by
-// mh_set_option("attn_v3", bits), bit 0 forward, bit 1 dQ, bit 2 dK/dV).
+// Event-level causal attention (head_dim 64, bf16), third form of the three MFMA kernels of attention_mfma.hip -- the
+// default (same orientation, same LDS tile format, same results to rounding; selected per kernel by
+// mh_set_option("attn_v3", bits): bit 0 forward, bit 1 dQ, bit 2 dK/dV; bits 3 / 4: the backward pair / the forward take their
+// transposed operands out of the row-major tiles with ds_read_b64_tr_b16 instead of from prepared [B,H,64,Sp] copies).
 //
 // What the ISA of the first form showed (r02, `hipcc -S` of attention_mfma.hip) and what changes here:
 //  * every MFMA pair sat behind its own `ds_read_b128 ; s_waitcnt lgkmcnt(0)`: 16-32 exposed LDS round trips per tile and
@@ -18,7 +19,13 @@
 //    needs it.
 //  * the row maximum crosses the two wave halves through v_permlane32_swap (VALU) instead of ds_bpermute, whose wait would
 //    also wait for the fragment batch in flight.
-// Roofline: MFMA (2.5 PFLOP/s bf16 dense), VALU co-limited at head_dim 64.
+//  * half of the forward's time was LDS-DMA issue and the barrier (ablation below): the requests go out in the SGPR-base form
+//    (one address VGPR each, no 64-bit VALU adds), and the kernels stage only row-major tiles -- K and V; K and V; Q and dO --
+//    reading V^T, K^T, Q^T, dO^T out of them with transpose reads: 4 / 4 / 5 requests per wave and tile instead of 4 / 6 / 9,
+//    and no transposed copies in HBM.
+//  * delta rides in the matrix pipe: the dP chains start from C = delta and multiply negated dO (dQ) / V (dK/dV) fragments.
+// Bound: VALU issue slots and per-wave serialisation at head_dim 64, not the matrix pipe (39 % busy) -- DESIGN.md section 4,
+// "the SIMD issue model".
 #include "attn_mfma_common.h"
 
 int g_attn_v3 = 31;     // mh_set_option("attn_v3", bits): 1 forward, 2 dQ, 4 dK/dV, 8 transpose reads in dQ + dK/dV (needs 2 | 4),
