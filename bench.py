@@ -25,6 +25,7 @@ A step = forward + backward + gradient all-reduce (N>1) + global-norm clip + Ada
 `--mode block` / `--mode generate` print those measurements as the top-level line instead.
 """
 import argparse
+import gc
 import glob
 import json
 import os
@@ -177,6 +178,7 @@ def setup(args):
 
 def timed(fn_step, steps: int, dist, sync):
     """EXACTLY `steps` steps bracketed by barrier + synchronize on both sides; MAX over ranks"""
+    gc.collect()  # (a full collection that is already due lands here rather than between two launches of the timed region)
     sync()
     if dist is not None:
         dist.barrier()
@@ -529,7 +531,13 @@ def main():
             plain = [(e0.elapsed_time(e1), f) for e0, e1, f, shp in prof if len(shp) == 6]  # no elementwise work in the epilogue
             print("[bench] GEMM launches by shape (M,N,K,splitk,transA,transB[,fused epilogue]): calls, total ms, TFLOP/s", file=sys.stderr)
             for shp, (t_, f_, n_) in sorted(by_shape.items(), key=lambda kv: -kv[1][0]):
-                print(f"[bench]   {shp}: {n_:4d} {t_:9.3f} {f_ / (t_ * 1e-3) / 1e12:8.1f}", file=sys.stderr)
+                w_ = sorted(1e3 * e0.elapsed_time(e1) for e0, e1, _, s_ in prof if s_ == shp)
+                print(f"[bench]   {shp}: {n_:4d} {t_:9.3f} {f_ / (t_ * 1e-3) / 1e12:8.1f}   (us per launch: min {w_[0]:.1f}, median {w_[len(w_) // 2]:.1f}, max {w_[-1]:.1f})",
+                      file=sys.stderr)
+            if os.environ.get("MH_BENCH_WINDOWS"):  # the windows of one shape in launch order
+                for shp in by_shape:
+                    if str(shp) == os.environ["MH_BENCH_WINDOWS"]:
+                        print("[bench]   windows in order:", " ".join(f"{1e3 * e0.elapsed_time(e1):.0f}" for e0, e1, _, s_ in prof if s_ == shp), file=sys.stderr)
             pmc, pmc_src = pmc_traffic()
             out["roofline"] = {"bound": "mfma", "kernel": "gemm_pp256_kernel (all projection GEMMs: fwd, dgrad, wgrad, lm_head; split-K reductions inside the window)",
                                "achieved": ach, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": ach / PEAK_BF16_TFLOPS,
