@@ -161,6 +161,12 @@ int mh_attn_prep_bwd(const void* qkv, const void* o, const void* dout, float* de
 int mh_attn_bwd(const void* qkv, const void* dout, const float* lse, const float* delta, const void* qt,
                 const void* kt, const void* dot, void* dqkv, int64_t B, int64_t S, int H, float scale,
                 const float* cos_t, const float* sin_t, int dtype, void* stream);
+/* the same backward in ONE call for the default bf16 kernels (third form with transpose reads, no transposed copies): the dQ
+ * kernel computes delta = rowsum(dO * O) from the rows it holds anyway and leaves it in `delta` (scratch, [B,H,Sp] fp32) for
+ * the dK/dV kernel launched behind it -- no pass of its own over O and dO.  MH_ERR_ARG for fp32 or when another kernel form
+ * is selected (mh_set_option("attn_v3")): use the two calls above.                                                      */
+int mh_attn_bwd_o(const void* qkv, const void* o, const void* dout, const float* lse, float* delta, void* dqkv, int64_t B,
+                  int64_t S, int H, float scale, const float* cos_t, const float* sin_t, int dtype, void* stream);
 /* NOTE: lse and delta are laid out [B,H,Sp] with Sp = S rounded up to a multiple of 64 (entries past S unused).
  * The *_plain variants run the exact-fp32-math thread-per-row kernels for either dtype; tests use them to
  * cross-check the MFMA kernels on the device.                                                              */

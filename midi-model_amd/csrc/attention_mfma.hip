@@ -425,7 +425,7 @@ int mh_attn_fwd_mfma3(const void* qkv, const void* vt, void* o, float* lse, int6
                       hipStream_t st);
 int mh_attn_bwd_mfma3(const void* qkv, const void* dout, const float* lse, const float* delta, const void* qt, const void* kt,
                       const void* dot, void* dqkv, int64_t B, int64_t S, int H, float scale, const float* cos_t,
-                      const float* sin_t, int which, hipStream_t st);
+                      const float* sin_t, int which, hipStream_t st, const void* o = nullptr);
 
 int mh_attn_fwd_mfma(const void* qkv, const void* vt, void* o, float* lse, int64_t B, int64_t S, int H, float scale,
                      hipStream_t st) {
@@ -440,6 +440,15 @@ int mh_attn_fwd_mfma(const void* qkv, const void* vt, void* o, float* lse, int64
                                         scale * LOG2E, BH, nt);
   MH_LAUNCH_CHECK();
   return MH_OK;
+}
+
+// backward in one call, delta = rowsum(dO * O) computed by the dQ kernel (third form with transpose reads only)
+int mh_attn_bwd_o_mfma(const void* qkv, const void* o, const void* dout, const float* lse, float* delta, void* dqkv, int64_t B,
+                       int64_t S, int H, float scale, const float* cos_t, const float* sin_t, hipStream_t st) {
+  MH_REQUIRE(S < (1 << 24), "attn_bwd: sequence too long");
+  MH_REQUIRE((g_attn_v3 & 14) == 14, "attn_bwd_o: served by the third form with transpose reads (mh_set_option(\"attn_v3\") bits 2|4|8); "
+             "use mh_attn_prep_bwd + mh_attn_bwd otherwise");
+  return mh_attn_bwd_mfma3(qkv, dout, lse, delta, nullptr, nullptr, nullptr, dqkv, B, S, H, scale, cos_t, sin_t, 14, st, o);
 }
 
 int mh_attn_bwd_mfma(const void* qkv, const void* dout, const float* lse, const float* delta, const void* qt,

@@ -28,8 +28,9 @@
 // "the SIMD issue model".
 #include "attn_mfma_common.h"
 
-int g_attn_v3 = 31;     // mh_set_option("attn_v3", bits): 1 forward, 2 dQ, 4 dK/dV, 8 transpose reads in dQ + dK/dV (needs 2 | 4),
-                        // 16 transpose reads in the forward (needs 1; the caller then passes no V^T copy)
+int g_attn_v3 = 63;     // mh_set_option("attn_v3", bits): 1 forward, 2 dQ, 4 dK/dV, 8 transpose reads in dQ + dK/dV (needs 2 | 4),
+                        // 16 transpose reads in the forward (needs 1; the caller then passes no V^T copy), 32 the host side
+                        // calls mh_attn_bwd_o (delta computed inside the dQ kernel; needs 2 | 4 | 8)
 int g_attn_v3_wps = 0;  // mh_set_option("attn_v3_wps", n): register budget (waves per SIMD) override for A/B runs, 0 = default
 
 __device__ inline bf16x8 ldsv(const char* p) { return *reinterpret_cast<const bf16x8*>(p); }
@@ -341,7 +342,9 @@ __global__ __launch_bounds__(256, WPS) void attn_bwd_dq3_kernel(const bf16* __re
                                                               const bf16* __restrict__ kt_, bf16* __restrict__ dqkv, int S,
                                                               int Sp, int H, float scale, int BH, int nqt,
                                                               const float* __restrict__ cos_t,
-                                                              const float* __restrict__ sin_t) {
+                                                              const float* __restrict__ sin_t,
+                                                              const bf16* __restrict__ o_ /* != NULL: delta is computed here */,
+                                                              float* __restrict__ delta_w) {
   extern __shared__ __attribute__((aligned(16))) char smem[];  // [stage][K | V | K^T], or [stage][K | V] with transpose reads
   constexpr int NT = TR ? 2 : 3;  // tiles per stage
   const int tid = threadIdx.x, lane = tid & 63;
@@ -364,19 +367,37 @@ __global__ __launch_bounds__(256, WPS) void attn_bwd_dq3_kernel(const bf16* __re
   const bf16* ktbase = TR ? nullptr : kt_ + bh * HD * Sp;
 
   bf16x8 qf[4], dof[4];
+  float dl = 0.f;
   {
     const bf16* qp = qkv + (b * S + qld) * D3 + (int64_t)h * HD + 8 * hi;
     const bf16* dp = dout + (b * S + qld) * D + (int64_t)h * HD + 8 * hi;
+    bf16x8 of[4];
+    if (o_ != nullptr) {
+      const bf16* op = o_ + (b * S + qld) * D + (int64_t)h * HD + 8 * hi;
+#pragma unroll
+      for (int s = 0; s < 4; ++s) of[s] = *reinterpret_cast<const bf16x8*>(op + 16 * s);
+    }
 #pragma unroll
     for (int s = 0; s < 4; ++s) {
       qf[s] = *reinterpret_cast<const bf16x8*>(qp + 16 * s);
       const bf16x8 d = *reinterpret_cast<const bf16x8*>(dp + 16 * s);
 #pragma unroll
       for (int e = 0; e < 8; ++e) dof[s][e] = -d[e];  // (see dq3_tile)
+      if (o_ != nullptr) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) dl = __builtin_fmaf((float)d[e], (float)of[s][e], dl);
+      }
     }
   }
   float lse2 = lse[bh * Sp + qld] * LOG2E;
-  const float dl = delta[bh * Sp + qld];
+  if (o_ != nullptr) {
+    // delta = rowsum(dO * O) of this lane's query row: the two half-waves hold 32 of the 64 columns each; the dK/dV kernel
+    // (launched behind this one) reads it from delta_w -- no pass of its own over O and dO
+    dl += __shfl_xor(dl, 32, 64);
+    if (hi == 0 && qrow < S) delta_w[bh * Sp + qrow] = dl;
+  } else {
+    dl = delta[bh * Sp + qld];
+  }
   f32x16 dlt;
 #pragma unroll
   for (int r = 0; r < 16; ++r) dlt[r] = dl;
@@ -707,7 +728,8 @@ int mh_attn_fwd_mfma3(const void* qkv, const void* vt, void* o, float* lse, int6
 int mh_attn_bwd_mfma3(const void* qkv, const void* dout, const float* lse, const float* delta, const void* qt, const void* kt,
                       const void* dot, void* dqkv, int64_t B, int64_t S, int H, float scale, const float* cos_t,
                       const float* sin_t, int which /* bit 1: dQ, bit 2: dK/dV, bit 3: transpose reads (no qt / kt / dot) */,
-                      hipStream_t st) {
+                      hipStream_t st, const void* o /* != NULL: the dQ kernel computes delta and WRITES it (needs bit 1) */) {
+  MH_REQUIRE(o == nullptr || (which & 2), "attn_bwd: delta inside the dQ kernel needs the third form of it");
   MH_REQUIRE(S * 3 * H * HD < (int64_t(1) << 31), "attn_bwd: sequence too long (32-bit panel offsets)");
   const bool tr = (which & 8) != 0;
   MH_REQUIRE(tr || (qt != nullptr && kt != nullptr && dot != nullptr), "attn_bwd(bf16): needs the transposed copies (mh_attn_prep_bwd)");
@@ -717,7 +739,8 @@ int mh_attn_bwd_mfma3(const void* qkv, const void* dout, const float* lse, const
 #define MH_DQ(WPS, TR_)                                                                                                     \
   attn_bwd_dq3_kernel<WPS, TR_><<<grid, 256, (TR_ ? 4 : 6) * TILE64, st>>>((const bf16*)qkv, (const bf16*)dout, lse, delta,     \
                                                                         (const bf16*)kt, (bf16*)dqkv, (int)S, (int)Sp, H, scale, \
-                                                                        BH, nt, cos_t, sin_t)
+                                                                        BH, nt, cos_t, sin_t, (const bf16*)o,         \
+                                                                        const_cast<float*>(delta))
   if (which & 2) {
     if (g_attn_v3_wps == 2) {
       if (tr) MH_DQ(2, true); else MH_DQ(2, false);

@@ -876,6 +876,9 @@ int mh_attn_bwd_mfma(const void* qkv, const void* dout, const float* lse, const 
                      const void* kt, const void* dot, void* dqkv, int64_t B, int64_t S, int H, float scale,
                      const float* cos_t, const float* sin_t, hipStream_t st);
 
+int mh_attn_bwd_o_mfma(const void* qkv, const void* o, const void* dout, const float* lse, float* delta, void* dqkv, int64_t B,
+                       int64_t S, int H, float scale, const float* cos_t, const float* sin_t, hipStream_t st);
+
 template <typename T>
 static int attn_plain_fwd(const void* qkv, void* o, float* lse, int64_t B, int64_t S, int H, float scale, hipStream_t st) {
   dim3 grid((unsigned)((S + 63) / 64), (unsigned)(B * H));
@@ -935,4 +938,13 @@ extern "C" int mh_attn_bwd(const void* qkv, const void* dout, const float* lse, 
   }
   mh_set_error("attn_bwd: bad dtype");
   return MH_ERR_ARG;
+}
+
+extern "C" int mh_attn_bwd_o(const void* qkv, const void* o, const void* dout, const float* lse, float* delta, void* dqkv,
+                             int64_t B, int64_t S, int H, float scale, const float* cos_t, const float* sin_t, int dtype,
+                             void* stream) {
+  MH_REQUIRE(B > 0 && S > 0 && H > 0 && B * H < 65536, "attn_bwd_o: bad shape");
+  MH_REQUIRE((cos_t == nullptr) == (sin_t == nullptr), "attn_bwd_o: cos and sin tables come together");
+  MH_REQUIRE(dtype == MH_BF16, "attn_bwd_o: bf16 only (fp32: mh_attn_prep_bwd + mh_attn_bwd)");
+  return mh_attn_bwd_o_mfma(qkv, o, dout, lse, delta, dqkv, B, S, H, scale, cos_t, sin_t, (hipStream_t)stream);
 }

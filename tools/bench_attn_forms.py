@@ -48,7 +48,8 @@ def main():
                 print(f"S={S} fwd  {name:28s}: {us:8.1f} us  {fl / us / 1e6:7.1f} TF/s (V^T prep included)", flush=True)
             for name, v3, wps in (("first form", 0, 0), ("v3 dQ narrow (3 w/SIMD)", 2, 3), ("v3 dQ wide (2 w/SIMD)", 2, 2),
                                   ("v3 dK/dV", 4, 0), ("v3 dQ wide + dK/dV", 6, 2), ("v3 dQ narrow + dK/dV", 6, 3),
-                                  ("v3 tr reads, no copies", 14, 3), ("v3 tr reads (dQ 2 w/SIMD)", 14, 2)):
+                                  ("v3 tr reads, no copies", 14, 3), ("v3 tr reads (dQ 2 w/SIMD)", 14, 2),
+                                  ("v3 tr reads, delta inside dQ", 46, 3)):
                 ops.set_option("attn_v3", v3)
                 ops.set_option("attn_v3_wps", wps)
                 us = timeit(lambda: ops.attn_bwd(qkv, o, do, lse, dqkv, B, S, H, 0.125), iters)
@@ -67,7 +68,7 @@ def main():
         us = timeit(lambda: lib().call("mh_attn_prep_bwd", qkv.data_ptr(), o.data_ptr(), do.data_ptr(), delta.data_ptr(), buf[0].data_ptr(),
                                        buf[1].data_ptr(), buf[2].data_ptr(), B, S, H, 1, st), iters)
         print(f"S={S} prep_bwd alone: {us:8.1f} us")
-    ops.set_option("attn_v3", 31)
+    ops.set_option("attn_v3", 63)
     ops.set_option("attn_v3_wps", 0)
 
 
