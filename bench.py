@@ -29,6 +29,7 @@ import gc
 import glob
 import json
 import os
+import re
 import socket
 import subprocess
 import sys
@@ -248,7 +249,10 @@ def summarize_launches(prof, wall_s: float, steps: int):
 def pmc_traffic():
     """memory-side bytes per gemm_pp256 launch from the newest committed rocprofv3 PMC pass (tools/gpu_pmc_bench.sh ->
     tools/pmc_to_json.py); counters need their own rocprofv3 runs, so the bench line cites the file it read"""
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_gemm_traffic.json")))
+    def run_key(path):  # r02_run23_... -> (2, 23): newest by round and run number, not by string order
+        m = re.match(r"r(\d+)_run(\d+)_", os.path.basename(path))
+        return (int(m.group(1)), int(m.group(2))) if m else (-1, -1)
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_gemm_traffic.json")), key=run_key)
     if not files:
         return None, None
     try:

@@ -44,7 +44,7 @@ extern "C" int mh_set_option(const char* name, int value) {
   }
   if (strcmp(name, "attn_v3") == 0) {  // third form of the event-level attention kernels: bit 0 forward, bit 1 dQ, bit 2 dK/dV,
                                        // bit 3 transpose reads in the backward pair (no transposed copies; needs bits 1 and 2),
-                                       // bit 4 in the forward, bit 5: callers use mh_attn_bwd_o (delta inside the dQ kernel)
+                                       // bit 4 in the forward, bit 5: callers use mh_attn_bwd_o (delta inside the dQ kernel), bit 6: three K/V stages in the forward
     g_attn_v3 = value;
     return 0;
   }

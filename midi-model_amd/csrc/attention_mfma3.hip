@@ -28,9 +28,10 @@
 // "the SIMD issue model".
 #include "attn_mfma_common.h"
 
-int g_attn_v3 = 63;     // mh_set_option("attn_v3", bits): 1 forward, 2 dQ, 4 dK/dV, 8 transpose reads in dQ + dK/dV (needs 2 | 4),
+int g_attn_v3 = 127;     // mh_set_option("attn_v3", bits): 1 forward, 2 dQ, 4 dK/dV, 8 transpose reads in dQ + dK/dV (needs 2 | 4),
                         // 16 transpose reads in the forward (needs 1; the caller then passes no V^T copy), 32 the host side
-                        // calls mh_attn_bwd_o (delta computed inside the dQ kernel; needs 2 | 4 | 8)
+                        // calls mh_attn_bwd_o (delta computed inside the dQ kernel; needs 2 | 4 | 8), 64 three K/V stages
+                        // in the forward (needs 1 | 16)
 int g_attn_v3_wps = 0;  // mh_set_option("attn_v3_wps", n): register budget (waves per SIMD) override for A/B runs, 0 = default
 
 __device__ inline bf16x8 ldsv(const char* p) { return *reinterpret_cast<const bf16x8*>(p); }
@@ -151,7 +152,7 @@ __device__ inline void fwd3_tile(const char* tK, const char* tV, const int (&tro
     for (int db = 0; db < 2; ++db) oacc[db] = mfma32(TR ? join8(vr[t][db][0], vr[t][db][1]) : vf[t][db], pf[t], oacc[db]);
 }
 
-template <int WPS, bool TR>
+template <int WPS, bool TR, int NS = 2 /* K/V stages in LDS: tile kt + NS - 1 is requested while tile kt is computed */>
 __global__ __launch_bounds__(256, WPS) void attn_fwd3_kernel(const bf16* __restrict__ qkv, const bf16* __restrict__ vt,
                                                           bf16* __restrict__ o, float* __restrict__ lse, int S, int Sp, int H,
                                                           float sc /* scale*log2(e) */, int BH, int nqt) {
@@ -197,43 +198,54 @@ __global__ __launch_bounds__(256, WPS) void attn_fwd3_kernel(const bf16* __restr
   }
 
   const int iD3 = (int)D3;
-  stage64u(kbase, iD3, 0, S - 1, 0, smem, wave, lane);
   int trof[2][2];
   tr_frag_offsets(lane, trof);
-  if (TR) stage64u(vtbase, iD3, 0, S - 1, 0, smem + TILE64, wave, lane);
-  else stage64u(vtbase, Sp, 0, HD - 1, 0, smem + TILE64, wave, lane);
+  auto stage_tile = [&](int t, int buf) {  // 4 LDS-DMA requests per wave
+    char* dst = smem + buf * 2 * TILE64;
+    stage64u(kbase, iD3, t * 64, S - 1, 0, dst, wave, lane);
+    if (TR) stage64u(vtbase, iD3, t * 64, S - 1, 0, dst + TILE64, wave, lane);
+    else stage64u(vtbase, Sp, 0, HD - 1, t * 64, dst + TILE64, wave, lane);
+  };
+  // Three stages: a tile's requests get two tile times to land instead of one (with two stages an iteration cannot be
+  // shorter than one memory round trip, which only the other resident workgroups cover).  wait_next(kt): tile kt + 1 has
+  // landed = everything but the youngest stage's four requests, when one was issued behind it.
+  auto wait_next = [&](int kt) {
+    if (NS == 3 && kt + 2 <= kt_last) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    else stage_wait_all();
+  };
+  stage_tile(0, 0);
+  if (NS == 3 && 1 <= kt_last) stage_tile(1, 1);
 #pragma unroll
   for (int s = 0; s < 4; ++s) asm volatile("" : "+v"(qf[s]));  // (see attn_bwd_dkv_kernel)
-  stage_wait_all();
-    __syncthreads();
+  wait_next(-1);
+  __syncthreads();
+  int cb = 0, nb = NS - 1;  // buffer of tile kt, buffer tile kt + NS - 1 goes to
   auto stage_next = [&](int kt) {
-    if (kt + 1 <= kt_last) {
-      char* nxt = smem + ((kt + 1) & 1) * 2 * TILE64;
-      stage64u(kbase, iD3, (kt + 1) * 64, S - 1, 0, nxt, wave, lane);
-      if (TR) stage64u(vtbase, iD3, (kt + 1) * 64, S - 1, 0, nxt + TILE64, wave, lane);
-      else stage64u(vtbase, Sp, 0, HD - 1, (kt + 1) * 64, nxt + TILE64, wave, lane);
-    }
+    if (kt + NS - 1 <= kt_last) stage_tile(kt + NS - 1, nb);
+    nb = (nb + 1 == NS) ? 0 : nb + 1;
+  };
+  auto advance = [&](int kt) {
+    wait_next(kt);
+    __syncthreads();
+    cb = (cb + 1 == NS) ? 0 : cb + 1;
   };
   int kt = 0;
   for (; kt < n_full; ++kt) {
     stage_next(kt);
-    const char* cur = smem + (kt & 1) * 2 * TILE64;
+    const char* cur = smem + cb * 2 * TILE64;
     fwd3_tile<false, TR>(cur, cur + TILE64, trof, foff, qf, oacc, m, l, hi, 0, sc);
-    stage_wait_all();
-    __syncthreads();
+    advance(kt);
   }
   if (kt <= kt_last) {
     stage_next(kt);
-    const char* cur = smem + (kt & 1) * 2 * TILE64;
+    const char* cur = smem + cb * 2 * TILE64;
     fwd3_tile<true, TR>(cur, cur + TILE64, trof, foff, qf, oacc, m, l, hi, qrow - kt * 64, sc);
-    stage_wait_all();
-    __syncthreads();
+    advance(kt);
     ++kt;
   }
   for (; kt <= kt_last; ++kt) {
     stage_next(kt);
-    stage_wait_all();
-    __syncthreads();
+    advance(kt);
   }
   const float lt = l + __shfl_xor(l, 32, 64);
   if (qrow < S) {
@@ -712,15 +724,22 @@ int mh_attn_fwd_mfma3(const void* qkv, const void* vt, void* o, float* lse, int6
 #define MH_FWD(WPS, TR_)                                                                                                    \
   attn_fwd3_kernel<WPS, TR_><<<grid, 256, 4 * TILE64, st>>>((const bf16*)qkv, (const bf16*)vt, (bf16*)o, lse, (int)S, (int)Sp, H, \
                                                           scale * LOG2E, BH, nt)
+#define MH_FWD3S(WPS, TR_)                                                                                                  \
+  attn_fwd3_kernel<WPS, TR_, 3><<<grid, 256, 6 * TILE64, st>>>((const bf16*)qkv, (const bf16*)vt, (bf16*)o, lse, (int)S, (int)Sp, \
+                                                             H, scale * LOG2E, BH, nt)
   const bool tr = (vt == nullptr);  // no prepared V^T copy: transpose reads
   // (register budget: with transpose reads the 256-register build measured 1-2 % ahead, with the prepared copy the
   //  168-register one; both fit three waves per SIMD -- profiles/r02_run18_attn_forms_ab.txt)
-  if (tr) {
+  if (tr && (g_attn_v3 & 64)) {  // three stages: -3 % at S = 2048, -1...-3 % at 4096 (profiles/r02_run22_*); the same in the
+                                 // backward pair measured +1.5 % (their tiles are twice as long) and is not built
+    if (g_attn_v3_wps == 3) MH_FWD3S(3, true); else MH_FWD3S(2, true);
+  } else if (tr) {
     if (g_attn_v3_wps == 3) MH_FWD(3, true); else MH_FWD(2, true);
   } else {
     if (g_attn_v3_wps == 2) MH_FWD(2, false); else MH_FWD(3, false);
   }
 #undef MH_FWD
+#undef MH_FWD3S
   MH_LAUNCH_CHECK();
   return MH_OK;
 }

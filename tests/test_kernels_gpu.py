@@ -305,9 +305,11 @@ def test_rope(ops, dtype, H, hd, S, M):
 # ------------------------------------------------------------------------------ event-level attention
 # form -> (attn_v3 bits, attn_v3_wps)
 ATTN_FORMS = {
-    "v3_tr_all": (63, 0),        # third form of all three kernels, transposed operands by transpose reads, delta inside dQ (the default)
-    "v3_tr_all_wps2": (63, 2),   # ... held to two / three waves per SIMD
-    "v3_tr_all_wps3": (63, 3),
+    "v3_tr_all": (127, 0),       # third form of all three kernels: transposed operands by transpose reads, delta inside dQ,
+                                 # three K/V stages in the forward (the default)
+    "v3_tr_all_wps2": (127, 2),  # ... held to two / three waves per SIMD
+    "v3_tr_all_wps3": (127, 3),
+    "v3_tr_all_2stage": (63, 0),      # ... forward with two K/V stages
     "v3_tr_all_delta_pass": (31, 0),  # ... delta from its own pass (mh_attn_prep_bwd + mh_attn_bwd)
     "v3_tr": (15, 0),            # ... forward from the prepared V^T copy
     "v3": (7, 0),                # ... all three from prepared transposed copies
@@ -353,11 +355,11 @@ def test_attention_fwd_bwd(ops, form, dtype, B, S, H):
     cmp(got, want.cpu(), dtype, k=2, what="attn bwd + rotation back")
     same = (got == want).float().mean().item()
     assert same > 0.99, f"fused rotation agrees with the separate pass on only {same:.4f} of the elements"
-    ops.set_option("attn_v3", 63)
+    ops.set_option("attn_v3", 127)
     ops.set_option("attn_v3_wps", 0)
 
 
-@pytest.mark.parametrize("v3", [31, 7, 0], ids=["v3_tr", "v3", "first_form"])
+@pytest.mark.parametrize("v3", [95, 31, 7, 0], ids=["v3_tr_3stage", "v3_tr", "v3", "first_form"])
 def test_attention_forward_when_the_reference_has_to_move(ops, v3):
     """Rows whose scores jump by far more than the lazy-rescale threshold between tiles (a few keys late in the sequence
     are scaled up 8x and 24x: q.k/8 moves by tens to more than a hundred log2 units), plus a first tile of tiny scores."""
@@ -375,7 +377,7 @@ def test_attention_forward_when_the_reference_has_to_move(ops, v3):
     ops.set_option("attn_v3", v3)
     o, lse = torch.empty((B * S, D), dtype=torch.bfloat16, device="cuda"), torch.zeros(B * H * Sp, device="cuda")
     ops.attn_fwd(qkv.cuda(), o, lse, B, S, H, 0.125)
-    ops.set_option("attn_v3", 63)
+    ops.set_option("attn_v3", 127)
     assert torch.isfinite(o.float()).all() and torch.isfinite(lse).all()
     cmp(o, o_ref, torch.bfloat16, what="attn o (moving reference)")
     got, want = lse.view(B, H, Sp)[:, :, :S].cpu(), lse_ref.view(B, H, Sp)[:, :, :S]

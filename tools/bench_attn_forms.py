@@ -41,7 +41,8 @@ def main():
         ref = {}
         for rnd in range(2):
             for name, v3, wps in (("first form", 0, 0), ("v3 fwd (3 waves/SIMD)", 1, 3), ("v3 fwd (2 waves/SIMD)", 1, 2),
-                                  ("v3 fwd tr reads, no V^T copy (3)", 17, 3), ("v3 fwd tr reads, no V^T copy (2)", 17, 2)):
+                                  ("v3 fwd tr reads, no V^T copy (3)", 17, 3), ("v3 fwd tr reads, no V^T copy (2)", 17, 2),
+                                  ("v3 fwd tr reads, three stages (3)", 81, 3), ("v3 fwd tr reads, three stages (2)", 81, 2)):
                 ops.set_option("attn_v3", v3)
                 ops.set_option("attn_v3_wps", wps)
                 us = timeit(lambda: ops.attn_fwd(qkv, o, lse, B, S, H, 0.125), iters)
@@ -68,7 +69,7 @@ def main():
         us = timeit(lambda: lib().call("mh_attn_prep_bwd", qkv.data_ptr(), o.data_ptr(), do.data_ptr(), delta.data_ptr(), buf[0].data_ptr(),
                                        buf[1].data_ptr(), buf[2].data_ptr(), B, S, H, 1, st), iters)
         print(f"S={S} prep_bwd alone: {us:8.1f} us")
-    ops.set_option("attn_v3", 63)
+    ops.set_option("attn_v3", 127)
     ops.set_option("attn_v3_wps", 0)
 
 

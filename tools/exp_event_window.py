@@ -60,7 +60,7 @@ def main():
         run(mode)
     ops.set_option("attn_v3", 0)
     run("plain(first form)")
-    ops.set_option("attn_v3", 63)
+    ops.set_option("attn_v3", 127)
 
 
 if __name__ == "__main__":
