@@ -16,6 +16,7 @@ the flat gradient buffer, so communication overlaps the rest of backward (refere
 from __future__ import annotations
 
 import math
+import os
 import random
 from typing import Callable, List, Optional, Tuple
 
@@ -210,6 +211,41 @@ class TrainMIDIModel(MIDIModel):
         if self._lora is None:
             raise RuntimeError("no adapter attached")
         self._lora.save(directory)
+
+    def save_peft(self, save_dir: str) -> None:
+        """the reference's name for save_adapter (train.py:234-244)"""
+        self.save_adapter(save_dir)
+
+    def gen_example(self, save_dir: str, prompt=None, max_len: int = 512, generator=None):
+        """train.py:208-232 without the Lightning / dataset globals: `example_batch` sequences generated from BOS and, when
+        `prompt` (int array [T, 8]) is given, as many continuations of its first 256 events, written under
+        save_dir/sample/<global_step>/ as <k>_<i>.npy token arrays -- and as .mid / .png next to them when the tokenizer
+        carries the reference's codec (detokenize / midi2img) and the reference's `MIDI` module is importable (CPU format
+        code, out of this build's scope: used as it is).  Returns the list of generated arrays."""
+        import numpy as np
+        base_dir = os.path.join(save_dir, "sample", str(self.global_step))
+        os.makedirs(base_dir, exist_ok=True)
+        try:
+            import MIDI  # the reference's module, when on sys.path
+        except Exception:
+            MIDI = None
+        has_codec = getattr(type(self.tokenizer), "detokenize", None) is not None and \
+            getattr(self.tokenizer, "_no_codec", None) is None
+        out = []
+        cases = [(0, None)] if prompt is None else [(0, None), (1, np.asarray(prompt)[:256].astype(np.int64))]
+        for k, pr in cases:
+            seqs = self.generate(pr, batch_size=self.example_batch, max_len=max_len, generator=generator)
+            for i, seq in enumerate(seqs):
+                seq = np.asarray(seq)
+                np.save(os.path.join(base_dir, f"{k}_{i}.npy"), seq)
+                out.append(seq)
+                if has_codec:
+                    score = self.tokenizer.detokenize(seq)
+                    self.tokenizer.midi2img(score).save(os.path.join(base_dir, f"{k}_{i}.png"))
+                    if MIDI is not None:
+                        with open(os.path.join(base_dir, f"{k}_{i}.mid"), "wb") as f:
+                            f.write(MIDI.score2midi(score))
+        return out
 
     def merge_and_unload(self):
         """fold the adapter into the weights (W <- W + scale * B @ A) and drop it; returns self"""

@@ -3,6 +3,7 @@ the fused training step + optimiser, the KV-cached decode loop and generate(), a
 test-only fake backend (tests/emu_ops.py) and checked against the reference-generated golden vectors.
 The same checks run on the real HIP kernels in test_model_gpu.py."""
 import json
+import os
 
 import numpy as np
 import pytest
@@ -474,3 +475,26 @@ def test_checkpoint_forms_load_strictly(orc, tiny, tmp_path):
     save_file({**state, "net.layers.0.extra.weight": torch.ones(3)}, str(tmp_path / "e.safetensors"))
     with pytest.raises(RuntimeError, match="unexpected"):
         mm.MIDIModel.from_checkpoint(tiny_config(), str(tmp_path / "e.safetensors"))
+
+
+def test_gen_example_and_save_peft_surface(tiny, golden, tmp_path):
+    """TrainMIDIModel.gen_example (train.py:208-232, minus the Lightning / dataset globals): example_batch sequences from
+    BOS and as many continuations of the prompt's first 256 events, saved per sequence; the same seeded stream as
+    generate().  save_peft is the reference's name for save_adapter."""
+    shp, sd, _ = tiny
+    g = golden("tiny_generate.npz")
+    with emu_ops.install():
+        model = TrainMIDIModel(tiny_config(), example_batch=3)
+        model.load_state_dict(sd)
+        out = model.gen_example(str(tmp_path), max_len=14, generator=torch.Generator().manual_seed(1234))
+        assert len(out) == 3 and all((o == w).all() for o, w in zip(out, g["sampled_b3"]))
+        files = sorted(os.listdir(tmp_path / "sample" / "0"))
+        assert files == ["0_0.npy", "0_1.npy", "0_2.npy"], files   # (tables-only tokenizer: no .mid / .png)
+        assert (np.load(tmp_path / "sample" / "0" / "0_1.npy") == g["sampled_b3"][1]).all()
+        out = model.gen_example(str(tmp_path / "p"), prompt=g["prompt"], max_len=12, generator=torch.Generator().manual_seed(3))
+        assert len(out) == 6 and all((o[:g["prompt"].shape[-2]] == g["prompt"].reshape(-1, 8)[:o.shape[0]]).all() for o in out[3:])
+        with pytest.raises(RuntimeError):
+            model.save_peft(str(tmp_path / "lora"))   # no adapter attached
+        model.add_adapter()
+        model.save_peft(str(tmp_path / "lora"))
+        assert sorted(os.listdir(tmp_path / "lora")) == ["adapter_config.json", "adapter_model.safetensors"]
