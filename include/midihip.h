@@ -162,8 +162,9 @@ int mh_attn_bwd(const void* qkv, const void* dout, const float* lse, const float
                 const void* kt, const void* dot, void* dqkv, int64_t B, int64_t S, int H, float scale,
                 const float* cos_t, const float* sin_t, int dtype, void* stream);
 /* the same backward in ONE call for the default bf16 kernels (third form with transpose reads, no transposed copies): the dQ
- * kernel computes delta = rowsum(dO * O) from the rows it holds anyway and leaves it in `delta` (scratch, [B,H,Sp] fp32) for
- * the dK/dV kernel launched behind it -- no pass of its own over O and dO.  MH_ERR_ARG for fp32 or when another kernel form
+ * kernel computes delta = rowsum(dO * O) from the rows it holds anyway and leaves it in `delta` for the dK/dV kernel launched
+ * behind it -- no pass of its own over O and dO.  `delta` is scratch of 2 * B*H*Sp floats here: the second half receives
+ * -lse * log2(e), the form the dK/dV kernel's exp2 wants (one multiply less per score).  MH_ERR_ARG for fp32 or when another kernel form
  * is selected (mh_set_option("attn_v3")): use the two calls above.                                                      */
 int mh_attn_bwd_o(const void* qkv, const void* o, const void* dout, const float* lse, float* delta, void* dqkv, int64_t B,
                   int64_t S, int H, float scale, const float* cos_t, const float* sin_t, int dtype, void* stream);

@@ -406,7 +406,10 @@ __global__ __launch_bounds__(256, WPS) void attn_bwd_dq3_kernel(const bf16* __re
     // delta = rowsum(dO * O) of this lane's query row: the two half-waves hold 32 of the 64 columns each; the dK/dV kernel
     // (launched behind this one) reads it from delta_w -- no pass of its own over O and dO
     dl += __shfl_xor(dl, 32, 64);
-    if (hi == 0 && qrow < S) delta_w[bh * Sp + qrow] = dl;
+    if (hi == 0 && qrow < S) {
+      delta_w[bh * Sp + qrow] = dl;
+      delta_w[(int64_t)BH * Sp + bh * Sp + qrow] = -lse2;  // second half of the scratch: -lse * log2(e) for the dK/dV kernel
+    }
   } else {
     dl = delta[bh * Sp + qld];
   }
@@ -484,7 +487,7 @@ __global__ __launch_bounds__(256, WPS) void attn_bwd_dq3_kernel(const bf16* __re
 // number of valid queries in the tile (S - q0, may exceed 64).  TR: the dO^T / Q^T fragments of dV^T += dO^T P and
 // dK^T += Q^T dS come out of the row-major dO / Q tiles through ds_read_b64_tr_b16 (addresses tdo / tq = tile +
 // tr_frag_offsets): no transposed copies of Q and dO in HBM, 5 instead of 9 LDS-DMA requests per wave and tile.
-template <bool MASK, bool TR, int QB>
+template <bool MASK, bool TR, int QB, bool PS>
 __device__ inline void dkv3_half(const char* tQ, const char* tDO, const char* tQT, const char* tDOT, const char* tLD,
                                  const unsigned (&tq)[2][2], const unsigned (&tdo)[2][2], const int (&foff)[4],
                                  const bf16x8 (&kf)[4], const bf16x8 (&vf)[4] /* -V */, f32x16 (&dkacc)[2], f32x16 (&dvacc)[2],
@@ -544,7 +547,8 @@ __device__ inline void dkv3_half(const char* tQ, const char* tDO, const char* tQ
 #pragma unroll
       for (int e = 0; e < 4; ++e) {  // S -> P, delta - dP -> -dS (unscaled), in place
         const int r = 8 * t + 4 * v4 + e;
-        float p = fast_exp2(__builtin_fmaf(sacc[r], sc, -la[t][v4][e] * LOG2E));
+        // (PS: the staged statistic already is -lse * log2(e), written by the dQ kernel: one multiply less per element)
+        float p = fast_exp2(__builtin_fmaf(sacc[r], sc, PS ? la[t][v4][e] : -la[t][v4][e] * LOG2E));
         float ds = p * pacc[r];
         if (MASK) {
           const int q = QB * 32 + 16 * t + 4 * v4 + e;  // (+ 8 hi, moved to the other side: see fwd3_tile)
@@ -574,7 +578,7 @@ __device__ inline void dkv3_half(const char* tQ, const char* tDO, const char* tQ
 #undef MH_DKV_REQUEST
 }
 
-template <bool MASK, bool TR>
+template <bool MASK, bool TR, bool PS>
 __device__ inline void dkv3_tile(const char* tQ, const char* tDO, const char* tQT, const char* tDOT, const char* tLD,
                                  const int (&trof)[2][2], const int (&foff)[4], const bf16x8 (&kf)[4], const bf16x8 (&vf)[4],
                                  f32x16 (&dkacc)[2], f32x16 (&dvacc)[2], int hi, int krel, int qlim, float sc) {
@@ -586,11 +590,11 @@ __device__ inline void dkv3_tile(const char* tQ, const char* tDO, const char* tQ
       tq[xb][half] = lds_addr32(tQ) + (unsigned)trof[xb][half];
       tdo[xb][half] = lds_addr32(tDO) + (unsigned)trof[xb][half];
     }
-  dkv3_half<MASK, TR, 0>(tQ, tDO, tQT, tDOT, tLD, tq, tdo, foff, kf, vf, dkacc, dvacc, hi, krel, qlim, sc);
-  dkv3_half<MASK, TR, 1>(tQ, tDO, tQT, tDOT, tLD, tq, tdo, foff, kf, vf, dkacc, dvacc, hi, krel, qlim, sc);
+  dkv3_half<MASK, TR, 0, PS>(tQ, tDO, tQT, tDOT, tLD, tq, tdo, foff, kf, vf, dkacc, dvacc, hi, krel, qlim, sc);
+  dkv3_half<MASK, TR, 1, PS>(tQ, tDO, tQT, tDOT, tLD, tq, tdo, foff, kf, vf, dkacc, dvacc, hi, krel, qlim, sc);
 }
 
-template <bool TR>
+template <bool TR, bool PS = false /* lse holds -lse * log2(e) (mh_attn_bwd_o: written by the dQ kernel) */>
 __global__ __launch_bounds__(256, 2) void attn_bwd_dkv3_kernel(const bf16* __restrict__ qkv, const bf16* __restrict__ dout,
                                                                const float* __restrict__ lse, const float* __restrict__ delta,
                                                                const bf16* __restrict__ qt_, const bf16* __restrict__ dot_,
@@ -688,7 +692,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv3_kernel(const bf16* __res
   }
   if (n_mask) {
     const char* cur = head(qt);
-    dkv3_tile<true, TR>(cur, cur + TILE64, cur + 2 * TILE64, cur + 3 * TILE64, cur + NT * TILE64, trof, foff, kf, vf, dkacc, dvacc, hi,
+    dkv3_tile<true, TR, PS>(cur, cur + TILE64, cur + 2 * TILE64, cur + 3 * TILE64, cur + NT * TILE64, trof, foff, kf, vf, dkacc, dvacc, hi,
                     krow - qt * 64, S - qt * 64, sc);
     stage_wait_all();
     __syncthreads();
@@ -696,14 +700,14 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv3_kernel(const bf16* __res
   }
   for (int i = 0; i < n_full; ++i, ++qt) {
     const char* cur = head(qt);
-    dkv3_tile<false, TR>(cur, cur + TILE64, cur + 2 * TILE64, cur + 3 * TILE64, cur + NT * TILE64, trof, foff, kf, vf, dkacc, dvacc, hi, 0,
+    dkv3_tile<false, TR, PS>(cur, cur + TILE64, cur + 2 * TILE64, cur + 3 * TILE64, cur + NT * TILE64, trof, foff, kf, vf, dkacc, dvacc, hi, 0,
                      64, sc);
     stage_wait_all();
     __syncthreads();
   }
   if (n_tail > 0) {
     const char* cur = head(qt);
-    dkv3_tile<true, TR>(cur, cur + TILE64, cur + 2 * TILE64, cur + 3 * TILE64, cur + NT * TILE64, trof, foff, kf, vf, dkacc, dvacc, hi,
+    dkv3_tile<true, TR, PS>(cur, cur + TILE64, cur + 2 * TILE64, cur + 3 * TILE64, cur + NT * TILE64, trof, foff, kf, vf, dkacc, dvacc, hi,
                     krow - qt * 64, S - qt * 64, sc);
     stage_wait_all();
     __syncthreads();
@@ -748,7 +752,7 @@ int mh_attn_bwd_mfma3(const void* qkv, const void* dout, const float* lse, const
                       const void* dot, void* dqkv, int64_t B, int64_t S, int H, float scale, const float* cos_t,
                       const float* sin_t, int which /* bit 1: dQ, bit 2: dK/dV, bit 3: transpose reads (no qt / kt / dot) */,
                       hipStream_t st, const void* o /* != NULL: the dQ kernel computes delta and WRITES it (needs bit 1) */) {
-  MH_REQUIRE(o == nullptr || (which & 2), "attn_bwd: delta inside the dQ kernel needs the third form of it");
+  MH_REQUIRE(o == nullptr || (which & 14) == 14, "attn_bwd: delta inside the dQ kernel needs the third form of both kernels");
   MH_REQUIRE(S * 3 * H * HD < (int64_t(1) << 31), "attn_bwd: sequence too long (32-bit panel offsets)");
   const bool tr = (which & 8) != 0;
   MH_REQUIRE(tr || (qt != nullptr && kt != nullptr && dot != nullptr), "attn_bwd(bf16): needs the transposed copies (mh_attn_prep_bwd)");
@@ -770,7 +774,12 @@ int mh_attn_bwd_mfma3(const void* qkv, const void* dout, const float* lse, const
   }
 #undef MH_DQ
   if (which & 4) {
-    if (tr)
+    if (tr && o != nullptr)  // (statistics pre-scaled by the dQ kernel above)
+      attn_bwd_dkv3_kernel<true, true><<<grid, 256, 2 * (2 * TILE64 + 2048), st>>>((const bf16*)qkv, (const bf16*)dout,
+                                                                                 delta + (int64_t)BH * Sp, delta, nullptr, nullptr,
+                                                                                 (bf16*)dqkv, (int)S, (int)Sp, H, scale, BH, nt,
+                                                                                 cos_t, sin_t);
+    else if (tr)
       attn_bwd_dkv3_kernel<true><<<grid, 256, 2 * (2 * TILE64 + 2048), st>>>((const bf16*)qkv, (const bf16*)dout, lse, delta, nullptr,
                                                                            nullptr, (bf16*)dqkv, (int)S, (int)Sp, H, scale, BH, nt,
                                                                            cos_t, sin_t);

@@ -370,9 +370,10 @@ def attn_bwd(qkv, o, dout, lse, dqkv, B: int, S: int, H: int, scale: float, cos_
     if _attn_v3 is None:
         _attn_v3 = get_option("attn_v3")
     Sp = round_up(S, 64)
-    delta = torch.empty((B * H * Sp,), dtype=torch.float32, device=qkv.device)
-    if qkv.dtype == torch.bfloat16 and (_attn_v3 & 14) == 14 and (_attn_v3 & 32):
-        # (default) one call: the dQ kernel computes delta from its own rows and hands it to the dK/dV kernel
+    fused = qkv.dtype == torch.bfloat16 and (_attn_v3 & 14) == 14 and (_attn_v3 & 32) != 0
+    delta = torch.empty(((2 if fused else 1) * B * H * Sp,), dtype=torch.float32, device=qkv.device)
+    if fused:
+        # (default) one call: the dQ kernel computes delta from its own rows and hands it (and -lse * log2 e) to the dK/dV kernel
         lib().call("mh_attn_bwd_o", _p(qkv), _p(o), _p(dout), _p(lse), _p(delta), _p(dqkv), B, S, H, scale, _p(cos_t), _p(sin_t),
                    dt(qkv), _stream())
         return dqkv
