@@ -1,7 +1,8 @@
 // Event-level causal attention (head_dim 64, bf16), third form of the three MFMA kernels of attention_mfma.hip -- the
 // default (same orientation, same LDS tile format, same results to rounding; selected per kernel by
 // mh_set_option("attn_v3", bits): bit 0 forward, bit 1 dQ, bit 2 dK/dV; bits 3 / 4: the backward pair / the forward take their
-// transposed operands out of the row-major tiles with ds_read_b64_tr_b16 instead of from prepared [B,H,64,Sp] copies).
+// transposed operands out of the row-major tiles with ds_read_b64_tr_b16 instead of from prepared [B,H,64,Sp] copies; bits 5 / 6
+// below; default 127 = all of them).
 //
 // What the ISA of the first form showed (r02, `hipcc -S` of attention_mfma.hip) and what changes here:
 //  * every MFMA pair sat behind its own `ds_read_b128 ; s_waitcnt lgkmcnt(0)`: 16-32 exposed LDS round trips per tile and
@@ -24,6 +25,10 @@
 //    reading V^T, K^T, Q^T, dO^T out of them with transpose reads: 4 / 4 / 5 requests per wave and tile instead of 4 / 6 / 9,
 //    and no transposed copies in HBM.
 //  * delta rides in the matrix pipe: the dP chains start from C = delta and multiply negated dO (dQ) / V (dK/dV) fragments.
+//  * mh_attn_bwd_o (bit 5, the host side's default): the dQ kernel computes delta = rowsum(dO * O) from the rows its lanes
+//    hold and leaves delta and -lse * log2(e) in the scratch buffer for the dK/dV kernel launched behind it: no delta pass
+//    over O and dO, one multiply less per score in dK/dV (32 of its ~210 VALU issue slots per 64-query tile).
+//  * the forward keeps three K/V stages in LDS (bit 6; counted vmcnt wait): a tile's requests get two tile times to land.
 // Bound: VALU issue slots and per-wave serialisation at head_dim 64, not the matrix pipe (39 % busy) -- DESIGN.md section 4,
 // "the SIMD issue model".
 #include "attn_mfma_common.h"
