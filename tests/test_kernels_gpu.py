@@ -384,6 +384,42 @@ def test_attention_forward_when_the_reference_has_to_move(ops, v3):
     assert ((got - want).abs() <= 1e-4 * want.abs().clamp(min=1.0)).all(), (got - want).abs().max()
 
 
+def test_attention_bwd_in_one_call_hands_over_delta_and_says_what_it_does_not_serve(ops):
+    """mh_attn_bwd_o: the dQ kernel leaves delta = rowsum(dO * O) and -lse * log2(e) in the 2 * B*H*Sp scratch; fp32 and the
+    other kernel forms are refused with an error (the two-call path serves them), not computed some other way."""
+    from midi_model_amd.lib import lib
+    B, S, H = 2, 200, 2
+    D, Sp = H * 64, 256
+    qkv = rnd((B * S, 3 * D), torch.bfloat16, 61).cuda()
+    do = rnd((B * S, D), torch.bfloat16, 62).cuda()
+    o = torch.empty((B * S, D), dtype=torch.bfloat16, device="cuda")
+    lse = torch.zeros(B * H * Sp, device="cuda")
+    ops.attn_fwd(qkv, o, lse, B, S, H, 0.125)
+    scratch = torch.full((2 * B * H * Sp,), float("nan"), device="cuda")
+    dqkv = torch.empty_like(qkv)
+    st = torch.cuda.current_stream().cuda_stream
+    args = (qkv.data_ptr(), o.data_ptr(), do.data_ptr(), lse.data_ptr(), scratch.data_ptr(), dqkv.data_ptr(), B, S, H, 0.125, 0, 0)
+    lib().call("mh_attn_bwd_o", *args, 1, st)
+    torch.cuda.synchronize()
+    want = (do.float() * o.float()).view(B, S, H, 64).sum(-1).permute(0, 2, 1)          # [B, H, S]
+    got = scratch[:B * H * Sp].view(B, H, Sp)[:, :, :S]
+    assert torch.allclose(got, want, rtol=1e-5, atol=1e-5), (got - want).abs().max()
+    got2 = scratch[B * H * Sp:].view(B, H, Sp)[:, :, :S]
+    assert torch.equal(got2, -(lse.view(B, H, Sp)[:, :, :S] * 1.4426950408889634))
+    ref = torch.empty_like(dqkv)
+    ops.set_option("attn_v3", 31)   # the two-call path (delta from its own pass)
+    ops.attn_bwd(qkv, o, do, lse, ref, B, S, H, 0.125)
+    cmp(dqkv, ref, torch.bfloat16, what="dqkv one call vs two calls")
+    ops.set_option("attn_v3", 7)    # the backward pair from prepared transposed copies: not served in one call
+    with pytest.raises(RuntimeError, match="attn_bwd_o"):
+        lib().call("mh_attn_bwd_o", *args, 1, st)
+    ops.set_option("attn_v3", 127)
+    with pytest.raises(RuntimeError, match="bf16 only"):
+        lib().call("mh_attn_bwd_o", *args, 0, st)        # fp32
+    mh_err = lib().cdll.mh_last_error()
+    assert mh_err
+
+
 def test_attention_mfma_vs_plain_on_device(ops):
     """bf16: the MFMA flash kernels against the thread-per-row kernels running on the same device data."""
     from midi_model_amd.lib import lib
