@@ -39,7 +39,7 @@ __device__ inline void stage64(const bf16* __restrict__ base, int64_t ld, int64_
   for (int it = 0; it < 2; ++it) {
     const int g8 = wave + 4 * it;
     const int r = g8 * 8 + rsub;
-    const int c = pc ^ ((r >> 1) & 7);
+    const int c = pc ^ lds_swz(r);
     int64_t grow = row0 + r;
     if (grow > row_clamp) grow = row_clamp;
     glds16(base + grow * ld + col0 + c * 8, lds_tile + g8 * 1024);
@@ -72,7 +72,7 @@ __device__ inline void stage64u(const bf16* __restrict__ base, int ld, int row0,
   for (int it = 0; it < 2; ++it) {
     const int g8 = wave + 4 * it;
     const int r = g8 * 8 + rsub;
-    const int c = pc ^ ((r >> 1) & 7);
+    const int c = pc ^ lds_swz(r);
     int grow = row0 + r;
     grow = grow > row_clamp ? row_clamp : grow;
     const unsigned off = (unsigned)(grow * ld + col0 + c * 8) * 2u;
@@ -109,7 +109,7 @@ __device__ inline bf16x8 join8(const u32x2& a, const u32x2& b) {
 // lane i of the group receives column i (4 rows); supplier p of group g points at row 8 hi + 4 half + (p >> 2), columns
 // xb*32 + 16 (g&1) + 8 (p&1) + 4 ((p>>1)&1) .. +3, which hands output lane i column xb*32 + pi32(16 (g&1) + i) -- the row
 // permutation the accumulator layout wants.  Two reads (half = 0, 1) make one 8-deep fragment; the 16-row step t of the
-// contraction is the immediate t * 2048 (it leaves the swizzle term (row >> 1) & 7 unchanged).
+// contraction is the immediate t * 2048 (it leaves the swizzle term lds_swz(row) unchanged).
 __device__ inline void tr_frag_offsets(int lane, int (&voff)[2][2]) {
   const int p = lane & 15, gb = (lane >> 4) & 1, hi = lane >> 5;
 #pragma unroll

@@ -166,7 +166,12 @@ __device__ inline uint64_t wave_max_u64_fast(uint64_t k) {
 // a row are XOR-swizzled with ((row>>1)&7) so that the ds_read_b128 fragment reads of both MFMA
 // shapes (16x16: lane (i=l&15,g=l>>4) -> row i, chunk 4kk+g; 32x32: lane (i=l&31,hi=l>>5) -> row
 // pi(i), chunk 2s+hi) hit 16 distinct 16-byte slots per lane group (MI355X_MICROARCH §LDS).
-__device__ inline int lds_tile_off(int row, int chunk) { return row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4); }
+// The XOR term is the BIT-REVERSED (row >> 1) & 7 (r02): any bijection of it serves the 16-byte fragment reads, and this one
+// also puts rows r and r + 2 into different 64-byte halves of the 128-byte bank row, which is what a ds_read_b64_tr_b16 of a
+// [4 rows][32 columns] block needs -- with the plain term rows r and r + 2 of such a read shared their 16 banks (2-way
+// conflicts on every transpose read of the attention kernels: a third of their LDS-active cycles, profiles/r02_run27_*).
+__device__ inline int lds_swz(int row) { return (((row >> 1) & 1) << 2) | (((row >> 2) & 1) << 1) | ((row >> 3) & 1); }
+__device__ inline int lds_tile_off(int row, int chunk) { return row * 128 + ((chunk ^ lds_swz(row)) << 4); }
 
 // Direct global->LDS staging (global_load_lds_dwordx4): one call moves 1 KiB = 8 tile rows per
 // wave.  The LDS image is lane-linear (base + lane*16), so the swizzle goes on the SOURCE chunk.

@@ -45,7 +45,7 @@ __device__ inline void stage_tile(const T* __restrict__ base, int64_t ld, int64_
   for (int it = 0; it < 4; ++it) {
     const int g8 = wave + 4 * it;  // 8-row group handled by this wave
     const int r = g8 * 8 + rsub;
-    const int c = pc ^ ((r >> 1) & 7);
+    const int c = pc ^ lds_swz(r);
     const int64_t grow = row0 + r;
     const int64_t k = k0 + (int64_t)c * EPC;
     const void* src = (grow < nrows && k < kend) ? (const void*)(base + grow * ld + k) : (const void*)g_zero16;
