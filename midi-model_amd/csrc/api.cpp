@@ -26,6 +26,9 @@ static int env_int(const char* name, int dflt) {
 }
 int g_mh_gemm_variant = env_int("MH_GEMM", 1);
 int g_mh_gemm_ablate = 0;
+// "gemm_k64": 1 (default) = products of two row-major operands (every forward projection) run the K-step-64 main loop of
+// gemm_pp256_kernel (whole-line LDS-DMA, r03), 0 = the K-step-32 loop everywhere (bit-identical results; A/B runs, MH_GEMM_K64)
+int g_mh_gemm_k64 = env_int("MH_GEMM_K64", 1);
 extern int g_skinny_mb, g_skinny_nbt;  // gemm_skinny.hip
 extern int g_attn_v3, g_attn_v3_wps;      // attention_mfma3.hip
 
@@ -36,6 +39,10 @@ extern "C" int mh_set_option(const char* name, int value) {
   }
   if (strcmp(name, "gemm_ablate") == 0) {
     g_mh_gemm_ablate = value;
+    return 0;
+  }
+  if (strcmp(name, "gemm_k64") == 0) {
+    g_mh_gemm_k64 = value;
     return 0;
   }
   if (strcmp(name, "skinny_mb") == 0) {  // 16-row blocks of the activation per workgroup of mh_gemm_skinny (0 = default)
@@ -63,6 +70,10 @@ extern "C" int mh_get_option(const char* name) {
   if (strcmp(name, "gemm") == 0) return g_mh_gemm_variant;
   if (strcmp(name, "skinny_mb") == 0) return g_skinny_mb;
   if (strcmp(name, "attn_v3") == 0) return g_attn_v3;
+  if (strcmp(name, "attn_v3_wps") == 0) return g_attn_v3_wps;
+  if (strcmp(name, "skinny_nbt") == 0) return g_skinny_nbt;
+  if (strcmp(name, "gemm_k64") == 0) return g_mh_gemm_k64;
+  if (strcmp(name, "gemm_ablate") == 0) return g_mh_gemm_ablate;
   return -1;
 }
 

@@ -19,6 +19,8 @@
 // Roofline: MFMA, 2.5 PFLOP/s dense bf16.
 #include <limits.h>
 
+#include <type_traits>
+
 #include "common.h"
 
 namespace {
@@ -97,7 +99,250 @@ __device__ inline bf16x8 frag(const char* tile, int row0, int fi, int fg) {
   }
 }
 
-template <bool TA, bool TB, int ABL, int EPI>
+// ---- second main loop (r03): K-step 64, whole-line LDS-DMA, two phases per K-tile -------------------------------------
+// What r01/r02 measured on the loop below (profiles/r01_run5_gemm_pp256_ablation.txt): the complete kernel runs at the rate of
+// its LDS-DMA alone (0.90 us per 32-deep step against 0.65 us for the MFMAs alone), and that rate is set by the number of
+// cache-line segments a request touches -- a K-step-32 piece is 16 rows x 64 B = 16 half lines per instruction, the same KiB
+// as 8 rows x 128 B takes 0.61 us.  Row-major operands therefore want 128-byte LDS rows, i.e. a 64-deep K-tile, and with
+// 64 KiB per K-tile only two tiles fit beside each other.  The lookahead the feed needs (1.5-2.5 us under load) then has to
+// come from re-filling a PART of a buffer as soon as its last reader is done:
+//   * a K-tile lives in one of two 64 KiB buffers as four 16 KiB regions [A-h0 | A-h1 | B-h0 | B-h1]; region A-h{mh} holds
+//     the 64 rows wr*128 + mh*64 + [0,64) of BOTH wave groups (wr = 0, 1), region B-h{nh} the 32 columns wn*64 + nh*32 +
+//     [0,32) of all four column quarters (EPI 2: nh = gate / up), so a region is read by all eight waves in the same phase;
+//   * two phases per K-tile, 32 MFMAs (16x16x32) each: P1 reads A-h0, B-h0, B-h1 (16 ds_read_b128) -> quadrants (0,0) (0,1);
+//     P2 reads A-h1 (8) -> (1,0) (1,1) with the B fragments still in registers;
+//   * regions are issued in the order A-h0, B-h0, B-h1, A-h1 of tile t, t+1, ... (2 LDS-DMA instructions per wave and
+//     region, 8 rows x 128 B each): seven regions before phase 0, then P1(t) issues A-h1(t+1) and P2(t) issues A-h0, B-h0,
+//     B-h1 of tile t+2 -- each one phase after the region's last read, three phases (1.5 K-tiles) ahead of its first read;
+//   * the fragment reads are waited for at the END of the load slot (the MFMA slot opens with MFMAs, and a region's
+//     reads are complete before the barrier that closes the slot they were issued in: the re-fill may follow at once);
+//   * counted waits only: before the barrier that opens phase q+1 a wave waits until its own pieces of the regions phase
+//     q+1 reads have landed (vmcnt(8): four regions stay in flight);
+//   * the two wave groups run one barrier apart (waves w and w+4 share a SIMD): one multiplies while the other reads and
+//     issues, two workgroup barriers per phase = four per 64-deep K-tile, as the K-step-32 loop has.
+// LDS row r of a region keeps its 16-byte chunk c at slot c ^ ((r >> 1) & 7): the four 16-lane groups of a ds_read_b128
+// fragment read (rows i, chunks 4 kb + g) hit 16 distinct slots of the 256-byte bank row (checked by enumeration, and
+// SQ_LDS_BANK_CONFLICT = 0 on the device); the swizzle is applied to the SOURCE chunk of the lane-linear LDS-DMA image.
+// Results are bit-identical to the K-step-32 loop's: the same 32-deep MFMA products are added in the same order.
+//
+// Schedules measured and dropped (profiles/r03_gemm_k64_schedules.txt; [32768 x 1024 x 16384], K-step-32 loop 1080-1130 TF):
+// four phases of 16 MFMAs per K-tile with the read wait at the head of the MFMA slot 1280-1350 (the guide's 8-phase shape: the
+// LDS latency sits in front of every MFMA slot and twice the barriers), the same with the wait in the load slot and one
+// region more lookahead 1330-1343, THIS schedule 1380-1436, its LDS-DMA issued at the tail of the MFMA slot instead 1180, one
+// region per wave in every slot (load and MFMA slots alike) 1230-1250: whatever lengthens the MFMA slot is paid in full; ONE
+// barrier per phase (LDS-safe: a phase's regions have landed before its interval opens and both groups' reads are complete when
+// it closes; the groups then alternate by program order only) 1320-1330: they drift into reading and issuing at the same time;
+// LDS-DMA ahead of the reads in the load slot: +-0.  In-kernel s_memtime timeline of this schedule (all eight waves, same file):
+// a load slot is 16 reads complete after ~400 cycles + the issue of 2 / 6 LDS-DMA instructions 300 / 600 (the L1 path takes a
+// 1 KiB request every ~40 cycles and blocks the issuing wave meanwhile) + ~130 of waits, the MFMA slot 600-650, a barrier ~100:
+// the load slot of one group is what the MFMAs of the other wait for.
+constexpr int P8_REGION = 128 * 128;  // 16 KiB
+constexpr int P8_BUF = 4 * P8_REGION;
+constexpr int P8_DBG_BYTES = 8 * 2048;  // timeline builds (ABL bit 7): 256 stamps per wave behind the two K-tile buffers
+
+template <int EPI, int ABL>
+__device__ __forceinline__ void p8_main_loop(char* smem, const bf16* __restrict__ A, int64_t lda, const bf16* __restrict__ B,
+                                             int64_t ldb, int64_t M, int64_t N, int64_t m0, int64_t n0, int64_t kbeg, int64_t kend,
+                                             int wave, int lane, const void* __restrict__ zero16, f32x4 (&acc)[4][8]) {
+  constexpr bool TL = (ABL & 128) != 0;   // timeline build
+  constexpr int LA = 7;                   // regions issued before phase 0
+  const int grp = wave >> 2, wn = wave & 3;
+  const int fi = lane & 15, fg = lane >> 4;
+  const int nt = (kend > kbeg) ? (int)((kend - kbeg + 63) / 64) : 0;
+  const int nreg = 4 * nt;  // regions of this K range, in issue order s = 4 t + {A-h0: 0, B-h0: 1, B-h1: 2, A-h1: 3}
+
+  // ---- timeline (ABL bit 7): lane 0 of every wave stamps s_memtime into LDS, 7 stamps per phase; workgroup 0 copies them out ----
+  int tl_n = 0;
+  auto stamp = [&]() {
+    if constexpr (TL) {
+      const uint64_t c = __builtin_readcyclecounter();
+      if (lane == 0 && tl_n < 256) *reinterpret_cast<uint64_t*>(smem + 2 * P8_BUF + wave * 2048 + tl_n * 8) = c;
+      ++tl_n;
+    }
+  };
+
+  // ---- LDS-DMA sources: instruction it of a region covers its rows (wave*2 + it)*8 + (lane >> 3), chunk lane & 7 ----
+  const bf16* pa[2];
+  const bf16* pb[2];
+  int kla[2][2], klb[2][2];  // [h][it]: kend - chunk*8 when the row exists, INT_MIN otherwise
+  const int64_t hoff_a = 64 * lda, hoff_b = (EPI == 2) ? (N / 2) * ldb : 32 * ldb;
+#pragma unroll
+  for (int it = 0; it < 2; ++it) {
+    const int lr = (wave * 2 + it) * 8 + (lane >> 3);
+    const int ch = (lane & 7) ^ ((lr >> 1) & 7);
+    const int64_t ra = m0 + (lr >> 6) * 128 + (lr & 63);                                       // + 64 for h = 1
+    const int64_t rb = (EPI == 2) ? n0 + lr : n0 + (lr >> 5) * 64 + (lr & 31);                  // + N/2 or + 32 for h = 1
+    const int64_t rb1 = (EPI == 2) ? rb + N / 2 : rb + 32;
+    pa[it] = A + (ra < M ? ra : 0) * lda + ch * 8;
+    pb[it] = B + (rb < N ? rb : 0) * ldb + ch * 8;
+    kla[0][it] = (ra < M) ? (int)kend - ch * 8 : INT_MIN;
+    kla[1][it] = (ra + 64 < M) ? (int)kend - ch * 8 : INT_MIN;
+    klb[0][it] = (rb < N) ? (int)kend - ch * 8 : INT_MIN;
+    klb[1][it] = (rb1 < N) ? (int)kend - ch * 8 : INT_MIN;
+  }
+  // region s of the issue order
+  auto issue = [&](int s) {
+    const int t = s >> 2, r = s & 3;            // r: 0 A-h0, 1 B-h0, 2 B-h1, 3 A-h1
+    const bool isb = (r == 1 || r == 2);
+    const int h = (r >= 2) ? 1 : 0;
+    const int slot = isb ? 2 + h : h;           // LDS order [A-h0 | A-h1 | B-h0 | B-h1]
+    const int k0 = (int)kbeg + t * 64;
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {
+      char* dst = smem + (t & 1) * P8_BUF + slot * P8_REGION + (wave * 2 + it) * 1024;
+      const bf16* p = isb ? pb[it] + (h ? hoff_b : 0) : pa[it] + (h ? hoff_a : 0);
+      const int kl = isb ? klb[h][it] : kla[h][it];
+      const void* src = (k0 < kl) ? (const void*)(p + k0) : zero16;
+      glds16(src, dst);
+    }
+  };
+
+  // ---- fragment reads ----
+  const int sw = (fi >> 1) & 7;
+  const int la0 = (grp * 64 + fi) * 128 + ((fg ^ sw) << 4);                     // K-block 0; K-block 1 = ^ 64
+  const int lb0 = 2 * P8_REGION + (wn * 32 + fi) * 128 + ((fg ^ sw) << 4);
+  bf16x8 fx[4][2], fw[2][2][2];  // fx[m4][kb]: the current A half; fw[nh][n2][kb]
+  auto read_a = [&](const char* buf, int mh) {
+    if ((ABL & 2) && buf != smem) return;
+#pragma unroll
+    for (int m4 = 0; m4 < 4; ++m4)
+#pragma unroll
+      for (int kb = 0; kb < 2; ++kb)
+        fx[m4][kb] = *reinterpret_cast<const bf16x8*>(buf + mh * P8_REGION + m4 * 2048 + (la0 ^ (kb << 6)));
+  };
+  auto read_b = [&](const char* buf, int nh) {
+    if ((ABL & 2) && buf != smem) return;
+#pragma unroll
+    for (int n2 = 0; n2 < 2; ++n2)
+#pragma unroll
+      for (int kb = 0; kb < 2; ++kb)
+        fw[nh][n2][kb] = *reinterpret_cast<const bf16x8*>(buf + nh * P8_REGION + n2 * 2048 + (lb0 ^ (kb << 6)));
+  };
+  auto mfma_q = [&](int mh, int nh) {
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+      for (int n2 = 0; n2 < 2; ++n2)
+#pragma unroll
+        for (int m4 = 0; m4 < 4; ++m4)
+          if (!(ABL & 4))
+            acc[nh * 2 + n2][mh * 4 + m4] =
+                __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw[nh][n2][kb], fx[m4][kb], acc[nh * 2 + n2][mh * 4 + m4], 0, 0, 0);
+  };
+  auto bar = [&]() {
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+  };
+  auto wait_lds = [&]() {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+  };
+  auto wait_out = [&](int out) {  // at most `out` regions (2 LDS-DMA instructions each) of this wave stay in flight
+    if (out >= 4) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    else if (out == 3) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    else if (out == 2) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    else if (out == 1) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  };
+  // regions 0 .. need(q)-1 must have landed before phase q = 2 t + p reads
+  auto need = [&](int q) { return (q >> 1) * 4 + ((q & 1) ? 4 : 3); };
+  // regions issued once phase q has issued its share
+  auto issued_after = [&](int q) {
+    const int n = (q >> 1) * 4 + ((q & 1) ? 11 : 8);
+    return n < nreg ? n : nreg;
+  };
+  // the LDS-DMA share of phase q.  STEADY: every region it names exists (no branches in the loop)
+  auto issue_phase = [&](int q, auto steady) {
+    constexpr bool ST = decltype(steady)::value;
+    if (!(ABL & 1)) {
+      const int t4 = (q >> 1) * 4;
+      if ((q & 1) == 0) {
+        if (ST || t4 + 7 < nreg) issue(t4 + 7);
+      } else {
+#pragma unroll
+        for (int j = 8; j < 11; ++j)
+          if (ST || t4 + j < nreg) issue(t4 + j);
+      }
+    }
+    stamp();
+  };
+  auto read_phase = [&](int t, int p) {
+    const char* buf = smem + (t & 1) * P8_BUF;
+    if (p == 0) {
+      read_b(buf, 0);
+      read_b(buf, 1);
+      read_a(buf, 0);
+    } else {
+      read_a(buf, 1);
+    }
+    stamp();
+  };
+  auto load_slot = [&](int t, int p, auto steady) {
+    read_phase(t, p);
+    issue_phase(2 * t + p, steady);
+    wait_lds();
+    stamp();
+  };
+  auto mfma_phase = [&](int p) {
+    mfma_q(p, 0);  // (no s_setprio around them: with or without measured the same here, 1400-1450 TF at K = 16384)
+    mfma_q(p, 1);
+    stamp();
+  };
+  auto wait_next = [&](int q, auto steady) {  // before the barrier that opens phase q + 1
+    if constexpr (decltype(steady)::value) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    else if (q + 1 < 2 * nt) wait_out(issued_after(q) - need(q + 1));
+    stamp();
+  };
+  // stamps per phase -- group 0: start, reads, issue, lds wait | barrier | after barrier, MFMAs issued, vmcnt | barrier
+  //                     group 1: start, MFMAs issued | barrier | after barrier, reads, issue, lds wait, vmcnt | barrier
+  auto tile_g0 = [&](int t, auto steady) {
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+      stamp();
+      load_slot(t, p, steady);
+      bar();
+      stamp();
+      mfma_phase(p);
+      wait_next(2 * t + p, steady);
+      bar();
+    }
+  };
+  // (slot 2q, between barriers 2q and 2q+1: group 0 reads phase q, group 1 multiplies phase q-1; slot 2q+1: the reverse)
+  auto tile_g1 = [&](int t, auto steady) {
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+      stamp();
+      if (2 * t + p > 0) mfma_phase(p ^ 1);
+      else stamp();
+      bar();
+      stamp();
+      load_slot(t, p, steady);
+      wait_next(2 * t + p, steady);
+      bar();
+    }
+  };
+
+#pragma unroll
+  for (int s = 0; s < LA; ++s)
+    if (s < nreg) issue(s);
+  if (nt > 0) wait_out((nreg < LA ? nreg : LA) - need(0));
+  bar();  // barrier 0: the regions of phase 0 are in LDS
+  const int nsteady = nt > 2 ? nt - 2 : 0;  // everything P2(t) issues exists: 4 t + 10 < 4 nt
+  if (grp == 0) {
+    for (int t = 0; t < nsteady; ++t) tile_g0(t, std::true_type{});
+    for (int t = nsteady; t < nt; ++t) tile_g0(t, std::false_type{});
+  } else {
+    for (int t = 0; t < nsteady; ++t) tile_g1(t, std::true_type{});
+    for (int t = nsteady; t < nt; ++t) tile_g1(t, std::false_type{});
+    if (nt > 0) mfma_phase(1);
+  }
+  if constexpr (TL) {  // (the caller copies the stamps out after its epilogue)
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  }
+}
+
+template <bool TA, bool TB, int ABL, int EPI, int ML>
 __global__ __launch_bounds__(512, 2) void gemm_pp256_kernel(const bf16* __restrict__ A, int64_t lda,
                                                             const bf16* __restrict__ B, int64_t ldb, bf16* C, int64_t ldc,
                                                             const bf16* R, int64_t ldr, int64_t M, int64_t N, int64_t K,
@@ -132,7 +377,6 @@ __global__ __launch_bounds__(512, 2) void gemm_pp256_kernel(const bf16* __restri
 
   const int64_t kbeg = (int64_t)zslice * k_per_split;
   const int64_t kend = (kbeg + k_per_split < K) ? kbeg + k_per_split : K;
-  const int nt = (kend > kbeg) ? (int)((kend - kbeg + QBK - 1) / QBK) : 0;
 
   f32x4 acc[4][8];  // [fn][fm]: 64 columns x 128 rows of this wave
 #pragma unroll
@@ -140,7 +384,23 @@ __global__ __launch_bounds__(512, 2) void gemm_pp256_kernel(const bf16* __restri
 #pragma unroll
     for (int b = 0; b < 8; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
   const int fi = lane & 15, fg = lane >> 4;
+  auto bar = [&]() {
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+  };
 
+  if constexpr (ML >= 1) {
+    p8_main_loop<EPI, ABL>(smem, A, lda, B, ldb, M, N, m0, n0, kbeg, kend, wave, lane, zero16, acc);
+    if constexpr ((ABL & 128) != 0) {  // timeline build: workgroup 0 hands its stamps to the caller (ws), then the normal epilogue
+      __syncthreads();
+      if (blockIdx.x == 0 && blockIdx.z == 0)
+        for (int i = tid; i < P8_DBG_BYTES / 8; i += 512)
+          reinterpret_cast<uint64_t*>(ws)[i] = reinterpret_cast<const uint64_t*>(smem + 2 * P8_BUF)[i];
+      __syncthreads();
+    }
+  } else {
+  const int nt = (kend > kbeg) ? (int)((kend - kbeg + QBK - 1) / QBK) : 0;
   StageCtx ca, cb;
   if constexpr (TA) stage_init_t(ca, A, lda, m0, M, kend, wave, lane);
   else stage_init_n(ca, A, lda, m0, M, kend, wave, lane, (ABL & 8) != 0);
@@ -188,11 +448,6 @@ __global__ __launch_bounds__(512, 2) void gemm_pp256_kernel(const bf16* __restri
     }
     __builtin_amdgcn_s_setprio(0);
   };
-  auto bar = [&]() {
-    __builtin_amdgcn_sched_barrier(0);
-    __builtin_amdgcn_s_barrier();
-    __builtin_amdgcn_sched_barrier(0);
-  };
   // Before barrier 2t every wave makes sure its own LDS-DMA of step t has landed; the 4 instructions each of steps
   // t+1 and t+2 may stay in flight.
   auto wait_step = [&](int t) {
@@ -239,6 +494,7 @@ __global__ __launch_bounds__(512, 2) void gemm_pp256_kernel(const bf16* __restri
     bar();    // barrier 2nt
     if (nt > 0) mfma_all(nt - 1);
   }
+  }  // ML == 0
 
   // epilogue: lane (fi, fg) of fragment (fn, fm) holds C[m][n..n+3], m = m0 + grp*128 + fm*16 + fi
   const bool partial = (gridDim.z > 1);
@@ -545,9 +801,10 @@ __global__ __launch_bounds__(512, 2) void gemm_pp256_kernel(const bf16* __restri
   }
 }
 
-template <bool TA, bool TB, int ABL, int EPI = 0>
+template <bool TA, bool TB, int ABL, int EPI = 0, int ML = 0>
 int launch_one(const void* A, int64_t lda, const void* B, int64_t ldb, void* C, int64_t ldc, const void* R, int64_t ldr,
                int64_t M, int64_t N, int64_t K, float alpha, float beta, int splitk, void* workspace, hipStream_t st) {
+  constexpr int LDSB = LDS_BYTES + ((ABL & 128) ? P8_DBG_BYTES : 0);
   static bool attr_set = false;
   static void* zero16 = nullptr;  // 16 zero bytes in device memory: the source of out-of-range LDS-DMA chunks
   if (zero16 == nullptr && hipGetSymbolAddress(&zero16, HIP_SYMBOL(g_zero16)) != hipSuccess) {
@@ -555,19 +812,20 @@ int launch_one(const void* A, int64_t lda, const void* B, int64_t ldb, void* C, 
     return MH_ERR_LAUNCH;
   }
   if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_pp256_kernel<TA, TB, ABL, EPI>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_pp256_kernel<TA, TB, ABL, EPI, ML>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, LDSB);
     if (e != hipSuccess) {
-      mh_set_error("gemm_pp256: cannot raise dynamic LDS to %d bytes: %s", LDS_BYTES, hipGetErrorString(e));
+      mh_set_error("gemm_pp256: cannot raise dynamic LDS to %d bytes: %s", LDSB, hipGetErrorString(e));
       return MH_ERR_LAUNCH;
     }
     attr_set = true;
   }
   const int64_t tiles_m = (M + QBM - 1) / QBM, tiles_n = (EPI == 2) ? N / 256 : (N + QBN - 1) / QBN;  // (EPI 2: I / 128)
   const int nwg = (int)(tiles_m * tiles_n);
-  const int64_t kps = ((K + splitk - 1) / splitk + QBK - 1) / QBK * QBK;
+  constexpr int KSTEP = (ML == 1) ? 64 : QBK;
+  const int64_t kps = ((K + splitk - 1) / splitk + KSTEP - 1) / KSTEP * KSTEP;
   dim3 grid(nwg, 1, splitk);
-  gemm_pp256_kernel<TA, TB, ABL, EPI><<<grid, 512, LDS_BYTES, st>>>((const bf16*)A, lda, (const bf16*)B, ldb, (bf16*)C, ldc,
+  gemm_pp256_kernel<TA, TB, ABL, EPI, ML><<<grid, 512, LDSB, st>>>((const bf16*)A, lda, (const bf16*)B, ldb, (bf16*)C, ldc,
                                                           (const bf16*)R, ldr, M, N, K, alpha, beta, (int)tiles_n, nwg, kps,
                                                           (float*)workspace, zero16);
   MH_LAUNCH_CHECK();
@@ -576,7 +834,8 @@ int launch_one(const void* A, int64_t lda, const void* B, int64_t ldb, void* C, 
 
 }  // namespace
 
-extern int g_mh_gemm_ablate;  // api.cpp
+extern int g_mh_gemm_ablate;   // api.cpp
+extern int g_mh_gemm_k64;      // api.cpp: row-major x row-major products take the K-step-64 main loop (default 1)
 
 // called by gemm.hip after argument validation (bf16 only)
 int mh_gemm_pp256_bf16(const void* A, int64_t lda, int ta, const void* B, int64_t ldb, int tb, void* C, int64_t ldc,
@@ -584,7 +843,7 @@ int mh_gemm_pp256_bf16(const void* A, int64_t lda, int ta, const void* B, int64_
                        void* workspace, hipStream_t st) {
 #define MH_PP(TA_, TB_, ABL_) \
   return launch_one<TA_, TB_, ABL_>(A, lda, B, ldb, C, ldc, R, ldr, M, N, K, alpha, beta, splitk, workspace, st)
-  if (ta == tb && g_mh_gemm_ablate) {  // micro-benchmark builds (wrong results), both-row-major / both-contraction-major
+  if (ta == tb && g_mh_gemm_ablate && !(g_mh_gemm_k64 && !ta)) {  // micro-benchmark builds (wrong results), both-row-major / both-contraction-major
 #define MH_AB(X_) \
   case X_:        \
     if (ta) MH_PP(true, true, X_); \
@@ -601,6 +860,17 @@ int mh_gemm_pp256_bf16(const void* A, int64_t lda, int ta, const void* B, int64_
   if (ta && tb) MH_PP(true, true, 0);
   if (ta) MH_PP(true, false, 0);
   if (tb) MH_PP(false, true, 0);
+  if (g_mh_gemm_k64) {  // both operands row-major: the K-step-64 main loop
+#define MH_P8(ABL_) \
+  return launch_one<false, false, ABL_, 0, 1>(A, lda, B, ldb, C, ldc, R, ldr, M, N, K, alpha, beta, splitk, workspace, st)
+    switch (g_mh_gemm_ablate) {  // (micro-benchmark builds: tools/bench_gemm.py, tools/gemm_timeline.py)
+      case 1: MH_P8(1);
+      case 4: MH_P8(4);
+      case 128: MH_P8(128);
+      default: MH_P8(0);
+    }
+#undef MH_P8
+  }
   MH_PP(false, false, 0);
 #undef MH_PP
 }
@@ -608,12 +878,14 @@ int mh_gemm_pp256_bf16(const void* A, int64_t lda, int ta, const void* B, int64_
 // gate|up = A * [Wgate; Wup]^T and a = round(silu(gate)) * up in one launch (both operands row-major); gemm.hip validates
 int mh_gemm_pp256_swiglu_bf16(const void* A, int64_t lda, const void* W, int64_t ldw, void* GU, int64_t ldgu, void* ACT,
                               int64_t ldact, int64_t M, int64_t I, int64_t K, hipStream_t st) {
+  if (g_mh_gemm_k64) return launch_one<false, false, 0, 2, 1>(A, lda, W, ldw, GU, ldgu, ACT, ldact, M, 2 * I, K, 1.f, 0.f, 1, nullptr, st);
   return launch_one<false, false, 0, 2>(A, lda, W, ldw, GU, ldgu, ACT, ldact, M, 2 * I, K, 1.f, 0.f, 1, nullptr, st);
 }
 
 // [q | k | v] = A * W^T with the rotary embedding applied to the q and k heads in the epilogue; gemm.hip validates
 int mh_gemm_pp256_rope_bf16(const void* A, int64_t lda, const void* W, int64_t ldw, void* C, int64_t ldc, const void* table,
                             int64_t S, int64_t pos0, int64_t M, int64_t N, int64_t K, hipStream_t st) {
+  if (g_mh_gemm_k64) return launch_one<false, false, 0, 3, 1>(A, lda, W, ldw, C, ldc, table, S | (pos0 << 32), M, N, K, 1.f, 0.f, 1, nullptr, st);
   return launch_one<false, false, 0, 3>(A, lda, W, ldw, C, ldc, table, S | (pos0 << 32), M, N, K, 1.f, 0.f, 1, nullptr, st);
 }
 

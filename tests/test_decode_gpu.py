@@ -42,8 +42,10 @@ def _n_steps(tok, ids):
     return alive[0] + 1 if all(a == alive[0] for a in alive) else tok.max_token_seq
 
 
-def test_production_decode_session_matches_oracle(orc, tok, medium_bf16, golden):
-    """64-event prompt prefill + 8 decoded events, greedy (top_k = 1): after every replayed graph the session's hidden
+@pytest.mark.parametrize("B,P,n_events", [(4, 65, 8), (64, 17, 4)], ids=["b4", "b64_benchmarked_batch"])
+def test_production_decode_session_matches_oracle(orc, tok, medium_bf16, golden, B, P, n_events):
+    """(B = 64: the batch bench.py --mode generate runs, where mh_gemm_skinny takes its 64-row tilings.)
+    64-event prompt prefill + 8 decoded events, greedy (top_k = 1): after every replayed graph the session's hidden
     state / logits are within the reference's own bf16 drift (x1.5) of the oracle's cached fp32 forward on the SAME
     tokens, and the greedy id equals the oracle's masked arg-max wherever the oracle's top-2 margin exceeds twice that
     bound.  The oracle is teacher-forced with the ids the device picked, so both sides see identical inputs throughout."""
@@ -52,7 +54,7 @@ def test_production_decode_session_matches_oracle(orc, tok, medium_bf16, golden)
     g = golden("medium_long_S2048.npz")
     hid_bound = DRIFT * float(g["ref_bf16_hidden_maxerr"])
     log_bound = DRIFT * float(g["ref_bf16_logits_maxerr"])
-    B, P, V = 4, 65, tok.vocab_size
+    V = tok.vocab_size
     prompt = orc.synthetic_events(tok, B, P, seed=31)
     torch.set_num_threads(min(os.cpu_count() or 8, 32))
     with torch.inference_mode():
@@ -67,7 +69,7 @@ def test_production_decode_session_matches_oracle(orc, tok, medium_bf16, golden)
         cache1 = orc.KV()
         hid_o = orc.midi_forward(sd, shp, prompt, cache1)[:, -1]
         worst_h, worst_l, checked, total = 0.0, 0.0, 0, 0
-        for ev_i in range(8):
+        for ev_i in range(n_events):
             err = (ses.hidden.float().cpu() - hid_o).abs().max().item()
             worst_h = max(worst_h, err)
             assert err <= hid_bound, (ev_i, err, hid_bound)

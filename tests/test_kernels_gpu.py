@@ -26,12 +26,15 @@ def ops():
     return real
 
 
-@pytest.fixture(params=[0, 1], ids=["gemm128", "gemmpp256"])
+@pytest.fixture(params=[0, 1, 2], ids=["gemm128", "gemmpp256", "gemmpp256k32"])
 def gemm_variant(request, ops):
-    """run the GEMM tests against both projection kernels (gemm.hip / gemm_pp256.hip)"""
-    ops.set_option("gemm", request.param)
+    """run the GEMM tests against the projection kernels: gemm.hip, gemm_pp256.hip as shipped (K-step-64 main loop for two
+    row-major operands, K-step-32 ping-pong loop otherwise), gemm_pp256.hip with the K-step-32 loop everywhere"""
+    ops.set_option("gemm", min(request.param, 1))
+    ops.set_option("gemm_k64", 0 if request.param == 2 else 1)
     yield request.param
     ops.set_option("gemm", 1)
+    ops.set_option("gemm_k64", 1)
 
 
 def rnd(shape, dtype, seed, scale=1.0):
@@ -148,8 +151,32 @@ def test_transpose(ops, dtype, R, C):
     assert torch.equal(out[:, :R].cpu(), x.T) and (out[:, R:] == 0).all()
 
 
+@pytest.fixture(params=[0, 1], ids=["k32", "k64"])
+def main_loop(request, ops):
+    """the two main loops of gemm_pp256_kernel behind the fused-epilogue entry points"""
+    ops.set_option("gemm_k64", request.param)
+    yield request.param
+    ops.set_option("gemm_k64", 1)
+
+
+def test_gemm_main_loops_agree_bit_for_bit(ops):
+    """both main loops add the same 32-deep MFMA products in the same order: identical bits, ragged shapes included"""
+    dt = torch.bfloat16
+    for (M, N, K) in [(512, 512, 1024), (300, 520, 2048 + 72), (1000, 3406, 1024), (256, 256, 64), (257, 264, 8)]:
+        a, b = rnd((M, K), dt, 81).cuda(), rnd((N, K), dt, 82).cuda()
+        outs = []
+        for v in (0, 1):
+            ops.set_option("gemm_k64", v)
+            o = torch.full((M, N), float("nan"), dtype=dt, device="cuda")
+            ops.gemm_nt(a, b, o, splitk=1)
+            outs.append(o)
+        ops.set_option("gemm_k64", 1)
+        for o in outs[1:]:
+            assert torch.equal(outs[0], o), (M, N, K, (outs[0].float() - o.float()).abs().max().item())
+
+
 @pytest.mark.parametrize("M,I,K", [(256, 128, 64), (300, 640, 1024), (1000, 4096, 1024), (77, 1024, 264)])
-def test_gemm_swiglu(ops, M, I, K):
+def test_gemm_swiglu(ops, main_loop, M, I, K):
     """gate|up projection with the SwiGLU forward as its epilogue == mh_gemm_nt followed by mh_swiglu_fwd"""
     dt = torch.bfloat16
     x, w = rnd((M, K), dt, 64, 0.5), rnd((2 * I, K), dt, 65, 0.5)
@@ -170,7 +197,7 @@ def test_gemm_swiglu(ops, M, I, K):
 
 
 @pytest.mark.parametrize("B,S,H,K", [(1, 256, 4, 64), (2, 150, 2, 256), (3, 100, 16, 1024), (1, 77, 1, 264), (2, 2048, 16, 1024)])
-def test_gemm_rope(ops, B, S, H, K):
+def test_gemm_rope(ops, main_loop, B, S, H, K):
     """q|k|v projection with the rotary embedding as its epilogue == mh_gemm followed by mh_rope (bit for bit), and the
     emulation within the bf16 bound"""
     from midi_model_amd.engine import RopeTable

@@ -423,3 +423,132 @@ def test_two_times_hidden_shape_against_oracle(orc, tok, dtype):
     flat_ref = torch.cat([sdg[k].grad.reshape(-1) for k in named]).double()
     cos = (torch.dot(flat, flat_ref) / (flat.norm() * flat_ref.norm())).item()
     assert cos >= 1.0 - 2.0 * DRIFT * (1.0 - float(g["ref_bf16_grad_cosine"])) - 1e-4, cos
+
+
+# ------------------------------------------------------------------------------ the benchmarked BATCH shapes (r03)
+def test_training_step_at_the_benchmarked_batch(orc, medium, tok, golden):
+    """bench.py's step: bf16, B = 16 x S = 2048 (M = 32,768 event rows, 262,144 token rows, (batch x head) = 256 attention
+    work items).  Sequence 0 of the batch is the sequence the B = 1 tests hold to the oracle; sequence 9 gets its own
+    oracle forward; every sequence's hidden state inside the batch must equal its B = 1 forward (no operation of the path
+    mixes sequences: train.py:168-188 -- the only batch-size dependence of the kernels is tiling / split-K / work order);
+    loss and gradient of the batch = the target-count-weighted mean of the 16 single-sequence steps (cross_entropy
+    reduction="mean" over non-pad targets, train.py:181-186)."""
+    g = golden("medium_long_S2048.npz")
+    shp, sd = medium
+    ref = oracle_run(orc, medium, tok, 2048, grads=True)
+    batch = torch.cat([ref["batch"], orc.synthetic_events(tok, 15, 2049, seed=61)], 0)
+    assert batch.shape == (16, 2049, 8)
+    hid_bound = DRIFT * float(g["ref_bf16_hidden_maxerr"])
+    log_bound, log_rms = DRIFT * float(g["ref_bf16_logits_maxerr"]), DRIFT * float(g["ref_bf16_logits_rmserr"])
+    model = build(sd, torch.bfloat16)
+    x, y = batch[:, :-1].cuda(), batch[:, 1:].cuda()
+    with torch.no_grad():
+        h16 = model.forward(x)
+        worst = 0.0
+        for b in range(16):
+            h1 = model.forward(x[b:b + 1])
+            worst = max(worst, (h16[b].float() - h1[0].float()).abs().max().item())
+        print(f"B=16 vs B=1 hidden states: worst |diff| {worst:.4f} (bound {hid_bound:.4f})")
+        assert worst <= hid_bound
+        for b in (0, 9):
+            logits = model.forward_token(h16[b], y[b, :, :-1]).float().cpu()
+            if b == 0:
+                want = ref["logits"]
+            else:
+                torch.set_num_threads(min(os.cpu_count() or 8, 32))
+                hid = orc.midi_forward(sd, shp, batch[b:b + 1, :-1]).reshape(-1, shp.n_embd)
+                want = orc.midi_forward_token(sd, shp, hid, batch[b, 1:, :-1])
+            d = logits - want
+            print(f"  sequence {b} inside the batch vs oracle: logits max {d.abs().max().item():.4f} rms {d.pow(2).mean().sqrt().item():.5f}")
+            assert d.abs().max().item() <= log_bound and d.pow(2).mean().sqrt().item() <= log_rms
+            top2 = want.topk(2, -1).values
+            safe = (top2[..., 0] - top2[..., 1]) > 2.0 * float(g["ref_bf16_logits_maxerr"])
+            assert safe.any() and (logits.argmax(-1)[safe] == want.argmax(-1)[safe]).all()
+    del h16
+    loss16 = model.training_step(batch.cuda()).item()
+    g16 = model.grad_buffer().float().clone()
+    counts = (batch[:, 1:] != tok.pad_id).sum(dim=(1, 2)).double()
+    wsum = torch.zeros_like(g16, dtype=torch.float64)
+    lsum = 0.0
+    for b in range(16):
+        model.zero_grad()
+        lb = model.training_step(batch[b:b + 1].cuda()).item()
+        w = (counts[b] / counts.sum()).item()
+        wsum += w * model.grad_buffer().double()
+        lsum += w * lb
+    assert abs(loss16 - lsum) < 2e-3, (loss16, lsum)
+    assert abs(loss16 - ref["loss"]) < 0.05  # (sequence 0 alone: the oracle's number; the batch mean sits next to it)
+    rel = ((g16.double() - wsum).norm() / wsum.norm()).item()
+    cos = (torch.dot(g16.double(), wsum) / (g16.double().norm() * wsum.norm())).item()
+    print(f"B=16 gradient vs weighted mean of 16 single-sequence gradients: relative error {rel:.5f}, cosine {cos:.6f}")
+    assert rel < 0.02 and cos > 0.9998
+
+
+_RAGGED = {}
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16], ids=["fp32", "bf16"])
+def test_ragged_length_and_pad_collated_batch(orc, medium, tok, golden, dtype):
+    """the reference-native length and collation (train.py:81,86-90,169): a (2, 2048, 8) batch -- the model sees S = 2047
+    events, one past a multiple of every tile size -- whose second sequence is 1400 events long and padded with pad rows
+    by collate_fn.  Loss (mean over non-pad targets) and every gradient norm against the oracle."""
+    g = golden("medium_long_S2048.npz")
+    shp, sd = medium
+    full = orc.synthetic_events(tok, 1, 2048, seed=71)[0]
+    short = orc.synthetic_events(tok, 1, 1400, seed=72)[0]
+    batch = torch.stack([full, torch.nn.functional.pad(short, (0, 0, 0, 2048 - 1400), value=tok.pad_id)])
+    if "ref" not in _RAGGED:
+        torch.set_num_threads(min(os.cpu_count() or 8, 32))
+        sdg = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+        loss, _ = orc.training_loss(sdg, shp, batch)
+        loss.backward()
+        _RAGGED["ref"] = (loss.item(), {k: v.grad for k, v in sdg.items()})
+    ref_loss, ref_grads = _RAGGED["ref"]
+    model = build(sd, dtype)
+    loss = model.training_step(batch.cuda()).item()
+    named = {k: p.grad.float().cpu() for k, p in model.named_parameters()}
+    flat = torch.cat([named[k].reshape(-1) for k in named]).double()
+    flat_ref = torch.cat([ref_grads[k].reshape(-1) for k in named]).double()
+    cos = (torch.dot(flat, flat_ref) / (flat.norm() * flat_ref.norm())).item()
+    if dtype == torch.float32:
+        assert abs(loss - ref_loss) < 2e-4, (loss, ref_loss)
+        for k in named:
+            want = ref_grads[k].norm().item()
+            assert abs(named[k].norm().item() - want) <= 2e-3 * want + 1e-8, k
+        rel = ((flat - flat_ref).norm() / flat_ref.norm()).item()
+        assert rel < 1e-3 and cos > 0.999999, (rel, cos)
+        # the pad rows of the short sequence contribute nothing: their embedding row receives no gradient
+        assert named["net.embed_tokens.weight"][tok.pad_id].abs().max().item() == 0.0
+        return
+    print(f"S=2047 pad-collated bf16: loss {loss:.5f} (oracle {ref_loss:.5f}), gradient cosine {cos:.5f}")
+    assert abs(loss - ref_loss) <= DRIFT * abs(float(g["ref_bf16_loss"]) - float(g["loss"])) + 5e-3
+    assert cos >= 1.0 - DRIFT * (1.0 - float(g["ref_bf16_grad_cosine"])) - 1e-4
+    ratio = (flat.norm() / flat_ref.norm()).item()
+    assert abs(ratio - 1.0) <= DRIFT * abs(float(g["ref_bf16_grad_norm_ratio"]) - 1.0) + 0.01
+
+
+def test_tv2o_large_forward_against_oracle(orc, tok):
+    """MIDIModelConfig.from_name("tv2o-large") (midi_model.py:92-94: 24 event-level layers, 6 token-level layers), fp32
+    verification mode, S = 512: every hidden state and logit against the oracle."""
+    shp = orc.Shape(n_layer=24, vocab=tok.vocab_size)
+    sd = orc.make_state_dict(shp, seed=3)
+    cfg = mm.MIDIModelConfig.from_name("tv2o-large")
+    assert cfg.net_config.num_hidden_layers == 24 and cfg.net_token_config.num_hidden_layers == 6
+    model = mm.MIDIModel(cfg)
+    model.load_state_dict(sd, strict=True)
+    model = model.to("cuda", torch.float32).eval()
+    batch = orc.synthetic_events(tok, 2, 513, seed=81)
+    torch.set_num_threads(min(os.cpu_count() or 8, 32))
+    with torch.no_grad():
+        hid_o = orc.midi_forward(sd, shp, batch[:, :-1])
+        y = batch[:, 1:].reshape(-1, 8)
+        log_o = orc.midi_forward_token(sd, shp, hid_o.reshape(-1, shp.n_embd), y[:, :-1])
+        hid = model.forward(batch[:, :-1].cuda())
+        logits = model.forward_token(hid.reshape(-1, shp.n_embd), y[:, :-1].cuda()).float().cpu()
+    herr = (hid.float().cpu() - hid_o).abs()
+    assert (herr <= 1e-3 * hid_o.abs() + 3e-4).all(), herr.max().item()
+    lerr = (logits - log_o).abs()
+    assert (lerr <= 1e-3 * log_o.abs() + 2e-4).all(), lerr.max().item()
+    top2 = log_o.topk(2, -1).values
+    safe = (top2[..., 0] - top2[..., 1]) > 1e-3
+    assert (logits.argmax(-1)[safe] == log_o.argmax(-1)[safe]).all()

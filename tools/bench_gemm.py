@@ -35,6 +35,8 @@ def main():
         shapes = [(32768, 1024, 512, 0, 0, 0), (32768, 1024, 1024, 0, 0, 12), (32768, 1024, 2048, 0, 0, 0), (32768, 1024, 4096, 0, 0, 12),
                   (32768, 3072, 1024, 0, 0, 12), (262144, 1024, 1024, 0, 0, 6), (32768, 8192, 1024, 0, 0, 12),
                   (8192, 1024, 32768, 1, 1, 12), (1024, 1024, 262144, 1, 1, 6), (1024, 1024, 32768, 1, 1, 12)]
+    if os.environ.get("MH_BENCH_SHAPES") == "nnq":  # ablation builds of the row-major main loops
+        shapes = [(32768, 1024, 4096, 0, 0, 12), (32768, 8192, 1024, 0, 0, 12), (32768, 1024, 16384, 0, 0, 0)]
     if os.environ.get("MH_BENCH_SHAPES") == "mixed":   # one row-major, one contraction-major operand
         shapes = [sh for sh in SHAPES if sh[3] != sh[4]] + [(8192, 1024, 32768, 1, 0, 0), (3072, 1024, 32768, 1, 0, 0)]
     if os.environ.get("MH_BENCH_SHAPES") == "wgrad":
@@ -52,7 +54,8 @@ def main():
             b[:, K:] = 0
         ref = None
         for v in variants:
-            ops.set_option("gemm", v % 10)
+            ops.set_option("gemm", min(v % 10, 1))            # 0 = gemm.hip, 1 = gemm_pp256.hip as shipped,
+            ops.set_option("gemm_k64", 0 if v % 10 == 2 else 1)  # 2 = gemm_pp256.hip with the K-step-32 loop everywhere
             ops.set_option("gemm_ablate", v // 10)  # e.g. 41 = variant 1 built without MFMA (see gemm_pp256.hip ABL)
             for sk in splitks:
                 out = torch.empty((M, N), device=dev, dtype=torch.bfloat16)
