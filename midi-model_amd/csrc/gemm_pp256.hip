@@ -136,6 +136,11 @@ __device__ inline bf16x8 frag(const char* tile, int row0, int fi, int fg) {
 // a load slot is 16 reads complete after ~400 cycles + the issue of 2 / 6 LDS-DMA instructions 300 / 600 (the L1 path takes a
 // 1 KiB request every ~40 cycles and blocks the issuing wave meanwhile) + ~130 of waits, the MFMA slot 600-650, a barrier ~100:
 // the load slot of one group is what the MFMAs of the other wait for.
+// What a K = 1024 tile costs beyond its main loop (same file, passes H-J): one tile per CU takes 10 us at K = 64 and 1.45 us per
+// further K-tile (1480 TFLOP/s); a build without the output stores saves 5.5 us per tile -- 256 CUs x 128 KiB written at once is
+// ~6 TB/s, the memory side's write rate.  Starting the XCDs out of phase changed nothing (the drain is bound per XCD), and
+// PERSISTENT workgroups (one per CU walking its XCD's tiles, the next tile's LDS-DMA issued while the stores drain) measured
+// +-0 on every shape: the dispatcher already overlaps teardown and fill; the drain itself is what a K = 1024 tile waits for.
 constexpr int P8_REGION = 128 * 128;  // 16 KiB
 constexpr int P8_BUF = 4 * P8_REGION;
 constexpr int P8_DBG_BYTES = 8 * 2048;  // timeline builds (ABL bit 7): 256 stamps per wave behind the two K-tile buffers
@@ -156,10 +161,17 @@ __device__ __forceinline__ void p8_main_loop(char* smem, const bf16* __restrict_
   auto stamp = [&]() {
     if constexpr (TL) {
       const uint64_t c = __builtin_readcyclecounter();
-      if (lane == 0 && tl_n < 256) *reinterpret_cast<uint64_t*>(smem + 2 * P8_BUF + wave * 2048 + tl_n * 8) = c;
+      if (lane == 0 && tl_n < 252) *reinterpret_cast<uint64_t*>(smem + 2 * P8_BUF + wave * 2048 + tl_n * 8) = c;
       ++tl_n;
     }
   };
+  auto mark = [&](int slot) {  // slots 252 (loop entry), 253 (first regions landed), 254 (loop done) of the wave's stamp array
+    if constexpr (TL) {
+      const uint64_t c = __builtin_readcyclecounter();
+      if (lane == 0) *reinterpret_cast<uint64_t*>(smem + 2 * P8_BUF + wave * 2048 + slot * 8) = c;
+    }
+  };
+  mark(252);
 
   // ---- LDS-DMA sources: instruction it of a region covers its rows (wave*2 + it)*8 + (lane >> 3), chunk lane & 7 ----
   const bf16* pa[2];
@@ -328,6 +340,7 @@ __device__ __forceinline__ void p8_main_loop(char* smem, const bf16* __restrict_
     if (s < nreg) issue(s);
   if (nt > 0) wait_out((nreg < LA ? nreg : LA) - need(0));
   bar();  // barrier 0: the regions of phase 0 are in LDS
+  mark(253);
   const int nsteady = nt > 2 ? nt - 2 : 0;  // everything P2(t) issues exists: 4 t + 10 < 4 nt
   if (grp == 0) {
     for (int t = 0; t < nsteady; ++t) tile_g0(t, std::true_type{});
@@ -337,7 +350,8 @@ __device__ __forceinline__ void p8_main_loop(char* smem, const bf16* __restrict_
     for (int t = nsteady; t < nt; ++t) tile_g1(t, std::false_type{});
     if (nt > 0) mfma_phase(1);
   }
-  if constexpr (TL) {  // (the caller copies the stamps out after its epilogue)
+  mark(254);
+  if constexpr (TL) {  // (the caller copies the stamps out before its epilogue)
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   }
 }

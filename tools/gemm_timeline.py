@@ -31,7 +31,7 @@ for v in variants:
     st = ws.cpu().view(8, 256)
     ops.set_option("gemm_ablate", 0)
     print(f"== variant {v} M={M} N={N} K={K}: shader cycles per segment, averaged over phases 8.. (two phases per K-tile)")
-    nphase = 256 // PER - 1
+    nphase = min(252 // PER - 1, 2 * ((K + 63) // 64) - 1)
     for w in (0, 4):
         names = list(LABELS0 if w < 4 else LABELS1)
         s = st[w].tolist()
@@ -48,3 +48,16 @@ for v in variants:
     t0 = st[0, 16 * PER].item()
     for w in range(8):
         print(f"  wave {w} stamps, phases 16..17 on wave 0's clock:", [x - t0 for x in st[w, 16 * PER:18 * PER + 1].tolist()])
+    # one tile per CU: where a tile's time goes (host-timed launch against the stamps of workgroup 0)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(10):
+        lib().call("mh_gemm", a.data_ptr(), K, 0, b.data_ptr(), K, 0, out.data_ptr(), N, None, 0, M, N, K, 1.0, 0.0, 1, 1,
+                   ws.data_ptr(), torch.cuda.current_stream().cuda_stream)
+    e1.record()
+    torch.cuda.synchronize()
+    tiles = ((M + 255) // 256) * ((N + 255) // 256)
+    for w in (0, 4):
+        ent, land, done = (st[w, i].item() for i in (252, 253, 254))
+        print(f"  wave {w}: entry -> first regions landed {land - ent} cycles, main loop {done - land} cycles ({tiles} tiles, "
+              f"{e0.elapsed_time(e1) * 100:.1f} us per launch of the instrumented build)")
