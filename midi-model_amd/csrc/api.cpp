@@ -27,7 +27,8 @@ static int env_int(const char* name, int dflt) {
 int g_mh_gemm_variant = env_int("MH_GEMM", 1);
 int g_mh_gemm_ablate = 0;
 // "gemm_k64": 1 (default) = products of two row-major operands (every forward projection) run the K-step-64 main loop of
-// gemm_pp256_kernel (whole-line LDS-DMA, r03), 0 = the K-step-32 loop everywhere (bit-identical results; A/B runs, MH_GEMM_K64)
+// gemm_pp256_kernel (whole-line LDS-DMA, r03) and so does the dgrad form (A row-major, B contraction-major), 2 = only the former,
+// 0 = the K-step-32 loop everywhere (bit-identical results; A/B runs, MH_GEMM_K64)
 int g_mh_gemm_k64 = env_int("MH_GEMM_K64", 1);
 extern int g_skinny_mb, g_skinny_nbt;  // gemm_skinny.hip
 extern int g_attn_v3, g_attn_v3_wps;      // attention_mfma3.hip

@@ -145,7 +145,10 @@ constexpr int P8_REGION = 128 * 128;  // 16 KiB
 constexpr int P8_BUF = 4 * P8_REGION;
 constexpr int P8_DBG_BYTES = 8 * 2048;  // timeline builds (ABL bit 7): 256 stamps per wave behind the two K-tile buffers
 
-template <int EPI, int ABL>
+// TB: B is contraction-major ([K][N], the dgrad form).  Its two regions are then the two 32-deep K-halves of the tile, 32 k-rows
+// x 512 B each in the layout of the K-step-32 loop (whole lines as they lie; both are read in P1 and free after it, like the
+// column halves of the row-major form), and the fragments come out of them with ds_read_b64_tr_b16 (frag<true>).
+template <int EPI, int ABL, bool TB>
 __device__ __forceinline__ void p8_main_loop(char* smem, const bf16* __restrict__ A, int64_t lda, const bf16* __restrict__ B,
                                              int64_t ldb, int64_t M, int64_t N, int64_t m0, int64_t n0, int64_t kbeg, int64_t kend,
                                              int wave, int lane, const void* __restrict__ zero16, f32x4 (&acc)[4][8]) {
@@ -177,20 +180,29 @@ __device__ __forceinline__ void p8_main_loop(char* smem, const bf16* __restrict_
   const bf16* pa[2];
   const bf16* pb[2];
   int kla[2][2], klb[2][2];  // [h][it]: kend - chunk*8 when the row exists, INT_MIN otherwise
-  const int64_t hoff_a = 64 * lda, hoff_b = (EPI == 2) ? (N / 2) * ldb : 32 * ldb;
+  const int64_t hoff_a = 64 * lda, hoff_b = TB ? 32 * ldb : (EPI == 2) ? (N / 2) * ldb : 32 * ldb;
 #pragma unroll
   for (int it = 0; it < 2; ++it) {
     const int lr = (wave * 2 + it) * 8 + (lane >> 3);
     const int ch = (lane & 7) ^ ((lr >> 1) & 7);
     const int64_t ra = m0 + (lr >> 6) * 128 + (lr & 63);                                       // + 64 for h = 1
-    const int64_t rb = (EPI == 2) ? n0 + lr : n0 + (lr >> 5) * 64 + (lr & 31);                  // + N/2 or + 32 for h = 1
-    const int64_t rb1 = (EPI == 2) ? rb + N / 2 : rb + 32;
     pa[it] = A + (ra < M ? ra : 0) * lda + ch * 8;
-    pb[it] = B + (rb < N ? rb : 0) * ldb + ch * 8;
     kla[0][it] = (ra < M) ? (int)kend - ch * 8 : INT_MIN;
     kla[1][it] = (ra + 64 < M) ? (int)kend - ch * 8 : INT_MIN;
-    klb[0][it] = (rb < N) ? (int)kend - ch * 8 : INT_MIN;
-    klb[1][it] = (rb1 < N) ? (int)kend - ch * 8 : INT_MIN;
+    if constexpr (TB) {  // instruction it of a K-half: k-rows (wave + 8 it) * 2 + (lane >> 5), 16-byte piece lane & 31 (stage_init_t)
+      const int krow = (wave + NWAVE * it) * 2 + (lane >> 5), pc = lane & 31;
+      const int lg = (pc >> 1) ^ tswz(krow);
+      const int64_t r = n0 + lg * 16 + (pc & 1) * 8;
+      pb[it] = B + (int64_t)krow * ldb + (r < N ? r : 0);
+      klb[0][it] = (r < N) ? (int)kend - krow : INT_MIN;        // (k0 + krow < kend)
+      klb[1][it] = (r < N) ? (int)kend - krow - 32 : INT_MIN;   // second K-half: k0 + 32 + krow < kend
+    } else {
+      const int64_t rb = (EPI == 2) ? n0 + lr : n0 + (lr >> 5) * 64 + (lr & 31);                // + N/2 or + 32 for h = 1
+      const int64_t rb1 = (EPI == 2) ? rb + N / 2 : rb + 32;
+      pb[it] = B + (rb < N ? rb : 0) * ldb + ch * 8;
+      klb[0][it] = (rb < N) ? (int)kend - ch * 8 : INT_MIN;
+      klb[1][it] = (rb1 < N) ? (int)kend - ch * 8 : INT_MIN;
+    }
   }
   // region s of the issue order
   auto issue = [&](int s) {
@@ -201,10 +213,11 @@ __device__ __forceinline__ void p8_main_loop(char* smem, const bf16* __restrict_
     const int k0 = (int)kbeg + t * 64;
 #pragma unroll
     for (int it = 0; it < 2; ++it) {
-      char* dst = smem + (t & 1) * P8_BUF + slot * P8_REGION + (wave * 2 + it) * 1024;
+      const int piece = (TB && isb) ? wave + NWAVE * it : wave * 2 + it;  // (k-rows 2 piece, 2 piece + 1 / rows 8 piece ..)
+      char* dst = smem + (t & 1) * P8_BUF + slot * P8_REGION + piece * 1024;
       const bf16* p = isb ? pb[it] + (h ? hoff_b : 0) : pa[it] + (h ? hoff_a : 0);
       const int kl = isb ? klb[h][it] : kla[h][it];
-      const void* src = (k0 < kl) ? (const void*)(p + k0) : zero16;
+      const void* src = (k0 < kl) ? (const void*)((TB && isb) ? p + (int64_t)k0 * ldb : p + k0) : zero16;
       glds16(src, dst);
     }
   };
@@ -227,8 +240,10 @@ __device__ __forceinline__ void p8_main_loop(char* smem, const bf16* __restrict_
 #pragma unroll
     for (int n2 = 0; n2 < 2; ++n2)
 #pragma unroll
-      for (int kb = 0; kb < 2; ++kb)
-        fw[nh][n2][kb] = *reinterpret_cast<const bf16x8*>(buf + nh * P8_REGION + n2 * 2048 + (lb0 ^ (kb << 6)));
+      for (int kb = 0; kb < 2; ++kb) {
+        if constexpr (TB) fw[nh][n2][kb] = frag<true>(buf + (2 + kb) * P8_REGION, wn * 64 + nh * 32 + n2 * 16, fi, fg);
+        else fw[nh][n2][kb] = *reinterpret_cast<const bf16x8*>(buf + nh * P8_REGION + n2 * 2048 + (lb0 ^ (kb << 6)));
+      }
   };
   auto mfma_q = [&](int mh, int nh) {
 #pragma unroll
@@ -405,7 +420,7 @@ __global__ __launch_bounds__(512, 2) void gemm_pp256_kernel(const bf16* __restri
   };
 
   if constexpr (ML >= 1) {
-    p8_main_loop<EPI, ABL>(smem, A, lda, B, ldb, M, N, m0, n0, kbeg, kend, wave, lane, zero16, acc);
+    p8_main_loop<EPI, ABL, TB>(smem, A, lda, B, ldb, M, N, m0, n0, kbeg, kend, wave, lane, zero16, acc);
     if constexpr ((ABL & 128) != 0) {  // timeline build: workgroup 0 hands its stamps to the caller (ws), then the normal epilogue
       __syncthreads();
       if (blockIdx.x == 0 && blockIdx.z == 0)
@@ -873,6 +888,8 @@ int mh_gemm_pp256_bf16(const void* A, int64_t lda, int ta, const void* B, int64_
   }
   if (ta && tb) MH_PP(true, true, 0);
   if (ta) MH_PP(true, false, 0);
+  if (tb && g_mh_gemm_k64 == 1)  // dgrad form (A row-major, B contraction-major): the K-step-64 main loop
+    return launch_one<false, true, 0, 0, 1>(A, lda, B, ldb, C, ldc, R, ldr, M, N, K, alpha, beta, splitk, workspace, st);
   if (tb) MH_PP(false, true, 0);
   if (g_mh_gemm_k64) {  // both operands row-major: the K-step-64 main loop
 #define MH_P8(ABL_) \
@@ -906,5 +923,6 @@ int mh_gemm_pp256_rope_bf16(const void* A, int64_t lda, const void* W, int64_t l
 // d gate | d up = SwiGLU'(gate|up) applied to A * B^T (A row-major [M,K], B contraction-major [K,I]); gemm.hip validates
 int mh_gemm_pp256_dswiglu_bf16(const void* A, int64_t lda, const void* B, int64_t ldb, const void* GU, int64_t ldgu,
                                void* DGU, int64_t lddgu, int64_t M, int64_t I, int64_t K, hipStream_t st) {
+  if (g_mh_gemm_k64 == 1) return launch_one<false, true, 0, 1, 1>(A, lda, B, ldb, DGU, lddgu, GU, ldgu, M, I, K, 1.f, 0.f, 1, nullptr, st);
   return launch_one<false, true, 0, 1>(A, lda, B, ldb, DGU, lddgu, GU, ldgu, M, I, K, 1.f, 0.f, 1, nullptr, st);
 }

@@ -160,15 +160,21 @@ def main_loop(request, ops):
 
 
 def test_gemm_main_loops_agree_bit_for_bit(ops):
-    """both main loops add the same 32-deep MFMA products in the same order: identical bits, ragged shapes included"""
+    """both main loops add the same 32-deep MFMA products in the same order: identical bits, ragged shapes included
+    (row-major x row-major and the dgrad form with B stored [K, N])"""
     dt = torch.bfloat16
-    for (M, N, K) in [(512, 512, 1024), (300, 520, 2048 + 72), (1000, 3406, 1024), (256, 256, 64), (257, 264, 8)]:
-        a, b = rnd((M, K), dt, 81).cuda(), rnd((N, K), dt, 82).cuda()
+    for (M, N, K, tb) in [(512, 512, 1024, False), (300, 520, 2048 + 72, False), (1000, 3406, 1024, False), (256, 256, 64, False),
+                          (257, 264, 8, False), (512, 512, 1024, True), (300, 520, 2048 + 72, True), (1000, 1024, 3406, True),
+                          (257, 264, 40, True), (640, 4096, 1024, True)]:
+        a = rnd((M, K), dt, 81).cuda()
+        if K % 8:
+            a = torch.cat([a, torch.zeros((M, 8 - K % 8), dtype=dt, device="cuda")], 1)
+        b = (rnd((K, N), dt, 82) if tb else rnd((N, K), dt, 82)).cuda()
         outs = []
         for v in (0, 1):
             ops.set_option("gemm_k64", v)
             o = torch.full((M, N), float("nan"), dtype=dt, device="cuda")
-            ops.gemm_nt(a, b, o, splitk=1)
+            ops.gemm_nt(a, b, o, K=K, tb=tb, splitk=1)
             outs.append(o)
         ops.set_option("gemm_k64", 1)
         for o in outs[1:]:
@@ -219,7 +225,7 @@ def test_gemm_rope(ops, main_loop, B, S, H, K):
 
 
 @pytest.mark.parametrize("M,I,K", [(256, 256, 64), (300, 520, 1024), (1000, 4096, 1024), (77, 1024, 264)])
-def test_gemm_dswiglu(ops, M, I, K):
+def test_gemm_dswiglu(ops, main_loop, M, I, K):
     """down_proj dgrad with the SwiGLU backward as its epilogue == mh_gemm followed by mh_swiglu_bwd"""
     dt = torch.bfloat16
     dx, wd, gu = rnd((M, K), dt, 61, 0.5), rnd((K, I), dt, 62, 0.5), rnd((M, 2 * I), dt, 63, 2.0)
