@@ -416,6 +416,28 @@ extern "C" int mh_kv_store_prefill(const void* qkv, void* kcache, void* vcache, 
   return MH_OK;
 }
 
+// sum over the aligned group of LPK (8, 16, 32 or 64) consecutive lanes, every lane of the group gets it: DPP moves inside a
+// 16-lane row, permlane swaps across rows (common.h, wave_sum_fast) -- the additions a shuffle-xor butterfly performs, without LDS
+template <int LPK>
+__device__ inline float group_sum(float v) {
+  static_assert(LPK == 8 || LPK == 16 || LPK == 32 || LPK == 64, "group_sum: 8, 16, 32 or 64 lanes");
+  v += dpp_move<0xB1>(v);   // quad_perm(1,0,3,2)
+  v += dpp_move<0x4E>(v);   // quad_perm(2,3,0,1)
+  v += dpp_move<0x141>(v);  // row_half_mirror
+  if (LPK >= 16) v += dpp_move<0x140>(v);  // row_mirror
+  if (LPK >= 32) {
+    const int iv = __float_as_int(v);
+    auto a = __builtin_amdgcn_permlane16_swap(iv, iv, false, false);
+    v = __int_as_float(a[0]) + __int_as_float(a[1]);
+  }
+  if (LPK >= 64) {
+    const int iw = __float_as_int(v);
+    auto b = __builtin_amdgcn_permlane32_swap(iw, iw, false, false);
+    v = __int_as_float(b[0]) + __int_as_float(b[1]);
+  }
+  return v;
+}
+
 // One block (4 waves) per (b,h).  LPK lanes cover one cached key row with 16-byte loads; every lane group
 // keeps an online-softmax state over its own subset of keys, merged at the end (groups, then waves).
 // APPEND: qkv holds the UNROTATED q,k,v of the new position; the block first rotates k and stores the k,v rows at index
@@ -479,13 +501,18 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(const T* __restrict__ 
   const T* kb = kc + bh * Lmax * HD;
   const T* vb = vc + bh * Lmax * HD;
   // four steps of the key loop at a time with all K / V rows requested first: one step per memory round trip was one
-  // round trip per 32 keys of head_dim 64 (13 us per layer at 128 cached events, r02 trace)
+  // round trip per 32 keys of head_dim 64 (13 us per layer at 128 cached events, r02 trace).  r03: the NEXT four steps are
+  // requested before the current four are reduced (two register sets, 16 row loads per lane in flight): at batch 64 x 1024
+  // events the kernel moved 1.6 GB per generated event at 4.6 TB/s with the loads of an iteration waiting behind its
+  // arithmetic (profiles/r03_run1_*); and the per-key sum over the LPK lanes of a row runs on DPP / permlane moves (group_sum)
+  // instead of three to five dependent ds_bpermute round trips (same additions in the same order: identical bits).
   constexpr int UNR = 4;
+  constexpr int STEP = 4 * KPW * UNR;
   const int ilen = (int)len;                 // (<= Lmax < 2^24: 32-bit key indices and element offsets from the uniform bases)
   const int lane_off = ch * N;
-  for (int j0 = wv * KPW; j0 < ilen; j0 += 4 * KPW * UNR) {
-    Pack<T> kv[UNR], vv[UNR];
-    bool ok[UNR];
+  Pack<T> kvA[UNR], vvA[UNR], kvB[UNR], vvB[UNR];
+  bool okA[UNR], okB[UNR];
+  auto request = [&](Pack<T> (&kv)[UNR], Pack<T> (&vv)[UNR], bool (&ok)[UNR], int j0) {
 #pragma unroll
     for (int u = 0; u < UNR; ++u) {
       const int j = j0 + u * 4 * KPW + grp;
@@ -494,16 +521,14 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(const T* __restrict__ 
       kv[u] = ld16(kb + off);
       vv[u] = ld16(vb + off);
     }
-    // all 2 UNR row loads are requested before the first dot product: without this fence hipcc started the arithmetic of
-    // the first row right behind its load and waited vmcnt(0) for it BEFORE issuing the other seven (r02 ISA)
-    __builtin_amdgcn_sched_barrier(0);
+  };
+  auto reduce = [&](const Pack<T> (&kv)[UNR], const Pack<T> (&vv)[UNR], const bool (&ok)[UNR]) {
 #pragma unroll
     for (int u = 0; u < UNR; ++u) {
       float s = 0.f;
 #pragma unroll
       for (int e = 0; e < N; ++e) s += q[e] * kv[u].get(e);
-#pragma unroll
-      for (int x = 1; x < LPK; x <<= 1) s += __shfl_xor(s, x, 64);
+      s = group_sum<LPK>(s);
       if (ok[u]) {
         const float nm = fmaxf(m, s);
         const float a = __expf(m - nm), p = __expf(s - nm);
@@ -512,6 +537,24 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(const T* __restrict__ 
         for (int e = 0; e < N; ++e) acc[e] = acc[e] * a + p * vv[u].get(e);
         m = nm;
       }
+    }
+  };
+  int j0 = wv * KPW;
+  if (j0 < ilen) {
+    request(kvA, vvA, okA, j0);
+    while (true) {
+      const int j1 = j0 + STEP;
+      if (j1 < ilen) request(kvB, vvB, okB, j1);
+      // (the requests above are issued before the first dot product below: without the fence hipcc starts the arithmetic of
+      //  the first row right behind its load and waits vmcnt(0) for it BEFORE issuing the others -- r02 ISA)
+      __builtin_amdgcn_sched_barrier(0);
+      reduce(kvA, vvA, okA);
+      if (j1 >= ilen) break;
+      j0 = j1 + STEP;
+      if (j0 < ilen) request(kvA, vvA, okA, j0);
+      __builtin_amdgcn_sched_barrier(0);
+      reduce(kvB, vvB, okB);
+      if (j0 >= ilen) break;
     }
   }
   // merge the KPW lane groups of the wave (lanes with equal `ch`)

@@ -358,6 +358,7 @@ extern "C" int mh_gemm_rope(const void* A, int64_t lda, const void* W, int64_t l
   MH_REQUIRE(M > 0 && K > 0 && N > 0 && N % 192 == 0 && head_dim == 64,
              "gemm_rope: bad shape M=%ld N=%ld K=%ld head_dim=%d (N = 3 * heads * 64)", (long)M, (long)N, (long)K, head_dim);
   MH_REQUIRE(S > 0 && pos0 >= 0 && pos0 + (S < M ? S : M) <= npos && npos < (int64_t(1) << 31), "gemm_rope: table too short");
+  MH_REQUIRE(S < (int64_t(1) << 31), "gemm_rope: S = %ld does not fit the 32 bits it travels in", (long)S);
   MH_REQUIRE(lda % 8 == 0 && ldw % 8 == 0 && ldc % 8 == 0 && lda >= K && ldw >= K && ldc >= N,
              "gemm_rope: leading dimensions must be multiples of 8 elements and cover the rows");
   MH_REQUIRE((((uintptr_t)A | (uintptr_t)W | (uintptr_t)C | (uintptr_t)table) & 15) == 0, "gemm_rope: 16-byte alignment");

@@ -35,7 +35,7 @@ namespace {
 // workgroup -- blockIdx.y picks the group of MB row blocks, so MB = 1 puts a 64-row step on 4x the workgroups, each reading a
 // quarter of the activation rows (the four workgroups of a column block get consecutive blockIdx.x-major ids b, b + gridDim.x,
 // ... : on the same XCD when gridDim.x is a multiple of 8, so the weight slab they share is fetched from HBM once).
-// BCH: chunks per wave that are requested in ONE batch (the host picks the largest of 8 / 4 / 2 / 1 dividing the wave's
+// BCH: chunks per wave that are requested in ONE batch (the host picks the largest of 8 / 4 / 1 dividing the wave's
 // chunk count).  r02 ISA of the first form: the chunk loop was rolled -- load W, load X, s_waitcnt vmcnt(0), MFMA, branch --
 // i.e. one memory round trip per 32-deep chunk and wave (4 in a row at K = 1024); the kernel arguments were fetched by six
 // separate s_load + wait pairs sunk into the blocks that use them; and the residual "prefetch" was converted to fp32 at once,
@@ -52,6 +52,10 @@ __global__ __launch_bounds__(NW * 64) void gemm_skinny_kernel(const bf16* __rest
   constexpr int MR = MB * 16;  // rows of this workgroup
   __shared__ float red[NW][MR][NB + 1];
   __shared__ float ssq[RSTD ? NW : 1][MR];
+  // (8 waves x 64 rows x 32 columns, the largest form instantiated, is 69.6 KiB: more than the 64 KiB every other CDNA part
+  // gives a workgroup, two workgroups per CU on gfx950 -- the only target; anything larger is a mistake in the launcher's table)
+  static_assert(sizeof(float) * NW * MR * (NB + 1) + sizeof(float) * (RSTD ? NW : 1) * MR <= 72 * 1024,
+                "gemm_skinny: static LDS of this form exceeds what the launcher's tilings were sized for");
   // all kernel arguments in one batch of scalar loads at entry (hipcc otherwise sinks each s_load into the block that first
   // uses it: a scalar-cache miss and a wait per block)
   asm volatile("" ::"s"(A), "s"(lda), "s"(W), "s"(ldw), "s"(C), "s"(ldc), "s"(R), "s"(ldr));

@@ -285,11 +285,17 @@ class DecodeSession:
         self.kv1.len += 1
 
     def tok_step(self, i: int) -> None:
-        """sample token position i of the current event into seq[:, i] (and ev for i == 0) -- the step-by-step form"""
+        """sample token position i of the current event into seq[:, i] (and ev for i == 0) -- the step-by-step form.
+        With the fused sampler the step READS the event's Exp(1) variates instead of drawing them: they come from
+        draw_noise() (called here for position 0 when the caller has not done so -- without it the step would sample against
+        stale variates and leave the generator where it was), and the caller reports the draws the reference loop would have
+        made with consumed(n_steps) once the event is complete (sample_event() does both)."""
         if self.use_graphs:
             if self.g_tok[i] is None:
                 with _CAPTURE_LOCK:
                     self._capture_step(i)
+            if self.g_noise is not None and not self._noise_pending and i == 0:
+                self.draw_noise()
             if self.g_noise is not None and self._noise_pending:
                 torch.cuda.current_stream().wait_event(self.noise_done)
             self.g_tok[i].replay()

@@ -465,6 +465,24 @@ class MIDIModel(nn.Module):
         cur_len = inp.shape[1]
         if cur_len >= max_len:
             return
+        # Every grammar mask must keep at least one id.  The reference fails with a (recoverable) multinomial error when a
+        # mask is empty (midi_model.py:152-165 on an all-zero row); the fused sampler has no such path -- it would hand a
+        # sentinel id to the next embedding lookup, which traps -- so an emptied mask is refused here, before any launch.
+        first_ids = {tok.eos_id, *tok.event_ids.values()}
+        if ban_eos:
+            first_ids.discard(tok.eos_id)
+        if disable_patch_change:
+            first_ids.discard(tok.event_ids["patch_change"])
+        if disable_control_change:
+            first_ids.discard(tok.event_ids["control_change"])
+        if not first_ids:
+            raise ValueError("generate: the options leave no legal event id at token position 0")
+        chans = sorted(set(int(c) for c in (disable_channels or [])))
+        n_chan = len(tok.parameter_ids["channel"])
+        if any(c < 0 or c >= n_chan for c in chans):
+            raise ValueError(f"generate: disable_channels holds a channel outside [0, {n_chan}): {chans}")
+        if len(chans) >= n_chan:
+            raise ValueError("generate: disable_channels bans every channel id: no legal token is left at the channel position")
         with torch.inference_mode():
             ses = self._checkout_session(B, max(max_len, cur_len) + 1, float(temp), float(top_p), int(top_k))
         try:
@@ -477,7 +495,7 @@ class MIDIModel(nn.Module):
                 if disable_control_change:
                     ses.first_mask[tok.event_ids["control_change"]] = 0
                 ses.ban.zero_()
-                for c in (disable_channels or []):
+                for c in chans:
                     ses.ban[tok.parameter_ids["channel"][c]] = 1
                 ses.reset()
                 ses.begin(generator)
@@ -555,11 +573,20 @@ class MIDIModel(nn.Module):
         if "state_dict" in state and not torch.is_tensor(state["state_dict"]):
             state = state["state_dict"]
         own = set(self.state_dict().keys())
-        for prefix in ("", "model.", "base_model.model.", "module.", "_orig_mod."):
-            if prefix and all(k.startswith(prefix) for k in state):
-                state = {k[len(prefix):]: v for k, v in state.items()}
+        # wrapper prefixes in any order and nesting (torch.compile's _orig_mod., DDP's module., Lightning's model., peft's
+        # base_model.model.): stripped, one at a time, until none covers every key or the keys are ours
+        prefixes = ("model.", "base_model.model.", "module.", "_orig_mod.")
+        for _ in range(8):
             if own & set(state):
                 break
+            hit = next((p for p in prefixes if state and all(k.startswith(p) for k in state)), None)
+            if hit is None:
+                break
+            state = {k[len(hit):]: v for k, v in state.items()}
+        if any(".base_layer." in k or ".lora_A." in k or ".lora_B." in k for k in state):
+            raise RuntimeError("this checkpoint holds peft-wrapped modules (base_layer / lora_A / lora_B keys): load the base weights "
+                               "with load_checkpoint_state and the adapter with MIDIModel.load_merge_lora(adapter_dir), or merge "
+                               "the adapter before saving (merge_and_unload)")
         state = {k: v for k, v in state.items() if not k.endswith(self._BENIGN_EXTRA)}
         res = self.load_state_dict(state, strict=False)
         if res.missing_keys or res.unexpected_keys:
@@ -573,10 +600,21 @@ class MIDIModel(nn.Module):
         """app.py:304-316: a Lightning ``.ckpt`` (torch pickle with ``state_dict``) or a ``.safetensors`` file next to a
         config given by name / object."""
         cfg = config if isinstance(config, MIDIModelConfig) else MIDIModelConfig.from_name(config)
+        trust = bool(kwargs.pop("trust_checkpoint", False))
         model = cls(cfg, **kwargs)
         if path.endswith(".safetensors"):
             from safetensors.torch import load_file
             state = load_file(path)
         else:
-            state = torch.load(path, map_location="cpu", weights_only=True)
+            import pickle
+            try:
+                state = torch.load(path, map_location="cpu", weights_only=True)
+            except pickle.UnpicklingError as e:
+                # the reference calls plain torch.load (app.py:314), which executes whatever the pickle names; a Lightning
+                # .ckpt with callback / hyper-parameter objects outside torch's allow-list lands here
+                if not trust and os.environ.get("MH_TRUST_CHECKPOINT", "0") != "1":
+                    raise RuntimeError(f"{path} holds pickled objects beyond tensors ({e}); re-save its state_dict alone, or pass "
+                                       "from_checkpoint(..., trust_checkpoint=True) / MH_TRUST_CHECKPOINT=1 to unpickle it as the "
+                                       "reference does (only for files you trust)") from e
+                state = torch.load(path, map_location="cpu", weights_only=False)
         return model.load_checkpoint_state(state)

@@ -198,5 +198,10 @@ class MIDITokenizer:
             for attr in ("vocab_size", "max_token_seq", "pad_id", "bos_id", "eos_id", "event_ids", "events"):
                 if getattr(tok, attr) != getattr(mine, attr):
                     raise RuntimeError(f"the importable midi_tokenizer disagrees with the {version} vocabulary on {attr}")
+            # the id ranges the device-side grammar masks are built from, and the id -> event-name map of the break rule
+            if {k: list(v) for k, v in tok.parameter_ids.items()} != mine.parameter_ids:
+                raise RuntimeError(f"the importable midi_tokenizer disagrees with the {version} vocabulary on parameter_ids")
+            if dict(tok.id_events) != dict(mine.id_events):
+                raise RuntimeError(f"the importable midi_tokenizer disagrees with the {version} vocabulary on id_events")
             return tok
         return MIDITokenizerV1() if version == "v1" else MIDITokenizerV2()

@@ -414,6 +414,11 @@ def test_serving_loop_masks_and_crop_match_oracle_seeded(orc, tiny, tok):
         assert not np.isin(want[:, 4:, 0], [tok.event_ids["patch_change"], tok.event_ids["control_change"]]).any()
         with pytest.raises(ValueError, match="outside"):
             model.generate(np.full((2, 8), tok.vocab_size, dtype=np.int64), batch_size=1, max_len=4)
+        # a mask emptied by the options is refused before any launch (the reference fails inside multinomial there)
+        with pytest.raises(ValueError, match="every channel"):
+            model.generate(prompt, batch_size=1, max_len=6, disable_channels=list(range(16)))
+        with pytest.raises(ValueError, match="outside"):
+            model.generate(prompt, batch_size=1, max_len=6, disable_channels=[16])
 
 
 def test_reference_serving_loop_on_the_drop_in_with_real_dynamic_cache(orc, tiny, tok):
@@ -475,6 +480,28 @@ def test_checkpoint_forms_load_strictly(orc, tiny, tmp_path):
     save_file({**state, "net.layers.0.extra.weight": torch.ones(3)}, str(tmp_path / "e.safetensors"))
     with pytest.raises(RuntimeError, match="unexpected"):
         mm.MIDIModel.from_checkpoint(tiny_config(), str(tmp_path / "e.safetensors"))
+    # wrapper prefixes in either nesting order (torch.compile inside DDP and the reverse)
+    for i, pre in enumerate(("module._orig_mod.", "_orig_mod.module.", "model._orig_mod.module.")):
+        save_file({pre + k: v for k, v in state.items()}, str(tmp_path / f"f{i}.safetensors"))
+        m = mm.MIDIModel.from_checkpoint(tiny_config(), str(tmp_path / f"f{i}.safetensors"))
+        assert torch.equal(m._flat, model._flat), pre
+    # peft-wrapped keys are named for what they are
+    wrapped = {k.replace("q_proj.weight", "q_proj.base_layer.weight"): v for k, v in state.items()}
+    wrapped["net.layers.0.self_attn.q_proj.lora_A.default.weight"] = torch.ones(4, 4)
+    save_file(wrapped, str(tmp_path / "g.safetensors"))
+    with pytest.raises(RuntimeError, match="peft-wrapped"):
+        mm.MIDIModel.from_checkpoint(tiny_config(), str(tmp_path / "g.safetensors"))
+    # a pickle that is more than tensors: a clear refusal, and the reference's behaviour on request
+
+    torch.save({"state_dict": state, "callbacks": {"x": _Opaque()}}, str(tmp_path / "h.ckpt"))
+    with pytest.raises(RuntimeError, match="trust_checkpoint"):
+        mm.MIDIModel.from_checkpoint(tiny_config(), str(tmp_path / "h.ckpt"))
+    m = mm.MIDIModel.from_checkpoint(tiny_config(), str(tmp_path / "h.ckpt"), trust_checkpoint=True)
+    assert torch.equal(m._flat, model._flat)
+
+
+class _Opaque:  # (module level: picklable by reference, not on torch.load's allow-list)
+    pass
 
 
 def test_gen_example_and_save_peft_surface(tiny, golden, tmp_path):
