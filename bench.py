@@ -246,13 +246,29 @@ def summarize_launches(prof, wall_s: float, steps: int):
     return out, by_name
 
 
-def pmc_traffic():
-    """memory-side bytes per gemm_pp256 launch from the newest committed rocprofv3 PMC pass (tools/gpu_pmc_bench.sh ->
-    tools/pmc_to_json.py); counters need their own rocprofv3 runs, so the bench line cites the file it read"""
+def summarize_allreduce(windows, steps: int, exposed_ms=()):
+    """windows: (bytes, launches) of every gradient exchange inside the timed region -- ONE per optimiser step, i.e. per
+    accumulation window of `accumulate_grad_batches` timed steps (micro-batches; DDP no_sync inside a window).  Per optimiser
+    step the payload is the whole flat gradient buffer (467,685,376 B for tv2o-medium in bf16); per timed step it is that
+    divided by the window length."""
+    n = len(windows)
+    total = sum(b for b, _ in windows)
+    return {"allreduce_windows": n,
+            "allreduce_bytes_per_optimizer_step": (total / n) if n else 0,
+            "allreduce_bytes_per_step": total / max(1, steps),
+            "allreduce_launches_per_optimizer_step": (sum(l for _, l in windows) / n) if n else 0,
+            "allreduce_exposed_ms_per_optimizer_step": (sum(exposed_ms) / len(exposed_ms)) if exposed_ms else None,
+            "allreduce_exposed_ms_per_step": (sum(exposed_ms) / max(1, steps)) if exposed_ms else None}
+
+
+def pmc_traffic(kind: str = "gemm"):
+    """memory-side bytes per gemm_pp256 launch (kind "gemm", tools/gpu_pmc_bench.sh) or per generated event (kind "generate",
+    tools/gpu_decode_profile.sh) from the newest committed rocprofv3 PMC pass; counters need their own rocprofv3 runs, so the
+    bench line cites the file it read"""
     def run_key(path):  # r02_run23_... -> (2, 23): newest by round and run number, not by string order
         m = re.match(r"r(\d+)_run(\d+)_", os.path.basename(path))
         return (int(m.group(1)), int(m.group(2))) if m else (-1, -1)
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_gemm_traffic.json")), key=run_key)
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", f"r*_pmc_{kind}_traffic.json")), key=run_key)
     if not files:
         return None, None
     try:
@@ -359,6 +375,8 @@ def measure_generate(args, world: int, rank: int, dist, steps: int, warmup: int)
     nodes = getattr(ses, "nodes_per_event", None)
     del model
     torch.cuda.empty_cache()
+    pmc, pmc_src = pmc_traffic("generate")
+    pmc_ok = pmc is not None and (B, n_new) == (64, 1024)  # (the committed pass is of THIS workload; other shapes get none)
     return {
         "metric": f"MIDI events/sec, KV-cached generate(), {args.config}", "value": world * B * n_new * steps / dt, "unit": "events/s",
         "ms_per_step": 1e3 * dt / steps, "steps": steps, "warmup": warmup,
@@ -370,7 +388,11 @@ def measure_generate(args, world: int, rank: int, dist, steps: int, warmup: int)
                    "graph_nodes_per_event": nodes},
         "roofline": {"bound": "hbm", "kernel": "decode step (weights + K/V cache streamed once per event / token step)",
                      "achieved": by / per_event_s / 1e9, "peak": PEAK_HBM_GBS, "unit": "GB/s",
-                     "frac": by / per_event_s / (PEAK_HBM_GBS * 1e9), "traffic": None, "algorithmic_bytes_per_event_step": by},
+                     "frac": by / per_event_s / (PEAK_HBM_GBS * 1e9),
+                     "traffic": pmc["bytes_per_event_step"] if pmc_ok else None, "traffic_source": pmc_src if pmc_ok else None,
+                     "traffic_detail": ({k: v for k, v in pmc.items() if k not in ("bytes_per_event_step", "top_readers_bytes_per_event")}
+                                        if pmc_ok else None),
+                     "algorithmic_bytes_per_event_step": by},
     }
 
 
@@ -490,6 +512,11 @@ def main():
     ops.gemm_profile = None
     loss_v = float(loss.item())
     red = model._reducer
+    # the same K steps once more WITHOUT the HIP events around the GEMM launches (what the instrumentation of the timed
+    # region costs is visible in the line: value_no_gemm_events beside value)
+    dt_plain = None
+    if not args.no_gemm_events:
+        dt_plain, _ = timed(step, args.steps, dist, torch.cuda.synchronize)
     # kernel-family shares: events around EVERY C-ABI launch cost ~2 % of the step (the host falls behind on the short
     # kernels), so they are taken over two extra steps AFTER the timed region and normalised by those steps' own wall time
     launches, fam_steps, fam_dt = None, 2, None
@@ -518,15 +545,15 @@ def main():
                        "optimizer": "AdamW bf16-true + global-norm clip 1.0" if args.dtype == "bf16" else "AdamW fp32 + clip"},
             "comm": comm_info(world, dist),
             "loss": loss_v,
+            "value_no_gemm_events": (events / dt_plain) if dt_plain else None,
+            "ms_per_step_no_gemm_events": (1e3 * dt_plain / args.steps) if dt_plain else None,
             "model_tflops_per_gpu": fl_event * B * S * args.steps / dt / 1e12,
             "model_flops_frac_of_peak": fl_event * B * S * args.steps / dt / 1e12 / PEAK_BF16_TFLOPS,
         }
         if world > 1:
             st = red.stats if red is not None else []
             exposed = [a.elapsed_time(b) for a, b, _, _ in st if a is not None]
-            out["allreduce_bytes_per_step"] = (sum(x[2] for x in st) / max(1, len(st))) if st else 0
-            out["allreduce_launches_per_step"] = (sum(x[3] for x in st) / max(1, len(st))) if st else 0
-            out["allreduce_exposed_ms_per_step"] = (sum(exposed) / len(exposed)) if exposed else None
+            out.update(summarize_allreduce([(x[2], x[3]) for x in st], args.steps, exposed))
         if prof:
             ms = sum(e0.elapsed_time(e1) for e0, e1, _, _ in prof)
             fl = sum(f for _, _, f, _ in prof)
@@ -582,6 +609,12 @@ def main():
                 out[key] = fn()
             except Exception as e:  # an extra must never cost the headline number
                 out[key] = {"error": repr(e)}
+        if rank == 0 and not args.no_cpu_baseline and isinstance(out.get("generate"), dict) and "error" not in out["generate"]:
+            try:  # the CPU oracle's generate() beside the GPU number (bounded sample: batch 64 x 8 events)
+                out["generate"]["cpu_baseline"] = cpu_baseline_generate(args.gen_batch, 8)
+            except Exception as e:
+                out["generate"]["cpu_baseline"] = {"value": None, "unit": "events/s", "cores": os.cpu_count(), "kind": "port",
+                                                   "sample": f"failed: {e!r}"}
     if rank == 0:
         if world == 1 and not args.no_cpu_baseline:
             try:

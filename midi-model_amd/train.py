@@ -98,6 +98,15 @@ class GradReducer:
         if self.pending is not None:
             self._launch(*self.pending)
             self.pending = None
+        if self.launched:
+            # every element of the flat gradient buffer goes out exactly once per accumulation window: the ranges announced by
+            # the backward (lm_head, token-level layers and embedding, event-level layers and embedding, norm vectors) tile it
+            cover = sorted(self.launched)
+            ok = cover[0][0] == 0 and cover[-1][1] == self.flat.numel() and all(a[1] == b[0] for a, b in zip(cover, cover[1:]))
+            if not ok:
+                gaps = [(a[1], b[0]) for a, b in zip(cover, cover[1:]) if a[1] != b[0]]
+                raise RuntimeError(f"GradReducer: the launched ranges do not tile the gradient buffer [0, {self.flat.numel()}): "
+                                   f"first {cover[0]}, last {cover[-1]}, seams {gaps[:4]}")
         ev = None
         if self.profile and self.comm_stream is not None:
             ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))

@@ -162,3 +162,32 @@ def test_bench_spawns_its_own_ranks(tmp_path):
         r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2"], capture_output=True, text=True, env=env,
                            timeout=120)
         assert r.returncode != 0 and "refusing" in r.stderr
+
+
+def test_bench_allreduce_summary_semantics():
+    """bench.py's `allreduce_*` keys under --accumulate 2: the reducer reports one exchange per optimiser step (the whole flat
+    gradient buffer, 467,685,376 B for tv2o-medium in bf16), i.e. one per TWO timed steps; per timed step that is half."""
+    import importlib.util
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(root, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    flat = 467_685_376
+    d = bench.summarize_allreduce([(flat, 15), (flat, 15), (flat, 15)], steps=6, exposed_ms=[0.5, 0.7, 0.6])
+    assert d["allreduce_windows"] == 3 and d["allreduce_bytes_per_optimizer_step"] == flat
+    assert d["allreduce_bytes_per_step"] == flat / 2 and d["allreduce_launches_per_optimizer_step"] == 15
+    assert abs(d["allreduce_exposed_ms_per_optimizer_step"] - 0.6) < 1e-9 and abs(d["allreduce_exposed_ms_per_step"] - 0.3) < 1e-9
+    d = bench.summarize_allreduce([(flat, 15)] * 5, steps=5)  # --accumulate 1 (the headline): one exchange per step
+    assert d["allreduce_bytes_per_step"] == flat and d["allreduce_exposed_ms_per_step"] is None
+
+
+def test_grad_reducer_refuses_an_untiled_buffer():
+    """finish() checks that the ranges launched in a window tile the flat gradient buffer exactly once"""
+    from midi_model_amd.train import GradReducer
+    r = GradReducer(torch.zeros(100), None, bucket_bytes=1 << 20)
+    r.world = 2                      # (no process group here: exercise the bookkeeping only)
+    r._launch = lambda lo, hi: r.launched.append((lo, hi))
+    r.ready(60, 100)
+    r.ready(0, 50)                   # [50, 60) never announced
+    with pytest.raises(RuntimeError, match="do not tile"):
+        r.finish()
