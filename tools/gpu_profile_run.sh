@@ -18,6 +18,13 @@ cp $(find /tmp/prof_$T -name "*kernel_stats.csv" | head -1) $O/${T}_rocprofv3_ke
 bash tools/gpu_pmc_bench.sh > /dev/null 2>&1
 cp $O/pmc_bench_traffic.txt $O/${T}_pmc_training_step_traffic_by_kernel.txt; cp $O/pmc_gemm_traffic.json $O/${T}_pmc_gemm_traffic.json
 timeout 300 python tools/bench_attn_forms.py > $O/${T}_attn_forms_ab.txt 2>&1
+# the north_star block line with its own rocprofv3 kernel stats; the other configurations of SURVEY.md 8(d); the vendor library
+timeout 300 python bench.py --mode block > $O/${T}_block_bench.json 2>/dev/null
+(cd /tmp && rm -rf /tmp/profb_$T && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/profb_$T -o block -- python $R/bench.py --mode block > /dev/null 2>&1)
+cp $(find /tmp/profb_$T -name "*kernel_stats.csv" | head -1) $O/${T}_block_rocprofv3_kernel_stats.csv 2>/dev/null
+timeout 600 python bench.py --config tv2o-large --seq 4096 --batch 4 --steps 3 --warmup 1 --no-cpu-baseline --no-extras > $O/${T}_tv2o_large_seq4096_bench.json 2>/dev/null
+timeout 600 python tools/check_big_config.py > $O/${T}_two_times_hidden_config.txt 2>&1
+timeout 300 python tools/bench_hipblaslt_torch.py > $O/${T}_hipblaslt_same_gpu.txt 2>&1
 python - <<PY
 import json
 d=json.loads(open("$O/${T}_bench.json").read().strip().splitlines()[-1]); a=d['attention']; b=d.get('block',{}); g=d.get('generate',{})
