@@ -31,9 +31,13 @@ extern "C" {
 
 const char* mh_last_error(void);
 int mh_version(void);
-/* runtime options: "gemm" = 1 (production bf16 kernel: 256x256 tile, ping-pong wave groups) | 0 (128x128 two-stage
- * kernel, the independent check); "gemm_ablate" = micro-benchmark builds of the production kernel (wrong results);
- * "skinny_mb" = 16-row activation blocks per workgroup of mh_gemm_skinny (1 | 2 | 4; 0 = default). */
+/* runtime options (A/B runs and tests; every default is the production path; mh_get_option returns -1 for an unknown name):
+ * "gemm" = 1 (production bf16 kernel: 256x256 tile, ping-pong wave groups) | 0 (128x128 two-stage kernel, the independent
+ * check); "gemm_k64" = 1 (products with a row-major A operand -- forward projections, dgrads -- run the K-step-64 main loop
+ * with whole-line LDS-DMA) | 2 (only row-major x row-major) | 0 (the K-step-32 loop everywhere; identical bits);
+ * "gemm_ablate" = micro-benchmark / timeline builds of the production kernel (wrong results);
+ * "skinny_mb" / "skinny_nbt" = 16-row activation blocks / 16-column blocks per workgroup of mh_gemm_skinny (0 = default);
+ * "attn_v3" / "attn_v3_wps" = forms of the event-level attention kernels (attention_mfma3.hip). */
 int mh_set_option(const char* name, int value);
 int mh_get_option(const char* name);
 
