@@ -129,7 +129,7 @@ __device__ inline bf16x8 frag(const char* tile, int row0, int fi, int fg) {
 // four phases of 16 MFMAs per K-tile with the read wait at the head of the MFMA slot 1280-1350 (the guide's 8-phase shape: the
 // LDS latency sits in front of every MFMA slot and twice the barriers), the same with the wait in the load slot and one
 // region more lookahead 1330-1343, THIS schedule 1380-1436, its LDS-DMA issued at the tail of the MFMA slot instead 1180, one
-// region per wave in every slot (load and MFMA slots alike) 1230-1250: whatever lengthens the MFMA slot is paid in full; ONE
+// region per wave in every slot (load and MFMA slots alike; MFMA-slot group issuing last 1230-1250, first 1260-1340): whatever lengthens the MFMA slot is paid in full; ONE
 // barrier per phase (LDS-safe: a phase's regions have landed before its interval opens and both groups' reads are complete when
 // it closes; the groups then alternate by program order only) 1320-1330: they drift into reading and issuing at the same time;
 // LDS-DMA ahead of the reads in the load slot: +-0.  In-kernel s_memtime timeline of this schedule (all eight waves, same file):
