@@ -552,3 +552,30 @@ def test_tv2o_large_forward_against_oracle(orc, tok):
     top2 = log_o.topk(2, -1).values
     safe = (top2[..., 0] - top2[..., 1]) > 1e-3
     assert (logits.argmax(-1)[safe] == log_o.argmax(-1)[safe]).all()
+
+
+# ------------------------------------------------------------------------------ race screen of the K-step-64 main loop (r03)
+@pytest.mark.parametrize("M,N,K,tb", [(32768, 3072, 1024, False), (65536, 1024, 4096, False), (32768, 8192, 1024, False),
+                                      (32768, 3406, 1024, False), (32768, 1024, 8192, True), (32768, 1024, 3406, True),
+                                      (262144, 1024, 3072, True)],
+                         ids=["qkv", "down_S4096", "gate_up", "lm_head", "dgrad_gate_up", "dgrad_lm_head", "dgrad_token_qkv"])
+def test_k64_main_loop_is_bit_identical_to_k32_at_benchmarked_shapes(M, N, K, tb):
+    """The K-step-64 loop refills parts of an LDS buffer while other parts are being read (counted vmcnt waits, one phase of
+    distance): a misplaced wait would show as rare wrong tiles that come and go with timing.  Both loops add the same 32-deep
+    MFMA products in the same order, so their outputs must be IDENTICAL -- at the benchmarked shapes, with every CU busy, three
+    launches each (different operands), every element compared."""
+    from midi_model_amd import ops
+    for rep in range(3):
+        a = _bf16_exact((M, K + (-K) % 8), 70 + rep).cuda()
+        if K % 8:
+            a[:, K:] = 0
+        b = _bf16_exact((K, N + (-N) % 64) if tb else (N, K + (-K) % 8), 80 + rep, 0.05).cuda()
+        outs = []
+        for k64 in (0, 1):
+            ops.set_option("gemm_k64", k64)
+            o = torch.full((M, N + (-N) % 64), float("nan"), dtype=torch.bfloat16, device="cuda")[:, :N]
+            ops.gemm_nt(a, b, o, K=K, tb=tb, splitk=1)
+            outs.append(o)
+        ops.set_option("gemm_k64", 1)
+        same = torch.equal(outs[0], outs[1])
+        assert same, (M, N, K, tb, rep, int((outs[0] != outs[1]).sum()), (outs[0].float() - outs[1].float()).abs().max().item())
