@@ -16,6 +16,9 @@
 //   * 64-byte-row LDS layout: chunk c of row r sits at r*64 + ((c ^ X[(r>>2)&3]) << 4), X = {0,3,2,1}: the four
 //     16-lane groups of a ds_read_b128 fragment read (rows i, chunk g) each hit 16 distinct 16-byte slots of the
 //     256-byte bank row; contraction-major operands keep the 32-byte-granule swizzle and ds_read_b64_tr_b16.
+// r03: products whose A operand is row-major (every forward projection, every dgrad) run the SECOND main loop further down
+// (K-step 64, whole 128-byte lines per LDS-DMA piece, partial buffer re-fill); the loop described above still serves the weight
+// gradients (both operands contraction-major: their 512-byte k-rows were whole lines all along) and option "gemm_k64" = 0.
 // Roofline: MFMA, 2.5 PFLOP/s dense bf16.
 #include <limits.h>
 
