@@ -135,7 +135,8 @@ __device__ inline bf16x8 frag(const char* tile, int row0, int fi, int fg) {
 // region per wave in every slot (load and MFMA slots alike; MFMA-slot group issuing last 1230-1250, first 1260-1340): whatever lengthens the MFMA slot is paid in full; ONE
 // barrier per phase (LDS-safe: a phase's regions have landed before its interval opens and both groups' reads are complete when
 // it closes; the groups then alternate by program order only) 1320-1330: they drift into reading and issuing at the same time;
-// LDS-DMA ahead of the reads in the load slot, or interleaved with them: +-0.  In-kernel s_memtime timeline of this schedule (all eight waves, same file):
+// LDS-DMA ahead of the reads in the load slot, or interleaved with them: +-0 (in the build without stamps the two overlap anyway);
+// the next phase's fragment reads at the tail of the MFMA slot: +-0 alone, 8-10 % slower inside the block benchmark.  In-kernel s_memtime timeline of this schedule (all eight waves, same file):
 // a load slot is 16 reads complete after ~400 cycles + the issue of 2 / 6 LDS-DMA instructions 300 / 600 (the L1 path takes a
 // 1 KiB request every ~40 cycles and blocks the issuing wave meanwhile) + ~130 of waits, the MFMA slot 600-650, a barrier ~100:
 // the load slot of one group is what the MFMAs of the other wait for.
