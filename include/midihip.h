@@ -31,13 +31,20 @@ extern "C" {
 
 const char* mh_last_error(void);
 int mh_version(void);
-/* runtime options (A/B runs and tests; every default is the production path; mh_get_option returns -1 for an unknown name):
+/* 1 when the library was built with -DMH_AB_BUILDS (libmidihip_ab.so: the test / measurement library that also holds the
+ * first-form attention kernels, the 128x128 bf16 GEMM and the ablation builds of the production GEMM), 0 for libmidihip.so. */
+int mh_ab_builds(void);
+/* runtime options (A/B runs and tests; every default is the production path; mh_get_option returns -1 for an unknown name).
+ * THREAD-LOCAL: a value set here applies to later calls made by the SAME host thread only; other threads (e.g. the
+ * concurrent generators of app.py:496) keep their own values, new threads start from the defaults.
  * "gemm" = 1 (production bf16 kernel: 256x256 tile, ping-pong wave groups) | 0 (128x128 two-stage kernel, the independent
- * check); "gemm_k64" = 1 (products with a row-major A operand -- forward projections, dgrads -- run the K-step-64 main loop
- * with whole-line LDS-DMA) | 2 (only row-major x row-major) | 0 (the K-step-32 loop everywhere; identical bits);
- * "gemm_ablate" = micro-benchmark / timeline builds of the production kernel (wrong results);
+ * check; bf16: A/B library only); "gemm_k64" = 1 (products with a row-major A operand -- forward projections, dgrads -- run
+ * the K-step-64 main loop with whole-line LDS-DMA) | 2 (only row-major x row-major) | 0 (the K-step-32 loop everywhere;
+ * identical bits); "gemm_ablate" = micro-benchmark / timeline builds of the production kernel (wrong results; A/B library
+ * only -- the production library returns MH_ERR_ARG for any non-zero value at the next mh_gemm call);
  * "skinny_mb" / "skinny_nbt" = 16-row activation blocks / 16-column blocks per workgroup of mh_gemm_skinny (0 = default);
- * "attn_v3" / "attn_v3_wps" = forms of the event-level attention kernels (attention_mfma3.hip). */
+ * "attn_v3" / "attn_v3_wps" = forms of the event-level attention kernels (attention_mfma3.hip; values that select a
+ * first-form kernel: A/B library only). */
 int mh_set_option(const char* name, int value);
 int mh_get_option(const char* name);
 

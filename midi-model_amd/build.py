@@ -15,6 +15,10 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(HERE, "_build")
 LIB = os.path.join(HERE, "libmidihip.so")
+# the A/B test library: the same sources with -DMH_AB_BUILDS (first-form attention kernels, the 128x128 bf16 GEMM, the
+# ablation / timeline builds of the production GEMM).  Loaded only by tests and tools (lib.use_ab()), never by the package.
+OBJ_AB = os.path.join(HERE, "_build_ab")
+LIB_AB = os.path.join(HERE, "libmidihip_ab.so")
 INCLUDE = os.path.join(os.path.dirname(HERE), "include")
 
 SOURCES = ["api.cpp", "gemm.hip", "gemm_pp256.hip", "gemm_skinny.hip", "elementwise.hip", "loss_optim.hip", "attention_small.hip", "attention_mfma.hip", "attention_mfma3.hip"]
@@ -37,20 +41,23 @@ def _newest_header() -> float:
     return t
 
 
-def build(force: bool = False, verbose: bool = False) -> str:
-    os.makedirs(OBJ, exist_ok=True)
+def build(force: bool = False, verbose: bool = False, ab: bool = True) -> str:
+    """production library (+ the A/B test library unless ab=False); returns the production library's path"""
     hipcc = _hipcc()
     hdr_t = _newest_header()
     jobs = []
-    for src in SOURCES:
-        s = os.path.join(CSRC, src)
-        o = os.path.join(OBJ, os.path.splitext(src)[0] + ".o")
-        if force or not os.path.exists(o) or os.path.getmtime(o) < max(os.path.getmtime(s), hdr_t):
-            jobs.append((s, o))
+    variants = [(OBJ, LIB, [])] + ([(OBJ_AB, LIB_AB, ["-DMH_AB_BUILDS"])] if ab else [])
+    for objdir, _, extra in variants:
+        os.makedirs(objdir, exist_ok=True)
+        for src in SOURCES:
+            s = os.path.join(CSRC, src)
+            o = os.path.join(objdir, os.path.splitext(src)[0] + ".o")
+            if force or not os.path.exists(o) or os.path.getmtime(o) < max(os.path.getmtime(s), hdr_t):
+                jobs.append((s, o, extra))
 
     def run(job):
-        s, o = job
-        cmd = [hipcc, *FLAGS, "-x", "hip", "-c", s, "-o", o]
+        s, o, extra = job
+        cmd = [hipcc, *FLAGS, *extra, "-x", "hip", "-c", s, "-o", o]
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError(f"hipcc failed on {s}:\n{r.stderr}")
@@ -61,12 +68,13 @@ def build(force: bool = False, verbose: bool = False) -> str:
     if jobs:
         with ThreadPoolExecutor(max_workers=min(len(jobs), os.cpu_count() or 4)) as ex:
             list(ex.map(run, jobs))
-    objs = [os.path.join(OBJ, os.path.splitext(s)[0] + ".o") for s in SOURCES]
-    if jobs or not os.path.exists(LIB):
-        cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB, *objs]
-        r = subprocess.run(cmd, capture_output=True, text=True)
-        if r.returncode != 0:
-            raise RuntimeError(f"link failed:\n{r.stderr}")
+    for objdir, lib, _ in variants:
+        objs = [os.path.join(objdir, os.path.splitext(s)[0] + ".o") for s in SOURCES]
+        if any(o.startswith(objdir + os.sep) for _, o, _ in jobs) or not os.path.exists(lib):
+            cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", lib, *objs]
+            r = subprocess.run(cmd, capture_output=True, text=True)
+            if r.returncode != 0:
+                raise RuntimeError(f"link failed:\n{r.stderr}")
     return LIB
 
 

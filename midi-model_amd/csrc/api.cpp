@@ -14,6 +14,12 @@ void mh_set_error(const char* fmt, ...) {
 }
 
 // ---- runtime options -------------------------------------------------------------------------------------
+// Every option is THREAD-LOCAL: mh_set_option changes what the CALLING host thread's later launches select and nothing
+// else, so a test or probe that flips a kernel form cannot change what a generator running on another thread of the
+// process launches (app.py:496 runs up to 10 on one model).  A new thread starts from the defaults below (environment
+// variables are read once per thread).  The forms that exist only for A/B measurements (first-form attention kernels, the
+// 128x128 bf16 GEMM, the wrong-by-design ablation builds of the production GEMM) are compiled only with -DMH_AB_BUILDS
+// into libmidihip_ab.so (build.py); the production library refuses the option values that would select them.
 // "gemm": 1 = the production bf16 kernel (gemm_pp256.hip: 256x256 tile, 4-stage LDS-DMA ring, ping-pong wave groups),
 // 0 = the first structure (gemm.hip: 128x128, 2 stages), which also serves fp32; kept as an independent check of the
 // production kernel in the GPU tests.  Initial value from the environment variable MH_GEMM (default 1).
@@ -24,14 +30,14 @@ static int env_int(const char* name, int dflt) {
   const char* v = getenv(name);
   return (v && *v) ? atoi(v) : dflt;
 }
-int g_mh_gemm_variant = env_int("MH_GEMM", 1);
-int g_mh_gemm_ablate = 0;
+thread_local int g_mh_gemm_variant = env_int("MH_GEMM", 1);
+thread_local int g_mh_gemm_ablate = 0;
 // "gemm_k64": 1 (default) = products of two row-major operands (every forward projection) run the K-step-64 main loop of
 // gemm_pp256_kernel (whole-line LDS-DMA, r03) and so does the dgrad form (A row-major, B contraction-major), 2 = only the former,
 // 0 = the K-step-32 loop everywhere (bit-identical results; A/B runs, MH_GEMM_K64)
-int g_mh_gemm_k64 = env_int("MH_GEMM_K64", 1);
-extern int g_skinny_mb, g_skinny_nbt;  // gemm_skinny.hip
-extern int g_attn_v3, g_attn_v3_wps;      // attention_mfma3.hip
+thread_local int g_mh_gemm_k64 = env_int("MH_GEMM_K64", 1);
+extern thread_local int g_skinny_mb, g_skinny_nbt;  // gemm_skinny.hip
+extern thread_local int g_attn_v3, g_attn_v3_wps;      // attention_mfma3.hip
 
 extern "C" int mh_set_option(const char* name, int value) {
   if (strcmp(name, "gemm") == 0) {
@@ -80,3 +86,11 @@ extern "C" int mh_get_option(const char* name) {
 
 extern "C" const char* mh_last_error(void) { return g_err; }
 extern "C" int mh_version(void) { return 1; }
+// 1 when this library holds the A/B-only kernel forms (libmidihip_ab.so), 0 for the production library
+extern "C" int mh_ab_builds(void) {
+#ifdef MH_AB_BUILDS
+  return 1;
+#else
+  return 0;
+#endif
+}

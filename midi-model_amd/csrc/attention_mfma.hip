@@ -27,6 +27,9 @@
 // Roofline: MFMA (2.5 PFLOP/s bf16 dense), VALU co-limited.
 #include "attn_mfma_common.h"
 
+// The first-form kernels are compiled only into the A/B test library (libmidihip_ab.so, -DMH_AB_BUILDS, build.py): the
+// production library holds the third form and the dispatch below, and refuses the option values that select this form.
+#ifdef MH_AB_BUILDS
 // ---------------------------------------------------------------------------------------------------
 // forward
 // ---------------------------------------------------------------------------------------------------
@@ -418,8 +421,10 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const bf16* __rest
   }
 }
 
+#endif  // MH_AB_BUILDS
+
 // ---------------------------------------------------------------------------------------------------
-extern int g_attn_v3;  // attention_mfma3.hip: the third form of the three kernels (bit 0 forward, bit 1 dQ, bit 2 dK/dV, bit 3
+extern thread_local int g_attn_v3;  // attention_mfma3.hip: the third form of the three kernels (bit 0 forward, bit 1 dQ, bit 2 dK/dV, bit 3
                        // transpose reads in the backward pair instead of the prepared copies)
 int mh_attn_fwd_mfma3(const void* qkv, const void* vt, void* o, float* lse, int64_t B, int64_t S, int H, float scale,
                       hipStream_t st);
@@ -432,6 +437,10 @@ int mh_attn_fwd_mfma(const void* qkv, const void* vt, void* o, float* lse, int64
   MH_REQUIRE(S < (1 << 24), "attn_fwd: sequence too long");
   if ((g_attn_v3 & 1) && (vt != nullptr || (g_attn_v3 & 16)))  // (vt == NULL + bit 4: V through transpose reads)
     return mh_attn_fwd_mfma3(qkv, vt, o, lse, B, S, H, scale, st);
+#ifndef MH_AB_BUILDS
+  MH_REQUIRE(false, "attn_fwd(bf16): option attn_v3 = %d selects the first form of the kernel, which is only in the A/B test "
+             "library (libmidihip_ab.so)", g_attn_v3);
+#else
   MH_REQUIRE(vt != nullptr, "attn_fwd(bf16): the first form needs the transposed V copy (mh_attn_prep_fwd)");
   const int64_t Sp = (S + 63) / 64 * 64;
   const int nt = (int)((S + 127) / 128), BH = (int)(B * H);
@@ -440,6 +449,7 @@ int mh_attn_fwd_mfma(const void* qkv, const void* vt, void* o, float* lse, int64
                                         scale * LOG2E, BH, nt);
   MH_LAUNCH_CHECK();
   return MH_OK;
+#endif
 }
 
 // backward in one call, delta = rowsum(dO * O) computed by the dQ kernel (third form with transpose reads only)
@@ -465,6 +475,10 @@ int mh_attn_bwd_mfma(const void* qkv, const void* dout, const float* lse, const 
     const int rc = mh_attn_bwd_mfma3(qkv, dout, lse, delta, qt, kt, dot, dqkv, B, S, H, scale, cos_t, sin_t, g_attn_v3 & 14, st);
     if (rc != MH_OK) return rc;
   }
+#ifndef MH_AB_BUILDS
+  MH_REQUIRE((g_attn_v3 & 6) == 6, "attn_bwd(bf16): option attn_v3 = %d selects first-form kernels, which are only in the A/B "
+             "test library (libmidihip_ab.so)", g_attn_v3);
+#else
   if (!(g_attn_v3 & 2)) {
     attn_bwd_dq_kernel<<<grid, 256, 6 * TILE64, st>>>((const bf16*)qkv, (const bf16*)dout, lse, delta, (const bf16*)kt,
                                              (bf16*)dqkv, (int)S, (int)Sp, H, scale, BH, nt, cos_t, sin_t);
@@ -475,5 +489,7 @@ int mh_attn_bwd_mfma(const void* qkv, const void* dout, const float* lse, const 
                                               (const bf16*)dot, (bf16*)dqkv, (int)S, (int)Sp, H, scale, BH, nt, cos_t, sin_t);
     MH_LAUNCH_CHECK();
   }
+#endif
+  (void)grid;
   return MH_OK;
 }

@@ -33,11 +33,11 @@
 // "the SIMD issue model".
 #include "attn_mfma_common.h"
 
-int g_attn_v3 = 127;     // mh_set_option("attn_v3", bits): 1 forward, 2 dQ, 4 dK/dV, 8 transpose reads in dQ + dK/dV (needs 2 | 4),
+thread_local int g_attn_v3 = 127;     // mh_set_option("attn_v3", bits): 1 forward, 2 dQ, 4 dK/dV, 8 transpose reads in dQ + dK/dV (needs 2 | 4),
                         // 16 transpose reads in the forward (needs 1; the caller then passes no V^T copy), 32 the host side
                         // calls mh_attn_bwd_o (delta computed inside the dQ kernel; needs 2 | 4 | 8), 64 three K/V stages
                         // in the forward (needs 1 | 16)
-int g_attn_v3_wps = 0;  // mh_set_option("attn_v3_wps", n): register budget (waves per SIMD) override for A/B runs, 0 = default
+thread_local int g_attn_v3_wps = 0;  // mh_set_option("attn_v3_wps", n): register budget (waves per SIMD) override for A/B runs, 0 = default
 
 __device__ inline bf16x8 ldsv(const char* p) { return *reinterpret_cast<const bf16x8*>(p); }
 // eight consecutive accumulator registers -> one bf16 operand fragment, as four explicit two-element conversions (each one

@@ -248,7 +248,7 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
   }
 }
 
-extern int g_mh_gemm_variant;  // api.cpp
+extern thread_local int g_mh_gemm_variant;  // api.cpp
 int mh_gemm_pp256_bf16(const void* A, int64_t lda, int ta, const void* B, int64_t ldb, int tb, void* C, int64_t ldc,
                        const void* R, int64_t ldr, int64_t M, int64_t N, int64_t K, float alpha, float beta, int splitk,
                        void* workspace, hipStream_t st);  // gemm_pp256.hip
@@ -273,7 +273,11 @@ static int gemm_launch(const void* A, int64_t lda, int ta, const void* B, int64_
   const int64_t kps = ((K + splitk - 1) / splitk + BK - 1) / BK * BK;
   MH_REQUIRE(splitk == 1 || workspace != nullptr, "gemm: split-K needs a workspace");
   if constexpr (sizeof(T) == 2) {
+#ifdef MH_AB_BUILDS
     if (g_mh_gemm_variant != 0)  // production kernel; 0 = the first structure below (kept as an independent check)
+#else  // the bf16 instantiations of the first structure are only in the A/B test library (libmidihip_ab.so)
+    MH_REQUIRE(g_mh_gemm_variant != 0, "gemm(bf16): option gemm = 0 selects the 128x128 kernel, which is only in the A/B test library");
+#endif
       return mh_gemm_pp256_bf16(A, lda, ta, B, ldb, tb, C, ldc, R, ldr, M, N, K, alpha, beta, splitk, workspace, st);
   }
   const int nwg = (int)(tiles_m * tiles_n);
@@ -282,10 +286,12 @@ static int gemm_launch(const void* A, int64_t lda, int ta, const void* B, int64_
   gemm_nt_kernel<T, TA_, TB_><<<grid, 256, 0, st>>>((const T*)A, lda, (const T*)B, ldb, (T*)C, ldc, (const T*)R, ldr, M, N, \
                                                      K, alpha, beta, (int)tiles_n, nwg, kps, (float*)workspace)
   if constexpr (sizeof(T) == 2) {
+#ifdef MH_AB_BUILDS
     if (ta && tb) MH_GEMM_LAUNCH(true, true);
     else if (ta) MH_GEMM_LAUNCH(true, false);
     else if (tb) MH_GEMM_LAUNCH(false, true);
     else MH_GEMM_LAUNCH(false, false);
+#endif
   } else {
     MH_GEMM_LAUNCH(false, false);
   }

@@ -867,8 +867,8 @@ int launch_one(const void* A, int64_t lda, const void* B, int64_t ldb, void* C, 
 
 }  // namespace
 
-extern int g_mh_gemm_ablate;   // api.cpp
-extern int g_mh_gemm_k64;      // api.cpp: row-major x row-major products take the K-step-64 main loop (default 1)
+extern thread_local int g_mh_gemm_ablate;   // api.cpp
+extern thread_local int g_mh_gemm_k64;      // api.cpp: row-major x row-major products take the K-step-64 main loop (default 1)
 
 // called by gemm.hip after argument validation (bf16 only)
 int mh_gemm_pp256_bf16(const void* A, int64_t lda, int ta, const void* B, int64_t ldb, int tb, void* C, int64_t ldc,
@@ -876,6 +876,16 @@ int mh_gemm_pp256_bf16(const void* A, int64_t lda, int ta, const void* B, int64_
                        void* workspace, hipStream_t st) {
 #define MH_PP(TA_, TB_, ABL_) \
   return launch_one<TA_, TB_, ABL_>(A, lda, B, ldb, C, ldc, R, ldr, M, N, K, alpha, beta, splitk, workspace, st)
+#ifndef MH_AB_BUILDS
+  MH_REQUIRE(g_mh_gemm_ablate == 0, "gemm: option gemm_ablate = %d selects a micro-benchmark build, which is only in the A/B test "
+             "library (libmidihip_ab.so)", g_mh_gemm_ablate);
+#else
+  // timeline build: 16 KiB of stamps go to `workspace`, which split-K partials would share
+  MH_REQUIRE(g_mh_gemm_ablate != 128 || (workspace != nullptr && splitk == 1), "gemm_ablate 128 (timeline) needs a workspace and splitk 1");
+  // K-step-64 main loop: only these ablations exist; anything else would silently time the production kernel
+  MH_REQUIRE(!(g_mh_gemm_k64 && !ta && !tb) || g_mh_gemm_ablate == 0 || g_mh_gemm_ablate == 1 || g_mh_gemm_ablate == 4 ||
+                 g_mh_gemm_ablate == 128 || g_mh_gemm_ablate == 64,
+             "gemm_ablate %d is not built for the K-step-64 main loop (set gemm_k64 = 0 for the K-step-32 ablations)", g_mh_gemm_ablate);
   if (ta == tb && g_mh_gemm_ablate && !(g_mh_gemm_k64 && !ta)) {  // micro-benchmark builds (wrong results), both-row-major / both-contraction-major
 #define MH_AB(X_) \
   case X_:        \
@@ -890,6 +900,7 @@ int mh_gemm_pp256_bf16(const void* A, int64_t lda, int ta, const void* B, int64_
     if (tb) MH_PP(false, true, 64);
     MH_PP(false, false, 64);
   }
+#endif  // MH_AB_BUILDS
   if (ta && tb) MH_PP(true, true, 0);
   if (ta) MH_PP(true, false, 0);
   if (tb && g_mh_gemm_k64 == 1)  // dgrad form (A row-major, B contraction-major): the K-step-64 main loop
@@ -898,12 +909,15 @@ int mh_gemm_pp256_bf16(const void* A, int64_t lda, int ta, const void* B, int64_
   if (g_mh_gemm_k64) {  // both operands row-major: the K-step-64 main loop
 #define MH_P8(ABL_) \
   return launch_one<false, false, ABL_, 0, 1>(A, lda, B, ldb, C, ldc, R, ldr, M, N, K, alpha, beta, splitk, workspace, st)
+#ifdef MH_AB_BUILDS
     switch (g_mh_gemm_ablate) {  // (micro-benchmark builds: tools/bench_gemm.py, tools/gemm_timeline.py)
       case 1: MH_P8(1);
       case 4: MH_P8(4);
       case 128: MH_P8(128);
-      default: MH_P8(0);
+      default: break;
     }
+#endif
+    MH_P8(0);
 #undef MH_P8
   }
   MH_PP(false, false, 0);

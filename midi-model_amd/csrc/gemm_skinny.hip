@@ -25,8 +25,8 @@
 // Roofline: HBM; algorithmic bytes = rows(W) * K * 2 (weights once).
 #include "common.h"
 
-int g_skinny_mb = 0;   // mh_set_option("skinny_mb", ...): 16-row blocks per workgroup (0 = default, see the launcher)
-int g_skinny_nbt = 0;  // mh_set_option("skinny_nbt", ...): 16-column blocks per workgroup of the plain form (0 = default)
+thread_local int g_skinny_mb = 0;   // mh_set_option("skinny_mb", ...): 16-row blocks per workgroup (0 = default, see the launcher)
+thread_local int g_skinny_nbt = 0;  // mh_set_option("skinny_nbt", ...): 16-column blocks per workgroup of the plain form (0 = default)
 
 namespace {
 

@@ -14,6 +14,9 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 HEADER = os.path.join(os.path.dirname(HERE), "include", "midihip.h")
 LIB_PATH = os.environ.get("MH_LIB_PATH") or os.path.join(HERE, "libmidihip.so")  # (MH_LIB_PATH: A/B runs of two builds)
 
+# the A/B test library (build.py: the same sources with -DMH_AB_BUILDS); loaded by tests / tools through use_ab() only
+AB_LIB_PATH = os.path.join(HERE, "libmidihip_ab.so")
+
 MH_F32, MH_BF16 = 0, 1
 
 _CTYPES = {"int": ctypes.c_int, "int64_t": ctypes.c_int64, "float": ctypes.c_float}
@@ -45,12 +48,14 @@ def _to_ctype(t: str):
 
 
 class _Lib:
-    def __init__(self) -> None:
-        if not os.path.exists(LIB_PATH):
+    def __init__(self, path: str = "") -> None:
+        path = path or LIB_PATH
+        if not os.path.exists(path):
             raise RuntimeError(
-                f"{LIB_PATH} is missing: the HIP kernels are the only implementation of this path. "
+                f"{path} is missing: the HIP kernels are the only implementation of this path. "
                 "Build them with `python -c 'import __graft_entry__ as g; g.build()'` (needs hipcc).")
-        self.cdll = ctypes.CDLL(LIB_PATH)
+        self.path = path
+        self.cdll = ctypes.CDLL(path)
         self.protos = parse_header()
         for name, (ret, args) in self.protos.items():
             try:
@@ -78,6 +83,7 @@ class _Lib:
 
 
 _lib = None
+_ab_lib = None
 
 
 def lib() -> _Lib:
@@ -85,6 +91,28 @@ def lib() -> _Lib:
     if _lib is None:
         _lib = _Lib()
     return _lib
+
+
+class use_ab:
+    """``with use_ab():`` -- tests and measurement tools only: every C-ABI call of this process goes to the A/B library
+    (libmidihip_ab.so: the production sources + the kernel forms kept for comparisons) while the block runs.  The package
+    itself never enters it."""
+
+    def __enter__(self):
+        global _lib, _ab_lib
+        if _ab_lib is None:
+            _ab_lib = _Lib(AB_LIB_PATH)
+            if _ab_lib.cdll.mh_ab_builds() != 1:
+                raise RuntimeError(f"{AB_LIB_PATH} was not built with -DMH_AB_BUILDS")
+        self.prev = lib()
+        _ab_lib.profile = self.prev.profile
+        _lib = _ab_lib
+        return _ab_lib
+
+    def __exit__(self, *exc):
+        global _lib
+        _lib = self.prev
+        return False
 
 
 def available() -> bool:

@@ -51,6 +51,26 @@ _gemm_variant = None
 _attn_v3 = None  # cached mh_get_option("attn_v3"): which forms of the event-level attention kernels run (attn_bwd)
 
 
+class ab_library:
+    """``with ops.ab_library():`` (tests, tools): run on libmidihip_ab.so, the build that also holds the first-form attention
+    kernels, the 128x128 bf16 GEMM and the ablation builds; the cached option values follow the library in use"""
+
+    def __enter__(self):
+        global _gemm_variant, _attn_v3
+        from .lib import use_ab
+        self._ctx = use_ab()
+        self._ctx.__enter__()
+        self._saved = (_gemm_variant, _attn_v3)
+        _gemm_variant = _attn_v3 = None
+        return self
+
+    def __exit__(self, *exc):
+        global _gemm_variant, _attn_v3
+        self._ctx.__exit__(*exc)
+        _gemm_variant, _attn_v3 = self._saved
+        return False
+
+
 def set_option(name: str, value: int) -> None:
     """runtime kernel selection (see mh_set_option in include/midihip.h)"""
     global _gemm_variant, _attn_v3

@@ -425,7 +425,7 @@ def install():
     import midi_model_amd.model as model
     saved = {n: getattr(real, n) for n in _NAMES if hasattr(real, n)}
     missing = [n for n in dir(real) if not n.startswith("_") and callable(getattr(real, n)) and n not in saved
-               and n not in ("lib", "dt", "round_up", "Optional")]
+               and n not in ("lib", "dt", "round_up", "Optional", "ab_library")]
     assert not missing, f"emulator lacks stand-ins for {missing}"
     req = model.MIDIModel._require_gpu
     try:

@@ -27,6 +27,50 @@ def test_abi_exports_every_declared_symbol():
         handle.call("mh_gemm_nt", 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 1.0, 0.0, 1, 1, 0, 0)
 
 
+def test_ab_library_exports_the_same_abi_and_is_marked():
+    """libmidihip_ab.so (build.py, -DMH_AB_BUILDS: the forms kept for comparisons) has the production ABI and says what it is;
+    the package's own handle is the production library"""
+    from midi_model_amd import lib as L
+    import midi_model_amd.build as build
+    build.build()
+    assert L.lib().cdll.mh_ab_builds() == 0 and L.lib().path.endswith("libmidihip.so")
+    with L.use_ab() as ab:
+        assert L.lib() is ab and ab.cdll.mh_ab_builds() == 1
+        for name in L.parse_header():
+            assert hasattr(ab.cdll, name)
+    assert L.lib().cdll.mh_ab_builds() == 0
+
+
+def test_options_are_per_thread():
+    """mh_set_option is a thread-local context: what one host thread selects (a test, a probe) is invisible to the launches of
+    every other thread of the process (concurrent generators, app.py:496), and a new thread starts from the defaults"""
+    import threading
+    from midi_model_amd import lib as L
+    h = L.lib()
+    defaults = {n: h.cdll.mh_get_option(n.encode()) for n in ("gemm", "gemm_k64", "gemm_ablate", "skinny_mb", "skinny_nbt", "attn_v3", "attn_v3_wps")}
+    assert defaults["gemm"] == 1 and defaults["attn_v3"] == 127 and defaults["gemm_ablate"] == 0
+    seen = {}
+
+    def other():
+        seen["before"] = {n: h.cdll.mh_get_option(n.encode()) for n in defaults}
+        h.call("mh_set_option", b"attn_v3", 15)
+        seen["own"] = h.cdll.mh_get_option(b"attn_v3")
+
+    try:
+        h.call("mh_set_option", b"skinny_mb", 2)
+        h.call("mh_set_option", b"attn_v3", 31)
+        t = threading.Thread(target=other)
+        t.start()
+        t.join()
+        assert seen["before"] == defaults, (seen["before"], defaults)
+        assert seen["own"] == 15
+        assert h.cdll.mh_get_option(b"attn_v3") == 31 and h.cdll.mh_get_option(b"skinny_mb") == 2
+    finally:
+        h.call("mh_set_option", b"skinny_mb", 0)
+        h.call("mh_set_option", b"attn_v3", 127)
+    assert h.cdll.mh_get_option(b"no_such_option") == -1
+
+
 def test_missing_library_is_a_hard_error(monkeypatch, tmp_path):
     from midi_model_amd import lib as L
     monkeypatch.setattr(L, "LIB_PATH", str(tmp_path / "nope.so"))

@@ -42,9 +42,15 @@ def _n_steps(tok, ids):
     return alive[0] + 1 if all(a == alive[0] for a in alive) else tok.max_token_seq
 
 
-@pytest.mark.parametrize("B,P,n_events", [(4, 65, 8), (64, 17, 4)], ids=["b4", "b64_benchmarked_batch"])
-def test_production_decode_session_matches_oracle(orc, tok, medium_bf16, golden, B, P, n_events):
-    """(B = 64: the batch bench.py --mode generate runs, where mh_gemm_skinny takes its 64-row tilings.)
+@pytest.mark.parametrize("B,P,n_events,cap,rows", [(4, 65, 8, 256, None), (64, 17, 4, 256, None),
+                                                      (64, 1001, 8, 2048, (0, 9, 18, 27, 36, 45, 54, 63))],
+                         ids=["b4", "b64_benchmarked_batch", "b64_cap2048_depth1000_benchmarked_session"])
+def test_production_decode_session_matches_oracle(orc, tok, medium_bf16, golden, B, P, n_events, cap, rows):
+    """(B = 64: the batch bench.py --mode generate runs, where mh_gemm_skinny takes its 64-row tilings.  The third case is the
+    session bench.py --mode generate checks out -- BASELINE configs[3]: capacity 2048, batch 64 -- at the DEPTH it runs to:
+    a 1001-event prefill, then 8 events decoded by the replayed graphs with pos_dev = 1001..1008, i.e. attn_decode_kernel<64>
+    over 1000+ cached keys at 64 x 16 heads.  Sequences are independent, so the oracle follows 8 of the 64 rows (every row
+    of the device batch still goes through the 64-row tilings; midi_model.py:195-248).)
     64-event prompt prefill + 8 decoded events, greedy (top_k = 1): after every replayed graph the session's hidden
     state / logits are within the reference's own bf16 drift (x1.5) of the oracle's cached fp32 forward on the SAME
     tokens, and the greedy id equals the oracle's masked arg-max wherever the oracle's top-2 margin exceeds twice that
@@ -58,7 +64,8 @@ def test_production_decode_session_matches_oracle(orc, tok, medium_bf16, golden,
     prompt = orc.synthetic_events(tok, B, P, seed=31)
     torch.set_num_threads(min(os.cpu_count() or 8, 32))
     with torch.inference_mode():
-        ses = DecodeSession(model, B, 256, 1.0, 0.98, 1)
+        ses = DecodeSession(model, B, cap, 1.0, 0.98, 1)
+        assert ses.cap == cap and ses.kv1.k.shape[-2] == cap
         assert ses.g_net is not None and ses.g_steps is not None and ses.g_noise is not None, "captured graphs are the production form"
         assert ses.fold1 is not None and ses.lm_fold is not None and ses.fused_sampler, "folded norms + fused sampler"
         ses.first_mask.copy_(model._grammar()[0])
@@ -66,20 +73,24 @@ def test_production_decode_session_matches_oracle(orc, tok, medium_bf16, golden,
         ses.reset()
         ses.begin(torch.Generator(device="cuda").manual_seed(1))
         ses.prefill(prompt.cuda())
+        R = torch.arange(B) if rows is None else torch.tensor(rows)  # the rows the oracle follows
+        Bo = R.numel()
         cache1 = orc.KV()
-        hid_o = orc.midi_forward(sd, shp, prompt, cache1)[:, -1]
+        hid_o = orc.midi_forward(sd, shp, prompt[R], cache1)[:, -1]
         worst_h, worst_l, checked, total = 0.0, 0.0, 0, 0
         for ev_i in range(n_events):
-            err = (ses.hidden.float().cpu() - hid_o).abs().max().item()
+            assert int(ses.pos.item()) == P + ev_i
+            err = (ses.hidden.float().cpu()[R] - hid_o).abs().max().item()
             worst_h = max(worst_h, err)
             assert err <= hid_bound, (ev_i, err, hid_bound)
             cache2 = orc.KV()
-            names, end = [""] * B, [False] * B
+            names, end = [""] * Bo, [False] * Bo
             n_steps, i, prev = tok.max_token_seq, 0, None
             while i < n_steps:
                 ses.tok_step(i)
-                lg = ses.logits[:, :V].float().cpu()
-                ids = ses.seq[:, i].cpu()
+                lg = ses.logits[:, :V].float().cpu()[R]
+                ids_all = ses.seq[:, i].cpu()
+                ids = ids_all[R]
                 lo = orc.midi_forward_token(sd, shp, hid_o if i == 0 else None, None if i == 0 else prev[:, None], cache2)[:, -1]
                 e = (lg - lo).abs().max().item()
                 worst_l = max(worst_l, e)
@@ -90,18 +101,18 @@ def test_production_decode_session_matches_oracle(orc, tok, medium_bf16, golden,
                 margin = top2.values[:, 0] - top2.values[:, 1]  # (inf where a single id is legal)
                 assert mask.gather(1, ids[:, None]).all(), "the device sampled an id outside the grammar mask"
                 safe = margin > 2 * log_bound
-                total += B
+                total += Bo
                 checked += int(safe.sum())
                 assert (ids[safe] == top2.indices[:, 0][safe]).all(), (ev_i, i, ids.tolist(), top2.indices[:, 0].tolist())
                 if i == 0:
-                    assert torch.equal(ses.ev.cpu(), ids)
+                    assert torch.equal(ses.ev.cpu(), ids_all)
                     names = [tok.id_events.get(int(t), "") for t in ids]
                     end = [int(t) == tok.eos_id for t in ids]
-                    n_steps = _n_steps(tok, ids.tolist())
+                    n_steps = _n_steps(tok, ids_all.tolist())  # (the break rule looks at the whole device batch)
                 prev = ids
                 i += 1
-            event = ses.seq.cpu().clone()
-            for b in range(B):  # positions past the event's arity hold PAD (fill_rest of the fused sampler)
+            event = ses.seq.cpu().clone()[R]
+            for b in range(Bo):  # positions past the event's arity hold PAD (fill_rest of the fused sampler)
                 ar = 0 if end[b] else len(tok.events[names[b]])
                 assert (event[b, 1 + ar:] == tok.pad_id).all()
             ses.net_step()
@@ -110,6 +121,47 @@ def test_production_decode_session_matches_oracle(orc, tok, medium_bf16, golden,
     print(f"decode session vs oracle: worst hidden err {worst_h:.4f} (bound {hid_bound:.4f}), worst logits err {worst_l:.4f} "
           f"(bound {log_bound:.4f}); greedy ids checked on {checked}/{total} rows with a safe margin")
     assert checked > 0.4 * total
+
+
+def test_greedy_generate_600_events_fp32_follows_the_oracle_id_for_id(orc, tok):
+    """``generate()`` itself at depth (midi_model.py:195-248): fp32 tv2o-medium, greedy (top_k = 1), BOS prompt, batch 2,
+    max_len 600 -- a capacity-1024 session, ~600 replays of the net / steps graphs with pos_dev running past 255 and 511.
+    The oracle is teacher-forced with the device's ids in ONE uncached pass (event-level forward over the 599 generated
+    events, token-level forward over every octet): at every sampling position the device's id must be the oracle's
+    grammar-masked arg-max wherever the oracle's top-2 margin exceeds 1e-3 (fp32 noise is ~1e-5: nearly every position
+    qualifies, and a position that does not cannot hide a wrong continuation because the oracle sees the device's tokens)."""
+    shp = orc.Shape(vocab=tok.vocab_size)
+    sd = orc.make_state_dict(shp, seed=0)
+    m = mm.MIDIModel(mm.MIDIModelConfig.from_name("tv2o-medium"))
+    m.load_state_dict(sd, strict=True)
+    m = m.to("cuda", torch.float32).eval()
+    B, L, T, V = 2, 600, tok.max_token_seq, tok.vocab_size
+    out = m.generate(None, batch_size=B, max_len=L, top_k=1, ban_eos=True, generator=torch.Generator(device="cuda").manual_seed(3))
+    assert out.shape == (B, L, T) and out.dtype == np.int64
+    ses = m._sessions.idle[-1]
+    assert ses.cap == 1024 and int(ses.pos.item()) == L - 1, (ses.cap, int(ses.pos.item()))
+    ids = torch.from_numpy(out)
+    torch.set_num_threads(min(os.cpu_count() or 8, 32))
+    with torch.inference_mode():
+        hidden = orc.midi_forward(sd, shp, ids[:, :-1])                        # (B, L-1, D): hidden i predicts event i+1
+        tgt = ids[:, 1:].reshape(B * (L - 1), T)
+        logits = orc.midi_forward_token(sd, shp, hidden.reshape(B * (L - 1), -1), tgt[:, :-1])  # (N, 8, V)
+    N = tgt.shape[0]
+    names = [tok.id_events[int(t)] for t in tgt[:, 0]]
+    bad, checked = [], 0
+    for i in range(T):
+        mask = orc.grammar_mask(tok, i, names if i else [""] * N, [False] * N, ban_eos=True).bool()
+        assert mask.gather(1, tgt[:, i:i + 1]).all(), f"position {i}: an id outside the grammar mask"
+        legal = logits[:, i].masked_fill(~mask, float("-inf"))
+        top2 = legal.topk(2, -1)
+        margin = top2.values[:, 0] - top2.values[:, 1]
+        safe = margin > 1e-3
+        checked += int(safe.sum())
+        wrong = (tgt[:, i] != top2.indices[:, 0]) & safe
+        bad += [(int(n), i) for n in wrong.nonzero().flatten()]
+    assert not bad, f"device ids differ from the oracle's arg-max at (row*event, position): {bad[:8]}"
+    assert checked > 0.97 * N * T, (checked, N * T)
+    print(f"greedy generate, {L} events x {B}: {checked}/{N * T} sampling positions checked against the oracle's arg-max, all equal")
 
 
 def test_fused_sampler_inside_graphs_equals_oracle_chain_on_same_noise(orc, tok, medium_bf16):

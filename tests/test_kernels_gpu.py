@@ -3,6 +3,7 @@ against the CPU restatement of the same op (tests/emu_ops.py) on identical seede
 (verification mode, tight tolerance) and bf16 (production mode, inputs pre-rounded to bf16 so the check
 measures the kernel and not the input rounding).  Shapes cover ragged / non-multiple-of-tile sizes, single
 rows, padding and ignore-index edge cases."""
+import contextlib
 import math
 
 import numpy as np
@@ -30,11 +31,43 @@ def ops():
 def gemm_variant(request, ops):
     """run the GEMM tests against the projection kernels: gemm.hip, gemm_pp256.hip as shipped (K-step-64 main loop for two
     row-major operands, K-step-32 ping-pong loop otherwise), gemm_pp256.hip with the K-step-32 loop everywhere"""
-    ops.set_option("gemm", min(request.param, 1))
-    ops.set_option("gemm_k64", 0 if request.param == 2 else 1)
-    yield request.param
-    ops.set_option("gemm", 1)
-    ops.set_option("gemm_k64", 1)
+    with (ops.ab_library() if request.param == 0 else contextlib.nullcontext()):  # the 128x128 bf16 kernel: A/B library only
+        ops.set_option("gemm", min(request.param, 1))
+        ops.set_option("gemm_k64", 0 if request.param == 2 else 1)
+        yield request.param
+        ops.set_option("gemm", 1)
+        ops.set_option("gemm_k64", 1)
+
+
+def test_production_library_refuses_the_ab_only_forms(ops):
+    """the first-form attention kernels, the 128x128 bf16 GEMM and the wrong-by-design ablation builds are not in
+    libmidihip.so: selecting one is an error at the call, not a silent substitution"""
+    from midi_model_amd.lib import lib
+    assert lib().cdll.mh_ab_builds() == 0
+    a, b = torch.ones((64, 64), dtype=torch.bfloat16, device="cuda"), torch.ones((64, 64), dtype=torch.bfloat16, device="cuda")
+    c = torch.empty((64, 64), dtype=torch.bfloat16, device="cuda")
+    try:
+        ops.set_option("gemm", 0)
+        with pytest.raises(RuntimeError, match="A/B test library"):
+            ops.gemm_nt(a, b, c)
+        ops.set_option("gemm", 1)
+        ops.set_option("gemm_ablate", 4)
+        with pytest.raises(RuntimeError, match="A/B test"):
+            ops.gemm_nt(a, b, c)
+        ops.set_option("gemm_ablate", 0)
+        ops.gemm_nt(a, b, c)
+        assert (c.float() == 64).all()
+        ops.set_option("attn_v3", 0)
+        qkv = torch.zeros((64, 192), dtype=torch.bfloat16, device="cuda")
+        o, lse = torch.empty((64, 64), dtype=torch.bfloat16, device="cuda"), torch.zeros(64, device="cuda")
+        with pytest.raises(RuntimeError, match="A/B test"):
+            ops.attn_fwd(qkv, o, lse, 1, 64, 1, 0.125)
+        with pytest.raises(RuntimeError, match="A/B"):
+            ops.attn_bwd(qkv, o, o, lse, torch.empty_like(qkv), 1, 64, 1, 0.125)
+    finally:
+        ops.set_option("gemm", 1)
+        ops.set_option("gemm_ablate", 0)
+        ops.set_option("attn_v3", 127)
 
 
 def rnd(shape, dtype, seed, scale=1.0):
@@ -359,6 +392,11 @@ def test_attention_fwd_bwd(ops, form, dtype, B, S, H):
     if dtype == torch.float32 and form != "v3_tr_all":
         pytest.skip("fp32 has one forward kernel")
     v3, v3_wps = ATTN_FORMS[form]
+    with (ops.ab_library() if form == "first_form" else contextlib.nullcontext()):  # (first form: A/B library only)
+        _attention_fwd_bwd(ops, v3, v3_wps, dtype, B, S, H)
+
+
+def _attention_fwd_bwd(ops, v3, v3_wps, dtype, B, S, H):
     ops.set_option("attn_v3", v3)
     ops.set_option("attn_v3_wps", v3_wps)
     D = H * 64
@@ -407,10 +445,11 @@ def test_attention_forward_when_the_reference_has_to_move(ops, v3):
     Sp = (S + 63) // 64 * 64
     o_ref, lse_ref = torch.empty((B * S, D), dtype=torch.bfloat16), torch.zeros(B * H * Sp)
     emu.attn_fwd(qkv, o_ref, lse_ref, B, S, H, 0.125)
-    ops.set_option("attn_v3", v3)
-    o, lse = torch.empty((B * S, D), dtype=torch.bfloat16, device="cuda"), torch.zeros(B * H * Sp, device="cuda")
-    ops.attn_fwd(qkv.cuda(), o, lse, B, S, H, 0.125)
-    ops.set_option("attn_v3", 127)
+    with (ops.ab_library() if v3 == 0 else contextlib.nullcontext()):
+        ops.set_option("attn_v3", v3)
+        o, lse = torch.empty((B * S, D), dtype=torch.bfloat16, device="cuda"), torch.zeros(B * H * Sp, device="cuda")
+        ops.attn_fwd(qkv.cuda(), o, lse, B, S, H, 0.125)
+        ops.set_option("attn_v3", 127)
     assert torch.isfinite(o.float()).all() and torch.isfinite(lse).all()
     cmp(o, o_ref, torch.bfloat16, what="attn o (moving reference)")
     got, want = lse.view(B, H, Sp)[:, :, :S].cpu(), lse_ref.view(B, H, Sp)[:, :, :S]
@@ -575,10 +614,15 @@ def test_clip_and_adamw(ops, dtype):
 
 # ----------------------------------------------------------------------------------------------- decode
 @pytest.mark.parametrize("dtype", DTYPES)
-@pytest.mark.parametrize("H,hd,Lmax,length", [(16, 64, 128, 1), (16, 64, 128, 100), (4, 256, 8, 1), (4, 256, 8, 7), (2, 64, 1100, 1031)])
-def test_decode_attention_and_cache(ops, dtype, H, hd, Lmax, length):
+@pytest.mark.parametrize("B,H,hd,Lmax,length", [(3, 16, 64, 128, 1), (3, 16, 64, 128, 100), (3, 4, 256, 8, 1), (3, 4, 256, 8, 7),
+                                                (3, 2, 64, 1100, 1031), (64, 16, 64, 2048, 1024), (64, 16, 64, 2048, 2047)])
+def test_decode_attention_and_cache(ops, dtype, B, H, hd, Lmax, length):
+    """(the last two cases: the cache of the benchmarked generate session -- batch 64 x 16 heads, capacity 2048 -- at the
+    depth the benchmark ends at and at the last position the capacity holds)"""
     from midi_model_amd.engine import RopeTable
-    B, D = 3, H * hd
+    if B == 64 and length == 2047 and dtype == torch.float32:
+        pytest.skip("the full-capacity case runs in the production dtype (4 GiB of fp32 host copies otherwise)")
+    D = H * hd
     tab = RopeTable(hd, 10000.0, "cuda", Lmax + 1)
     kc, vc = rnd((B, H, Lmax, hd), dtype, 32), rnd((B, H, Lmax, hd), dtype, 33)
     qkv = rnd((B, 3 * D), dtype, 34)
