@@ -512,6 +512,11 @@ def main():
     ops.gemm_profile = None
     loss_v = float(loss.item())
     red = model._reducer
+    # the reducer's statistics belong to the timed region ONLY: snapshot them and stop collecting before the extra passes below
+    # (the un-instrumented re-run and the kernel-family steps would otherwise add their windows to the per-step numbers)
+    red_stats = list(red.stats) if red is not None else []
+    if red is not None:
+        red.profile = False
     # the same K steps once more WITHOUT the HIP events around the GEMM launches (what the instrumentation of the timed
     # region costs is visible in the line: value_no_gemm_events beside value)
     dt_plain = None
@@ -551,7 +556,7 @@ def main():
             "model_flops_frac_of_peak": fl_event * B * S * args.steps / dt / 1e12 / PEAK_BF16_TFLOPS,
         }
         if world > 1:
-            st = red.stats if red is not None else []
+            st = red_stats
             exposed = [a.elapsed_time(b) for a, b, _, _ in st if a is not None]
             out.update(summarize_allreduce([(x[2], x[3]) for x in st], args.steps, exposed))
         if prof:

@@ -99,6 +99,7 @@ class DecodeSession:
         self._off = 0          # philox offset of the next draw the reference loop would make
         self._draw_inc = 0     # philox offset consumed by one [B, V] exponential_ call
         self._noise_pending = False
+        self._noise_read = False   # the pending variates have been read by a tok_step (step-by-step form)
         self._steps_recorded = False
         self.noise_stream = self.noise_done = self.copy_stream = self.steps_done = self.seq_host = None
         if self.use_graphs:
@@ -259,6 +260,7 @@ class DecodeSession:
         """take over the caller's random stream (None = the device's default generator)"""
         self._user_gen = generator
         self._noise_pending = False
+        self._noise_read = False
         if self.gen is not None:
             src = generator if generator is not None else torch.cuda.default_generators[self.model.device.index or 0]
             self.gen.set_state(src.get_state())
@@ -294,8 +296,16 @@ class DecodeSession:
             if self.g_tok[i] is None:
                 with _CAPTURE_LOCK:
                     self._capture_step(i)
-            if self.g_noise is not None and not self._noise_pending and i == 0:
-                self.draw_noise()
+            if self.g_noise is not None and i == 0:
+                if self._noise_pending and self._noise_read:
+                    # the pending variates were already read by an earlier event's steps and never reported with consumed():
+                    # sampling against them again would repeat that event's draws and leave the generator where it was
+                    raise RuntimeError("DecodeSession.tok_step(0): the previous event's draws were not reported -- call "
+                                       "consumed(n_steps) after the last tok_step of an event (sample_event() does both)")
+                if not self._noise_pending:
+                    self.draw_noise()
+            if self.g_noise is not None:
+                self._noise_read = True
             if self.g_noise is not None and self._noise_pending:
                 torch.cuda.current_stream().wait_event(self.noise_done)
             self.g_tok[i].replay()
@@ -318,6 +328,7 @@ class DecodeSession:
         else:
             self.noise_stream.wait_stream(torch.cuda.current_stream())
         self.gen.set_offset(self._off)
+        self._noise_read = False
         if _NOISE_INLINE:  # (A/B: the draws on the caller's stream, no cross-stream dependency)
             self.g_noise.replay()
             self.noise_done.record(torch.cuda.current_stream())
@@ -332,6 +343,7 @@ class DecodeSession:
         if self.g_noise is not None:
             self._off += n_steps * self._draw_inc
             self._noise_pending = False
+            self._noise_read = False
 
     def n_steps_of(self, ids) -> tuple:
         """(number of sampling calls the reference makes for an event whose first tokens are `ids`, all rows ended?) --

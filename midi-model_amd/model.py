@@ -612,9 +612,12 @@ class MIDIModel(nn.Module):
             except pickle.UnpicklingError as e:
                 # the reference calls plain torch.load (app.py:314), which executes whatever the pickle names; a Lightning
                 # .ckpt with callback / hyper-parameter objects outside torch's allow-list lands here
-                if not trust and os.environ.get("MH_TRUST_CHECKPOINT", "0") != "1":
+                # the trust is per call: the caller vouches for THIS file (no process-wide switch)
+                if not trust:
                     raise RuntimeError(f"{path} holds pickled objects beyond tensors ({e}); re-save its state_dict alone, or pass "
-                                       "from_checkpoint(..., trust_checkpoint=True) / MH_TRUST_CHECKPOINT=1 to unpickle it as the "
-                                       "reference does (only for files you trust)") from e
+                                       "from_checkpoint(..., trust_checkpoint=True) to unpickle it as the reference does (only "
+                                       "for a file you trust: unpickling executes what the file names)") from e
+                import warnings
+                warnings.warn(f"from_checkpoint: unpickling {path} with weights_only=False (trust_checkpoint=True)", stacklevel=2)
                 state = torch.load(path, map_location="cpu", weights_only=False)
         return model.load_checkpoint_state(state)

@@ -59,6 +59,9 @@ class GradReducer:
         self.profile = False
         self.stats: list = []          # (start event | None, end event | None, bytes, launches) per optimiser step
         self._bytes = 0
+        # the ranges one accumulation window must cover (None = all of `flat`); a backward that legitimately skips ranges
+        # (frozen parameters) sets it to the trainable ranges
+        self.expected: Optional[List[Tuple[int, int]]] = None
 
     def ready(self, lo: int, hi: int):
         if self.world == 1:
@@ -95,18 +98,31 @@ class GradReducer:
     def finish(self):
         if self.world == 1:
             return
+        # every element of the expected ranges (default: the whole flat gradient buffer -- lm_head, token-level layers and
+        # embedding, event-level layers and embedding, norm vectors) goes out exactly once per accumulation window.  Checked
+        # BEFORE the tail is launched; a failure still drains what is in flight and clears the window's state, so one bad
+        # window does not poison the following ones.
+        cover = sorted(self.launched + ([self.pending] if self.pending is not None else []))
+        problem = None
+        if cover:
+            want = self.expected if self.expected is not None else [(0, self.flat.numel())]
+            merged = []
+            for a in cover:
+                if merged and merged[-1][1] == a[0]:
+                    merged[-1] = (merged[-1][0], a[1])
+                else:
+                    merged.append(a)
+            overlap = any(a[1] > b[0] for a, b in zip(cover, cover[1:]))
+            if overlap or merged != sorted(want):
+                problem = (f"GradReducer: the announced ranges do not tile the expected ranges {sorted(want)[:4]}: "
+                           f"merged {merged[:6]}, overlap={overlap}")
+        if problem is not None:
+            self.pending = None
+            self._drain()
+            raise RuntimeError(problem)
         if self.pending is not None:
             self._launch(*self.pending)
             self.pending = None
-        if self.launched:
-            # every element of the flat gradient buffer goes out exactly once per accumulation window: the ranges announced by
-            # the backward (lm_head, token-level layers and embedding, event-level layers and embedding, norm vectors) tile it
-            cover = sorted(self.launched)
-            ok = cover[0][0] == 0 and cover[-1][1] == self.flat.numel() and all(a[1] == b[0] for a, b in zip(cover, cover[1:]))
-            if not ok:
-                gaps = [(a[1], b[0]) for a, b in zip(cover, cover[1:]) if a[1] != b[0]]
-                raise RuntimeError(f"GradReducer: the launched ranges do not tile the gradient buffer [0, {self.flat.numel()}): "
-                                   f"first {cover[0]}, last {cover[-1]}, seams {gaps[:4]}")
         ev = None
         if self.profile and self.comm_stream is not None:
             ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
@@ -119,6 +135,16 @@ class GradReducer:
             if ev is not None:
                 ev[1].record()
             self.stats.append((ev[0] if ev else None, ev[1] if ev else None, self._bytes, len(self.launched)))
+        self._bytes = 0
+        self.works.clear()
+        self.launched.clear()
+
+    def _drain(self):
+        """wait for whatever is in flight and forget the window (error path of finish())"""
+        for w in self.works:
+            w.wait()
+        if self.comm_stream is not None:
+            torch.cuda.current_stream().wait_stream(self.comm_stream)
         self._bytes = 0
         self.works.clear()
         self.launched.clear()

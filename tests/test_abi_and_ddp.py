@@ -235,3 +235,17 @@ def test_grad_reducer_refuses_an_untiled_buffer():
     r.ready(0, 50)                   # [50, 60) never announced
     with pytest.raises(RuntimeError, match="do not tile"):
         r.finish()
+    # the failed window left nothing behind: the next, complete window goes through
+    assert not r.launched and not r.works and r.pending is None
+    r.ready(50, 100)
+    r.ready(0, 50)
+    r.finish()
+    assert not r.launched and r.pending is None
+    # a backward that legitimately skips ranges (frozen parameters) declares the ranges it covers
+    r.expected = [(0, 40), (70, 100)]
+    r.ready(70, 100)
+    r.ready(0, 40)
+    r.finish()
+    r.ready(70, 100)
+    with pytest.raises(RuntimeError, match="do not tile"):
+        r.finish()

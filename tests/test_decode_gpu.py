@@ -111,6 +111,7 @@ def test_production_decode_session_matches_oracle(orc, tok, medium_bf16, golden,
                     n_steps = _n_steps(tok, ids_all.tolist())  # (the break rule looks at the whole device batch)
                 prev = ids
                 i += 1
+            ses.consumed(n_steps)  # the draws the reference loop would have made for this event (decode.py contract)
             event = ses.seq.cpu().clone()[R]
             for b in range(Bo):  # positions past the event's arity hold PAD (fill_rest of the fused sampler)
                 ar = 0 if end[b] else len(tok.events[names[b]])
@@ -245,6 +246,16 @@ def test_steps_graph_equals_step_by_step_and_rng_stream_is_the_reference_loops(o
             assert (ses.seq.cpu().numpy() == events[k]).all(), k
             ses.consumed(ses.n_steps_of(events[k][:, 0].tolist())[0])
             ses.net_step()
+        ses.end()
+        # the contract is enforced: an event stepped with tok_step and never reported with consumed() cannot be followed by
+        # another event's step 0 on the same (already read) variates
+        ses.begin(gen.manual_seed(11))
+        ses.tok_step(0)
+        with pytest.raises(RuntimeError, match="consumed"):
+            ses.tok_step(0)
+        ses.consumed(1)
+        ses.tok_step(0)
+        ses.consumed(1)
         ses.end()
 
 

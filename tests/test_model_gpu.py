@@ -178,6 +178,7 @@ def test_bf16_decode_session_variants_agree(tiny, tok, monkeypatch):
             ses.tok_step(0)
             l0 = ses.logits[:, : tok.vocab_size].float().clone()
             ses.seq.copy_(batch[:2, 5].cuda())
+            ses.consumed(1)  # the draws of the step above are reported before the next event's step 0 (decode.py contract)
             ses.net_step()
             h1 = ses.hidden.float().clone()
             ses.tok_step(0)
