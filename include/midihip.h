@@ -138,6 +138,21 @@ int mh_copy_rows(const void* src, int64_t src_ld, void* dst, int64_t dst_ld, int
 int mh_collate_windows(const int16_t* tokens, int64_t n_events, const int64_t* win_start, const int64_t* win_len,
                        int64_t* out, int64_t B, int64_t L, int T, int64_t pad_id, void* stream);
 
+/* Data augmentation fused into the batch assembly: MIDITokenizer.augment (midi_tokenizer.py:364-417 v1, :1023-1102 v2), which
+ * MidiDataset.load_midi applies to every file it serves (train.py:62-63, aug=True by default).  Integer work: bit-exact.
+ * `tab` int32[40]: the tokenizer tables the rules need (midi-model_amd/tokenizer.py: augment_table; layout in csrc/augment.hip).
+ * mh_augment_piece_stats -- once per corpus: for every piece (file) p = events [piece_off[p], piece_off[p+1]) of the int16
+ *   corpus, stats[p*130 ...] = {lowest, highest pitch among its notes off the drum channel (128, -1 when there are none),
+ *   bit mask of the ORIGINAL channels of the notes of each ORIGINAL track [128]}: the whole-file facts behind the reference's
+ *   "file unchanged when a shifted pitch leaves 0..127" (:1065-1066) and its key-signature second pass (:1099-1104).
+ * mh_augment_collate_windows -- per batch: mh_collate_windows with window b taken from piece win_piece[b] and augmented with
+ *   shifts[b*6 ...] = {pitch, velocity, cc value, bpm, track, channel} (the reference's draw order, :1025-1030).          */
+int mh_augment_piece_stats(const int16_t* tokens, const int64_t* piece_off, int64_t n_pieces, const int32_t* tab,
+                           int32_t* stats, void* stream);
+int mh_augment_collate_windows(const int16_t* tokens, int64_t n_events, const int64_t* win_start, const int64_t* win_len,
+                               const int64_t* win_piece, const int32_t* shifts, const int32_t* stats, const int32_t* tab,
+                               int64_t* out, int64_t B, int64_t L, int T, int64_t pad_id, void* stream);
+
 /* ---- RMSNorm (TF:models/llama/modeling_llama.py:62-67) ---------------------------------------------
  * y = w * T(x * rsqrt(mean(x^2)+eps));  rstd[M] (fp32) is saved for the backward.                   */
 int mh_rmsnorm_fwd(const void* x, const void* w, void* y, float* rstd, int64_t M, int D, float eps, int dtype,

@@ -19,7 +19,7 @@ AB_LIB_PATH = os.path.join(HERE, "libmidihip_ab.so")
 
 MH_F32, MH_BF16 = 0, 1
 
-_CTYPES = {"int": ctypes.c_int, "int64_t": ctypes.c_int64, "float": ctypes.c_float}
+_CTYPES = {"int": ctypes.c_int, "int64_t": ctypes.c_int64, "float": ctypes.c_float, "int32_t": ctypes.c_int32}
 
 
 def parse_header(path: str = HEADER) -> Dict[str, Tuple[str, List[Tuple[str, str]]]]:

@@ -280,6 +280,29 @@ def collate_windows(tokens_i16: torch.Tensor, win_start: torch.Tensor, win_len: 
     return out
 
 
+def augment_piece_stats(tokens_i16: torch.Tensor, piece_off: torch.Tensor, tab: torch.Tensor, stats: torch.Tensor):
+    """stats[P, 130] int32 <- the whole-file facts MIDITokenizer.augment's two file-level rules need (mh_augment_piece_stats)"""
+    P = piece_off.numel() - 1
+    assert tokens_i16.dtype == torch.int16 and tokens_i16.is_contiguous() and piece_off.dtype == torch.int64
+    assert tab.dtype == torch.int32 and stats.dtype == torch.int32 and stats.is_contiguous() and stats.shape == (P, 130)
+    lib().call("mh_augment_piece_stats", _p(tokens_i16), _p(piece_off), P, _p(tab), _p(stats), _stream())
+    return stats
+
+
+def augment_collate_windows(tokens_i16: torch.Tensor, win_start: torch.Tensor, win_len: torch.Tensor, win_piece: torch.Tensor,
+                            shifts: torch.Tensor, stats: torch.Tensor, tab: torch.Tensor, out: torch.Tensor, pad_id: int):
+    """collate_windows with every window augmented as MIDITokenizer.augment would have augmented its file (shifts[B, 6] int32:
+    pitch, velocity, cc value, bpm, track, channel)"""
+    B, L, T = out.shape
+    assert tokens_i16.dtype == torch.int16 and tokens_i16.is_contiguous() and tokens_i16.shape[1] == T
+    assert win_start.dtype == torch.int64 and win_len.dtype == torch.int64 and win_piece.dtype == torch.int64
+    assert shifts.dtype == torch.int32 and shifts.shape == (B, 6) and shifts.is_contiguous() and stats.dtype == torch.int32
+    assert out.dtype == torch.int64 and out.is_contiguous() and tab.dtype == torch.int32
+    lib().call("mh_augment_collate_windows", _p(tokens_i16), tokens_i16.shape[0], _p(win_start), _p(win_len), _p(win_piece),
+               _p(shifts), _p(stats), _p(tab), _p(out), B, L, T, pad_id, _stream())
+    return out
+
+
 # ---------------------------------------------------------------------------------------- embeddings
 def embed_sum_fwd(tok: torch.Tensor, table: torch.Tensor, out: torch.Tensor) -> torch.Tensor:
     M, T = tok.shape

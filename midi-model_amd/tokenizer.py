@@ -162,6 +162,44 @@ def grammar_tables(tok):
     return first, lo, hi, arity
 
 
+AUG_TAB_SIZE = 40
+AUG_STATS = 2 + 128  # per piece: lowest / highest pitch off the drum channel, channel mask per track (csrc/augment.hip)
+
+
+def augment_table(tok):
+    """int32[40] for mh_augment_*: what MIDITokenizer.augment (midi_tokenizer.py:364-417, :1023-1102) reads of the tokenizer --
+    event ids, the octet columns of the parameters it touches, id bases and sizes -- from PUBLIC attributes, so the reference's
+    own tokenizer object works as well as the tables-only one.  Layout: csrc/augment.hip."""
+    names = ["note", "patch_change", "control_change", "set_tempo", "time_signature", "key_signature"]
+    tab = [0] * AUG_TAB_SIZE
+    tab[0] = tok.max_token_seq
+
+    def col(ev, pn):
+        return 1 + tok.events[ev].index(pn) if ev in tok.events and pn in tok.events[ev] else 0
+
+    for e, n in enumerate(names):
+        tab[1 + e] = tok.event_ids.get(n, -1)
+        tab[7 + e] = col(n, "track")
+        tab[13 + e] = col(n, "channel")
+    tab[19], tab[20] = col("note", "pitch"), col("note", "velocity")
+    tab[21], tab[22] = col("control_change", "controller"), col("control_change", "value")
+    tab[23] = col("set_tempo", "bpm")
+    tab[24], tab[25] = col("key_signature", "sf"), col("key_signature", "mi")
+    pid = tok.parameter_ids
+
+    def base(pn):
+        return pid[pn][0] if pn in pid else 0
+
+    tab[26], tab[27] = base("track"), len(pid["track"])
+    tab[28], tab[29] = base("channel"), len(pid["channel"])
+    tab[30], tab[31], tab[32], tab[33] = base("pitch"), base("velocity"), base("controller"), base("value")
+    tab[34], tab[35] = base("bpm"), len(pid["bpm"])
+    tab[36], tab[37] = base("sf"), base("mi")
+    if tab[27] > 128 or tab[29] > 32 or len(pid["pitch"]) != 128 or len(pid["velocity"]) != 128 or len(pid["value"]) != 128:
+        raise ValueError("augment_table: the device augmentation is built for <= 128 tracks, <= 32 channels, 128 pitches / velocities / values")
+    return tab
+
+
 class MIDITokenizerV1(_VocabTables):
     version = "v1"
 

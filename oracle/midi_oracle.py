@@ -23,6 +23,9 @@ function below cites the reference call site (``midi_model.py`` / ``train.py``) 
   sample_top_p_k     midi_model.py:152-165
   generate           midi_model.py:167-250
   adamw_step / lr    train.py:93-103,121-151 + torch.optim.AdamW (single-tensor path), clip = Trainer(gradient_clip_val=1.0) train.py:464
+  augment            midi_tokenizer.py:364-417 (v1), :1023-1102 (v2): the data augmentation MidiDataset.load_midi applies
+                     (train.py:62-63), integer arithmetic on token ids; pinned to tests/golden/augment_v{1,2}.npz
+                     (tests/gen_golden_augment.py ran the reference's own method)
 
 PINNING.  The reference ships no tests, fixtures or golden vectors, so the oracle
 is pinned against outputs of the reference itself: ``tests/gen_golden.py`` imports the real
@@ -390,3 +393,75 @@ def synthetic_events(tok, batch: int, length: int, seed: int = 0, note_p: float 
             rows[sel, pos] = ids[0] + (u[sel, pos - 1] * len(ids)).long().clamp_(max=len(ids) - 1)
     out[:, 1:] = rows.reshape(batch, length - 1, tok.max_token_seq)
     return out
+
+
+# --------------------------------------------------------------------------------------------
+# data augmentation (integer work on token ids)
+# --------------------------------------------------------------------------------------------
+def augment(tok, seq: np.ndarray, shifts) -> np.ndarray:
+    """``tokenizer.augment(midi_seq)`` (midi_tokenizer.py:364-417 for v1, :1023-1102 for v2) for one file, with the six
+    random draws handed in: ``shifts = (pitch, velocity, cc_value, bpm, track, channel)`` in the order the reference draws
+    them (:1025-1030).  ``seq`` is the file's token rows [n, T]; returns the augmented rows (same dtype).  Whole-array
+    numpy, one masked assignment per rule:
+
+      * every event: track <- (track + track_shift) mod n_track; channel <- (channel + channel_shift) mod n_channel,
+        except that channel 9 stays 9 and a channel that LANDS on 9 goes to (9 + channel_shift) mod n_channel (:1041-1056)
+      * note: pitch += pitch_shift unless the note's ORIGINAL channel is 9; velocity clamped to 1..127 (:1058-1070)
+      * any note whose pitch leaves 0..127: the file comes back UNCHANGED (:1065-1066)
+      * control_change: controllers 1, 2, 7, 11 get value += cc shift, clamped to 1..127 (:1075-1081)
+      * set_tempo: bpm += bpm shift, clamped to 1..(n_bpm - 1) (:1082-1086)
+      * key_signature (v2): key transposed by pitch_shift through sf2key / key2sf (:568-579, :1087-1097); second pass
+        (:1099-1104): when the key signature's SHIFTED track is, among the ORIGINAL tracks of the file's notes, one whose
+        notes all sit on channel 9, sf <- 0 (token sf_ids[7])
+    """
+    pitch_s, vel_s, cc_s, bpm_s, track_s, chan_s = (int(x) for x in shifts)
+    a = np.asarray(seq).astype(np.int64)
+    out = a.copy()
+    pid, npar = tok.parameter_ids, tok.event_parameters
+    names = {n: (a[:, 0] == eid) for n, eid in tok.event_ids.items()}
+
+    def col(name, pn):
+        return 1 + tok.events[name].index(pn)
+
+    for name, rows in names.items():
+        if not rows.any():
+            continue
+        if "track" in tok.events[name]:
+            c = col(name, "track")
+            out[rows, c] = pid["track"][0] + (a[rows, c] - pid["track"][0] + track_s) % npar["track"]
+        if "channel" in tok.events[name]:
+            c = col(name, "channel")
+            c0 = a[rows, c] - pid["channel"][0]
+            c1 = (c0 + chan_s) % npar["channel"]
+            c1 = np.where(c0 == 9, 9, np.where(c1 == 9, (9 + chan_s) % npar["channel"], c1))
+            out[rows, c] = pid["channel"][0] + c1
+    note = names["note"]
+    n_ch = a[note, col("note", "channel")] - pid["channel"][0]
+    p = a[note, col("note", "pitch")] - pid["pitch"][0] + np.where(n_ch != 9, pitch_s, 0)
+    if ((p < 0) | (p >= 128)).any():
+        return np.asarray(seq).copy()
+    out[note, col("note", "pitch")] = pid["pitch"][0] + p
+    v = a[note, col("note", "velocity")] - pid["velocity"][0] + vel_s
+    out[note, col("note", "velocity")] = pid["velocity"][0] + np.clip(v, 1, 127)
+    cc = names["control_change"]
+    ctrl = a[cc, col("control_change", "controller")] - pid["controller"][0]
+    val = a[cc, col("control_change", "value")] - pid["value"][0]
+    val = np.where(np.isin(ctrl, (1, 2, 7, 11)), np.clip(val + cc_s, 1, 127), val)
+    out[cc, col("control_change", "value")] = pid["value"][0] + val
+    st = names["set_tempo"]
+    bpm = a[st, col("set_tempo", "bpm")] - pid["bpm"][0] + bpm_s
+    out[st, col("set_tempo", "bpm")] = pid["bpm"][0] + np.clip(bpm, 1, npar["bpm"] - 1)
+    if "key_signature" in names:
+        ks = names["key_signature"]
+        sf = a[ks, col("key_signature", "sf")] - pid["sf"][0] - 7
+        mi = a[ks, col("key_signature", "mi")] - pid["mi"][0]
+        k = ((sf * 7) % 12 + pitch_s) % 12                       # sf2key, transposed
+        sf2 = (k * 7) % 12                                       # key2sf
+        sf2 = np.where((sf2 > 6) | ((mi == 1) & (sf2 >= 5)), sf2 - 12, sf2) + 7
+        # tracks (ORIGINAL numbering) whose notes all sit on the drum channel
+        n_tr = a[note, col("note", "track")] - pid["track"][0]
+        drum_only = np.array([t for t in np.unique(n_tr) if (n_ch[n_tr == t] == 9).all()], dtype=np.int64)
+        ks_tr = out[ks, col("key_signature", "track")] - pid["track"][0]   # SHIFTED track of the key signature
+        sf2 = np.where(np.isin(ks_tr, drum_only), 7, sf2)
+        out[ks, col("key_signature", "sf")] = pid["sf"][0] + sf2
+    return out.astype(np.asarray(seq).dtype)

@@ -114,6 +114,78 @@ def collate_windows(tokens_i16, win_start, win_len, out, pad_id):
     return out
 
 
+def augment_piece_stats(tokens_i16, piece_off, tab, stats):
+    """the whole-file facts of mh_augment_piece_stats (csrc/augment.hip), per piece: lowest / highest pitch among the notes off
+    channel 9, and for every ORIGINAL track the bit mask of its notes' ORIGINAL channels"""
+    t = [int(x) for x in tab]
+    a = tokens_i16.long()
+    for p in range(piece_off.numel() - 1):
+        rows = a[int(piece_off[p]): int(piece_off[p + 1])]
+        notes = rows[rows[:, 0] == t[1]]
+        tr, ch, pitch = notes[:, t[7]] - t[26], notes[:, t[13]] - t[28], notes[:, t[19]] - t[30]
+        off9 = pitch[ch != 9]
+        stats[p, 0] = int(off9.min()) if off9.numel() else 128
+        stats[p, 1] = int(off9.max()) if off9.numel() else -1
+        stats[p, 2:] = 0
+        for k in range(notes.shape[0]):
+            stats[p, 2 + int(tr[k])] |= 1 << int(ch[k])
+    return stats
+
+
+def augment_collate_windows(tokens_i16, win_start, win_len, win_piece, shifts, stats, tab, out, pad_id):
+    """mh_augment_collate_windows: row-local rules given the per-piece facts (the decomposition the device uses; the CPU tests
+    hold it to the oracle's whole-file restatement and to the reference's goldens)"""
+    t = [int(x) for x in tab]
+    out.fill_(pad_id)
+
+    def pymod(x, m):
+        return ((x % m) + m) % m
+
+    for b in range(out.shape[0]):
+        n, s0 = int(win_len[b]), int(win_start[b])
+        rows = tokens_i16[s0: s0 + n].long().clone()
+        sh = [int(x) for x in shifts[b]]
+        st = stats[int(win_piece[b])]
+        lo, hi = int(st[0]), int(st[1])
+        if not (hi >= 0 and (lo + sh[0] < 0 or hi + sh[0] > 127)):
+            for r in range(n):
+                v = [int(x) for x in rows[r]]
+                if v[0] < 0 or v[0] not in t[1:7]:
+                    continue
+                e = t[1:7].index(v[0])
+                tcol, ccol, c0, tr_new = t[7 + e], t[13 + e], -1, -1
+                if tcol:
+                    tr_new = pymod(v[tcol] - t[26] + sh[4], t[27])
+                if ccol:
+                    c0 = v[ccol] - t[28]
+                    c = pymod(c0 + sh[5], t[29])
+                    c = 9 if c0 == 9 else (pymod(9 + sh[5], t[29]) if c == 9 else c)
+                    v[ccol] = t[28] + c
+                if e == 0:
+                    v[t[19]] += sh[0] if c0 != 9 else 0
+                    v[t[20]] = t[31] + max(1, min(127, v[t[20]] - t[31] + sh[1]))
+                elif e == 2:
+                    if v[t[21]] - t[32] in (1, 2, 7, 11):
+                        v[t[22]] = t[33] + max(1, min(127, v[t[22]] - t[33] + sh[2]))
+                elif e == 3:
+                    v[t[23]] = t[34] + max(1, min(t[35] - 1, v[t[23]] - t[34] + sh[3]))
+                elif e == 5:
+                    sf, mi = v[t[24]] - t[36] - 7, v[t[25]] - t[37]
+                    k = pymod(pymod(sf * 7, 12) + sh[0], 12)
+                    sf = (k * 7) % 12
+                    if sf > 6 or (mi == 1 and sf >= 5):
+                        sf -= 12
+                    sf += 7
+                    if 0 <= tr_new < 128 and int(st[2 + tr_new]) == 1 << 9:
+                        sf = 7
+                    v[t[24]] = t[36] + sf
+                if tcol:
+                    v[tcol] = t[26] + tr_new
+                rows[r] = torch.tensor(v)
+        out[b, :n] = rows
+    return out
+
+
 def embed_sum_fwd(tok, table, out):
     out.copy_(table[tok].float().sum(1).to(out.dtype))
     return out

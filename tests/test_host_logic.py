@@ -261,6 +261,52 @@ def test_device_corpus_batches_follow_reference_collate(tok):
             assert got.dtype == torch.int64 and torch.equal(got, want)
 
 
+@pytest.mark.parametrize("ver", ["v1", "v2"])
+def test_augment_decomposition_and_sampler_follow_the_reference(orc, golden, ver):
+    """The device path splits MIDITokenizer.augment into per-file facts (computed once per corpus) + row-local rules applied
+    while a window is cut (csrc/augment.hip).  Here that decomposition (the backend-shaped restatement in emu_ops) is held to
+    the reference's own outputs on whole files, and WindowSampler(aug=True) to ``MidiDataset.load_midi`` + ``__getitem__`` +
+    ``collate_fn`` (train.py:48-90) restated with the oracle: same `random` stream -- six shifts, then the window draws, per
+    served file -- same windows, same augmented tokens."""
+    import random
+    from midi_model_amd.data import AUG_MAXIMA, TokenCorpus, WindowSampler
+    from midi_model_amd.tokenizer import AUG_STATS, augment_table
+    tok = mm.MIDITokenizerV1() if ver == "v1" else mm.MIDITokenizerV2()
+    g = golden(f"augment_{ver}.npz")
+    off = g["offsets"]
+    P = len(off) - 1
+    pieces = [g["tokens"][off[i]:off[i + 1]] for i in range(P)]
+    tab = torch.tensor(augment_table(tok), dtype=torch.int32)
+    tokens = torch.from_numpy(g["tokens"])
+    stats = emu_ops.augment_piece_stats(tokens, torch.from_numpy(off), tab, torch.zeros((P, AUG_STATS), dtype=torch.int32))
+    lens = torch.from_numpy(np.diff(off))
+    out = torch.empty((P, int(lens.max()), tok.max_token_seq), dtype=torch.int64)
+    emu_ops.augment_collate_windows(tokens, torch.from_numpy(off[:-1].copy()), lens, torch.arange(P), torch.from_numpy(g["shifts"]),
+                                    stats, tab, out, tok.pad_id)
+    for i in range(P):
+        n = int(lens[i])
+        assert np.array_equal(out[i, :n].numpy(), g["augmented"][off[i]:off[i + 1]].astype(np.int64)), (ver, i)
+        assert (out[i, n:] == tok.pad_id).all()
+    with emu_ops.install():
+        corpus = TokenCorpus(pieces, device="cpu")
+        sampler = WindowSampler(corpus, max_len=96, rand_start=True, seed=11, aug=True, tokenizer=tok)
+        idx = [3, 0, 7, 7, 1, 10, 4, 2]
+        got = sampler.batch(idx, pad_id=tok.pad_id)
+    rng = random.Random(11)
+    ref = []
+    for i in idx:
+        m = AUG_MAXIMA
+        sh = [rng.randint(-m[0], m[0]), rng.randint(-m[1], m[1]), rng.randint(-m[2], m[2]), rng.randint(-m[3], m[3]),
+              rng.randint(0, m[4]), rng.randint(0, m[5])]                       # tokenizer.augment's draws (midi_tokenizer.py:1025-1030)
+        mid = orc.augment(tok, pieces[i], sh)                                   # load_midi (train.py:62-63)
+        start = rng.randrange(0, max(1, mid.shape[0] - 96))                     # __getitem__ (train.py:73-78)
+        start = rng.choice([0, start])
+        ref.append(torch.from_numpy(mid[start:start + 96].astype(np.int64)))
+    L = max(len(x) for x in ref)
+    want = torch.stack([torch.nn.functional.pad(x, (0, 0, 0, L - x.shape[0]), value=tok.pad_id) for x in ref])
+    assert got.dtype == torch.int64 and torch.equal(got, want)
+
+
 def test_load_merge_lora(tmp_path, tiny):
     """a saved LoRA adapter merges as W += (alpha / r) * B @ A into exactly the targeted weights (midi_model.py:109-114)"""
     from safetensors.torch import save_file

@@ -715,3 +715,63 @@ def test_collate_windows(ops):
     out = torch.full((5, 300, 8), -1, dtype=torch.int64, device="cuda")
     ops.collate_windows(tokens.cuda(), start.cuda(), length.cuda(), out, 0)
     assert torch.equal(out.cpu(), want)
+
+
+@pytest.mark.parametrize("ver", ["v1", "v2"])
+def test_augment_on_the_device_is_bit_exact(ops, orc, golden, ver):
+    """mh_augment_piece_stats + mh_augment_collate_windows against (a) the outputs of the reference's own
+    MIDITokenizerV{1,2}.augment on whole files (tests/golden/augment_*.npz) and (b) the oracle on a large random corpus with
+    windows cut inside the files; per-file facts against the host restatement.  Integer work: every token equal."""
+    import midi_model_amd as mm
+    from midi_model_amd.data import TokenCorpus, WindowSampler
+    from midi_model_amd.tokenizer import AUG_STATS, augment_table
+    tok = mm.MIDITokenizerV1() if ver == "v1" else mm.MIDITokenizerV2()
+    g = golden(f"augment_{ver}.npz")
+    off = g["offsets"]
+    P = len(off) - 1
+    tab = torch.tensor(augment_table(tok), dtype=torch.int32)
+    tokens = torch.from_numpy(g["tokens"])
+    want_stats = emu.augment_piece_stats(tokens, torch.from_numpy(off), tab, torch.zeros((P, AUG_STATS), dtype=torch.int32))
+    stats = torch.full((P, AUG_STATS), -77, dtype=torch.int32, device="cuda")
+    ops.augment_piece_stats(tokens.cuda(), torch.from_numpy(off).cuda(), tab.cuda(), stats)
+    assert torch.equal(stats.cpu(), want_stats)
+    lens = torch.from_numpy(np.diff(off))
+    out = torch.full((P, int(lens.max()), tok.max_token_seq), -5, dtype=torch.int64, device="cuda")
+    ops.augment_collate_windows(tokens.cuda(), torch.from_numpy(off[:-1].copy()).cuda(), lens.cuda(), torch.arange(P).cuda(),
+                                torch.from_numpy(g["shifts"]).cuda(), stats, tab.cuda(), out, tok.pad_id)
+    out = out.cpu()
+    for i in range(P):
+        n = int(lens[i])
+        assert np.array_equal(out[i, :n].numpy(), g["augmented"][off[i]:off[i + 1]].astype(np.int64)), (ver, i)
+        assert (out[i, n:] == tok.pad_id).all()
+    # (b) a sampler over a random corpus: 40 files of 200..3000 events, windows of up to 512, against the oracle per file
+    import random
+    from midi_model_amd.data import AUG_MAXIMA, synthetic_events
+    rs = np.random.default_rng(5)
+    pieces = []
+    for i in range(40):
+        ev = synthetic_events(tok, 1, int(rs.integers(200, 3000)), seed=300 + i, note_p=0.7)[0].numpy().astype(np.int16)
+        if i % 3 == 0:  # narrow the pitch range so that some files do get augmented
+            col = 1 + tok.events["note"].index("pitch")
+            notes = ev[:, 0] == tok.event_ids["note"]
+            ev[notes, col] = tok.parameter_ids["pitch"][0] + 20 + (ev[notes, col] - tok.parameter_ids["pitch"][0]) % 80
+        pieces.append(ev)
+    corpus = TokenCorpus(pieces, device="cuda")
+    sampler = WindowSampler(corpus, max_len=512, rand_start=True, seed=21, aug=True, tokenizer=tok)
+    idx = [int(x) for x in rs.integers(0, 40, 24)]
+    got = sampler.batch(idx, pad_id=tok.pad_id).cpu()
+    rng = random.Random(21)
+    ref, n_aug = [], 0
+    for i in idx:
+        m = AUG_MAXIMA
+        sh = [rng.randint(-m[0], m[0]), rng.randint(-m[1], m[1]), rng.randint(-m[2], m[2]), rng.randint(-m[3], m[3]),
+              rng.randint(0, m[4]), rng.randint(0, m[5])]
+        mid = orc.augment(tok, pieces[i], sh)
+        n_aug += int((mid != pieces[i]).any())
+        start = rng.randrange(0, max(1, mid.shape[0] - 512))
+        start = rng.choice([0, start])
+        ref.append(torch.from_numpy(mid[start:start + 512].astype(np.int64)))
+    L = max(len(x) for x in ref)
+    want = torch.stack([torch.nn.functional.pad(x, (0, 0, 0, L - x.shape[0]), value=tok.pad_id) for x in ref])
+    assert torch.equal(got, want)
+    assert 0 < n_aug < len(idx), n_aug

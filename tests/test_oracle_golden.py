@@ -160,3 +160,22 @@ def test_sampler_noise_form_is_the_generator_form(orc, tok):
     q = torch.empty((5, tok.vocab_size)).exponential_(1.0, generator=torch.Generator().manual_seed(9))
     b = orc.sample_top_p_k(pr.clone(), 0.9, 12, noise=q.view(5, 1, -1))
     assert torch.equal(a, b)
+
+
+@pytest.mark.parametrize("ver", ["v1", "v2"])
+def test_augment_equals_the_reference_tokenizers_own_method(orc, golden, ver):
+    """oracle.augment against tests/golden/augment_v{1,2}.npz = the outputs of the reference's MIDITokenizerV{1,2}.augment
+    (midi_tokenizer.py:364-417, :1023-1102; tests/gen_golden_augment.py) on 12 files per version: drum-channel rules, clamps,
+    key-signature transposition + second pass, files returned unchanged, wide maxima with a track shift.  Integer work: equal."""
+    import midi_model_amd as mm
+    tok = mm.MIDITokenizerV1() if ver == "v1" else mm.MIDITokenizerV2()
+    g = golden(f"augment_{ver}.npz")
+    off = g["offsets"]
+    n_changed = 0
+    for i in range(len(off) - 1):
+        seq, want = g["tokens"][off[i]:off[i + 1]], g["augmented"][off[i]:off[i + 1]]
+        got = orc.augment(tok, seq, g["shifts"][i])
+        assert got.dtype == seq.dtype and np.array_equal(got, want), (ver, i, np.argwhere(got != want)[:4].tolist())
+        assert bool((seq != want).any()) == bool(g["changed"][i])
+        n_changed += int(g["changed"][i])
+    assert 0 < n_changed < len(off) - 1
