@@ -220,6 +220,120 @@ class TrainMIDIModel(MIDIModel):
         self.global_step += 1
         self._micro = 0
 
+    # ------------------------------------------------------------------------ training-state resume
+    _NO_DECAY = ("bias", "norm")  # train.py:123
+
+    def _optimizer_param_order(self, names):
+        """the parameter order of the reference's optimizer (train.py:121-131): named_parameters order, the decayed group
+        first, then the names containing 'bias' or 'norm'"""
+        names = list(names)
+        return [n for n in names if not any(nd in n for nd in self._NO_DECAY)] + \
+               [n for n in names if any(nd in n for nd in self._NO_DECAY)]
+
+    def training_state(self) -> dict:
+        """What ``trainer.fit(..., ckpt_path=opt.resume)`` (train.py:475-479) needs to continue a run, in the layout of a
+        Lightning ``.ckpt``: ``state_dict``, ``global_step``, ``optimizer_states[0]`` = the ``torch.optim.AdamW.state_dict()`` of
+        the reference's two parameter groups (per-parameter ``step`` / ``exp_avg`` / ``exp_avg_sq``), ``lr_schedulers[0]`` = the
+        LambdaLR position.  Ours on top: the accumulation phase (``mh_micro``) and, inside an accumulation window, the gradient
+        accumulated so far."""
+        if self._lora is not None:
+            raise RuntimeError("training_state: adapter training keeps its state in the adapter (save_adapter)")
+        if self._opt is None:
+            self.configure_optimizers()
+        names = [n for n, _ in self.named_parameters()]
+        order = self._optimizer_param_order(names)
+        n_decay = sum(1 for n in names if not any(nd in n for nd in self._NO_DECAY))
+        m, v = self._opt["m"], self._opt["v"]
+        state = {}
+        for i, n in enumerate(order):
+            off, cnt, _ = self._offsets[n]
+            state[i] = {"step": torch.tensor(float(self.global_step)),
+                        "exp_avg": m[off:off + cnt].detach().cpu().clone(), "exp_avg_sq": v[off:off + cnt].detach().cpu().clone()}
+        shapes = {n: p.shape for n, p in self.named_parameters()}
+        for i, n in enumerate(order):
+            state[i]["exp_avg"] = state[i]["exp_avg"].view(shapes[n])
+            state[i]["exp_avg_sq"] = state[i]["exp_avg_sq"].view(shapes[n])
+        lr_now = self.current_lr()
+        group = dict(lr=lr_now, initial_lr=self.lr, betas=self.betas, eps=self.eps, amsgrad=False, maximize=False, foreach=None,
+                     capturable=False, differentiable=False, fused=None)
+        out = {
+            "state_dict": {k: t.detach().cpu().clone() for k, t in self.state_dict().items()},
+            "global_step": int(self.global_step), "epoch": 0,
+            "optimizer_states": [{"state": state, "param_groups": [
+                dict(group, weight_decay=self.weight_decay, params=list(range(n_decay))),
+                dict(group, weight_decay=0.0, params=list(range(n_decay, len(order))))]}],
+            "lr_schedulers": [{"last_epoch": int(self.global_step), "_step_count": int(self.global_step) + 1,
+                               "base_lrs": [self.lr, self.lr], "_last_lr": [lr_now, lr_now]}],
+            "hyper_parameters": dict(lr=self.lr, weight_decay=self.weight_decay, warmup=self.warmup, max_step=self.max_step),
+            "mh_micro": int(self._micro),
+        }
+        if self._micro > 0 and self._flat_grad is not None:
+            out["mh_grad"] = self._flat_grad.detach().cpu().clone()
+        return out
+
+    def save_training_state(self, path: str) -> None:
+        torch.save(self.training_state(), path)
+
+    def load_training_state(self, state) -> "TrainMIDIModel":
+        """Resume from ``training_state()`` or from a Lightning ``.ckpt`` payload of the reference's trainer (a path or the
+        loaded dict): weights, AdamW moments (mapped back to parameters through the reference's group order), the step count
+        the bias corrections and the LR schedule run on, the accumulation phase.  Strict: a moment tensor that is missing or has
+        the wrong shape raises."""
+        if isinstance(state, (str, os.PathLike)):
+            state = torch.load(state, map_location="cpu", weights_only=True)
+        if "optimizer_states" not in state or "state_dict" not in state:
+            raise RuntimeError("load_training_state: not a training checkpoint (needs state_dict + optimizer_states)")
+        self.load_checkpoint_state(state)
+        if self._opt is None:
+            self.configure_optimizers()
+        # the checkpoint's own key order = the saving module's named_parameters order (state_dict of parameters only)
+        own = dict(self.named_parameters())
+        keys = list(state["state_dict"].keys())
+        prefixes = ("model.", "base_model.model.", "module.", "_orig_mod.")
+        for _ in range(8):
+            if set(keys) & set(own):
+                break
+            hit = next((p for p in prefixes if keys and all(k.startswith(p) for k in keys)), None)
+            if hit is None:
+                break
+            keys = [k[len(hit):] for k in keys]
+        names = [k for k in keys if k in own]
+        order = self._optimizer_param_order(names)
+        opt = state["optimizer_states"][0]
+        groups = opt["param_groups"]
+        idx = [i for g in groups for i in g["params"]]
+        if len(idx) != len(order) or set(order) != set(own):
+            raise RuntimeError(f"load_training_state: the optimizer holds {len(idx)} parameters, the model {len(own)} "
+                               f"({len(order)} of them in the checkpoint)")
+        m, v = self._opt["m"], self._opt["v"]
+        steps = set()
+        for i, n in zip(idx, order):
+            st = opt["state"].get(i)
+            if st is None:  # torch creates a parameter's state at its first step with a gradient
+                if int(state.get("global_step", 0)) != 0:
+                    raise RuntimeError(f"load_training_state: no optimizer state for {n} in a checkpoint at step {state.get('global_step')}")
+                continue
+            off, cnt, _ = self._offsets[n]
+            for key, dst in (("exp_avg", m), ("exp_avg_sq", v)):
+                t = st[key]
+                if tuple(t.shape) != tuple(own[n].shape):
+                    raise RuntimeError(f"load_training_state: {key} of {n} has shape {tuple(t.shape)}, expected {tuple(own[n].shape)}")
+                dst[off:off + cnt].copy_(t.reshape(-1).to(device=dst.device, dtype=dst.dtype))
+            steps.add(int(float(st["step"])))
+        if len(steps) > 1:
+            raise RuntimeError(f"load_training_state: parameters disagree on the step count {sorted(steps)} (the fused AdamW keeps one)")
+        self.global_step = int(state.get("global_step", steps.pop() if steps else 0))
+        self._micro = int(state.get("mh_micro", 0))
+        if "mh_grad" in state:
+            self.grad_buffer().copy_(state["mh_grad"].to(self._flat.device, self._flat.dtype))
+        elif self._micro > 0:
+            raise RuntimeError("load_training_state: the checkpoint was taken inside an accumulation window but holds no gradient")
+        hp = state.get("hyper_parameters") or {}
+        for k in ("lr", "weight_decay", "warmup", "max_step"):
+            if k in hp:
+                setattr(self, k, hp[k])
+        return self
+
     # ------------------------------------------------------------------------------------- LoRA
     def add_adapter(self, lora_config=None, **kwargs):
         """train.py:439-449: ``model.requires_grad_(False); model.add_adapter(LoraConfig(r=64, lora_alpha=128,

@@ -144,6 +144,131 @@ def test_fused_step_grads_and_optimizer(orc, tiny, golden, tok):
                 np.testing.assert_allclose(got, g[key], rtol=2e-4, atol=2e-6)
 
 
+def test_training_state_resume(orc, tiny, tok, tmp_path):
+    """``trainer.fit(..., ckpt_path=opt.resume)`` (train.py:475-479): (a) save -> load into a fresh model -> continue equals the
+    uninterrupted run bit for bit, also from the middle of an accumulation window; (b) a checkpoint in Lightning's layout
+    written from the REAL ``torch.optim.AdamW`` / ``LambdaLR`` of train.py:121-151 after two steps of the reference recipe
+    resumes here, and our third step lands where torch's third step lands."""
+    shp, sd, _ = tiny
+    batches = [orc.synthetic_events(tok, 2, 17, seed=40 + i) for i in range(4)]
+    kw = dict(lr=1e-2, warmup=2, max_step=10)
+    with emu_ops.install():
+        for nacc, n_before in ((1, 2), (2, 3)):  # (2, 3): one optimiser step + one micro-batch into the next window
+            a = TrainMIDIModel(tiny_config(), accumulate_grad_batches=nacc, **kw)
+            a.load_state_dict(sd)
+            for i in range(n_before):
+                a.fit_step(batches[i])
+            path = str(tmp_path / f"state_{nacc}.ckpt")
+            a.save_training_state(path)
+            b = TrainMIDIModel(tiny_config(), accumulate_grad_batches=nacc, **kw)
+            b.load_training_state(path)
+            assert b.global_step == a.global_step and b._micro == a._micro == n_before % nacc
+            assert torch.equal(b._flat, a._flat) and torch.equal(b._opt["m"], a._opt["m"]) and torch.equal(b._opt["v"], a._opt["v"])
+            la, lb = a.fit_step(batches[n_before]), b.fit_step(batches[n_before])
+            assert torch.equal(la, lb) and torch.equal(b._flat, a._flat) and b.global_step == a.global_step
+            assert torch.equal(b._opt["m"], a._opt["m"]) and torch.equal(b._opt["v"], a._opt["v"])
+        with pytest.raises(RuntimeError, match="not a training checkpoint"):
+            b.load_training_state({"state_dict": {}})
+
+    # (b) the reference recipe with the real torch objects
+    from midi_model_amd.train import lr_lambda
+    params = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    named = list(params.items())
+    no_decay = ["bias", "norm"]
+    opt = torch.optim.AdamW([{"params": [p for n, p in named if not any(nd in n for nd in no_decay)], "weight_decay": 0.01},
+                             {"params": [p for n, p in named if any(nd in n for nd in no_decay)], "weight_decay": 0.0}],
+                            lr=1e-2, betas=(0.9, 0.99), eps=1e-8)
+    sched = torch.optim.lr_scheduler.LambdaLR(opt, lambda s_: lr_lambda(s_, 2, 10))
+
+    def ref_step(bt):
+        opt.zero_grad()
+        loss, _ = orc.training_loss(params, shp, bt)
+        loss.backward()
+        torch.nn.utils.clip_grad_norm_(list(params.values()), 1.0)
+        opt.step()
+        sched.step()
+        return loss.item()
+
+    for i in range(2):
+        ref_step(batches[i])
+    ckpt = {"state_dict": {k: v.detach().clone() for k, v in params.items()}, "global_step": 2,
+            "optimizer_states": [opt.state_dict()], "lr_schedulers": [sched.state_dict()]}
+    path = str(tmp_path / "lightning_layout.ckpt")
+    torch.save(ckpt, path)
+    want_loss = ref_step(batches[2])
+    with emu_ops.install():
+        m = TrainMIDIModel(tiny_config(), accumulate_grad_batches=1, weight_decay=0.01, **kw)
+        m.load_training_state(path)
+        assert m.global_step == 2
+        got_loss = m.fit_step(batches[2]).item()
+    assert abs(got_loss - want_loss) < 5e-5 * abs(want_loss)
+    for n, p in m.named_parameters():
+        np.testing.assert_allclose(p.detach().numpy(), params[n].detach().numpy(), rtol=2e-4, atol=2e-6, err_msg=n)
+    st = opt.state_dict()["state"]
+    order = m._optimizer_param_order([n for n, _ in named])
+    for i, n in enumerate(order):
+        off, cnt, _ = m._offsets[n]
+        np.testing.assert_allclose(m._opt["m"][off:off + cnt].numpy(), st[i]["exp_avg"].reshape(-1).numpy(), rtol=2e-3, atol=1e-6, err_msg=n)
+        np.testing.assert_allclose(m._opt["v"][off:off + cnt].numpy(), st[i]["exp_avg_sq"].reshape(-1).numpy(), rtol=2e-3, atol=1e-9, err_msg=n)
+
+
+def test_midimodel_is_a_mixin_base_the_way_the_reference_trainer_uses_it(orc, tiny, tok, golden):
+    """``class TrainMIDIModel(MIDIModel, pl.LightningModule)`` (train.py:106-119): MIDIModel must cooperate as the FIRST of two
+    module bases.  Lightning is not installed, so the second base is a stand-in with LightningModule's construction contract
+    (an nn.Module subclass whose __init__ takes no arguments, sets its own attributes and offers log / hooks); the subclass is
+    written as the reference writes it -- ``super(TrainMIDIModel, self).__init__(config)`` then its own fields -- and its
+    training_step is the reference's (train.py:168-188) op for op on the public forward / forward_token surface."""
+    import torch.nn.functional as F
+    shp, sd, batch = tiny
+    g = golden("tiny_train.npz")
+
+    class StubLightningModule(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self._logged = {}
+            self.trainer = None
+
+        def log(self, name, value, **kw):
+            self._logged[name] = float(value.detach() if torch.is_tensor(value) else value)
+
+        def on_train_start(self):
+            return "hook"
+
+    class RefStyleTrainModel(mm.MIDIModel, StubLightningModule):
+        def __init__(self, config, lr=2e-4):
+            super(RefStyleTrainModel, self).__init__(config)
+            self.lr = lr
+            self.last_save_step = 0
+
+        def training_step(self, batch, batch_idx=0):  # train.py:168-188
+            x = batch[:, :-1].contiguous()
+            y = batch[:, 1:].contiguous()
+            hidden = self.forward(x)
+            hidden = hidden.reshape(-1, hidden.shape[-1])
+            y = y.reshape(-1, y.shape[-1])
+            x = y[:, :-1]
+            logits = self.forward_token(hidden, x)
+            loss = F.cross_entropy(logits.view(-1, self.tokenizer.vocab_size), y.view(-1), reduction="mean",
+                                   ignore_index=self.tokenizer.pad_id)
+            self.log("train/loss", loss)
+            return loss
+
+    assert [c.__name__ for c in RefStyleTrainModel.__mro__[:4]] == ["RefStyleTrainModel", "MIDIModel", "StubLightningModule", "Module"]
+    with emu_ops.install():
+        model = RefStyleTrainModel(tiny_config(), lr=1e-3)
+        assert model._logged == {} and model.on_train_start() == "hook" and model.lr == 1e-3   # both bases initialised
+        assert len(model.state_dict()) == len(sd) and isinstance(model, torch.nn.Module)
+        model.load_state_dict(sd, strict=True)
+        assert model.requires_grad_(True) is model and model.eval() is model and model.train() is model
+        loss = model.training_step(batch)
+        loss.backward()  # autograd through the drop-in's forward / forward_token (autograd.py)
+        assert abs(loss.item() - float(g["loss"])) < 3e-5 and abs(model._logged["train/loss"] - float(g["loss"])) < 3e-5
+        named = dict(model.named_parameters())
+        names = [str(n) for n in g["grad_names"]]
+        norms = np.array([named[n].grad.norm().item() for n in names])
+        np.testing.assert_allclose(norms, g["grad_norms"], rtol=5e-4, atol=1e-7)
+
+
 def test_grad_accumulation_averages_micro_batches(orc, tiny, tok):
     """accumulate_grad_batches=2 (the reference default, train.py:355): Lightning divides every micro-batch loss by the
     window length before its backward, so the window's gradient is the MEAN of the two micro-batch gradients (each
