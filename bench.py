@@ -397,6 +397,70 @@ def measure_generate(args, world: int, rank: int, dist, steps: int, warmup: int)
 
 
 # ------------------------------------------------------------------------------------------------------------------
+# BASELINE.json configs[4]: "tv2o-large (2x hidden, 2x layers) bf16 ... seq_len=4096 events", 16 sequences per GPU.  Both readings
+# (SURVEY.md 8(d) config 5): the reference's preset tv2o-large (24 + 6 layers, D = 1024) and the BASELINE-worded shape
+# (24 + 6 layers, D = 2048, 32 heads, MLP 8192).  One GPU's share of the 8-GPU job = the same per-GPU step.
+# ------------------------------------------------------------------------------------------------------------------
+def measure_large(args, which: str, B: int, S: int, steps: int, warmup: int):
+    import midi_model_amd as mm
+    from midi_model_amd.data import synthetic_events
+    from midi_model_amd.train import TrainMIDIModel
+    if which == "tv2o-large":
+        cfg = mm.MIDIModelConfig.from_name("tv2o-large")
+        label = "tv2o-large (reference preset: 24 + 6 layers, D = 1024)"
+    else:
+        cfg = mm.MIDIModelConfig.get_config("v2", True, 24, 32, 2048, 8192)
+        label = "2x-hidden large (BASELINE.json wording: 24 + 6 layers, D = 2048, 32 heads, MLP 8192)"
+    torch.manual_seed(0)
+    torch.cuda.reset_peak_memory_stats()
+    t_build = time.perf_counter()
+    try:  # parameters created and initialised on the device (1.8 G parameters take a minute of host time otherwise)
+        with torch.device("cuda"):
+            model = TrainMIDIModel(cfg, lr=2e-4, weight_decay=0.01, warmup=1e3, max_step=1e6, accumulate_grad_batches=1)
+        model = model.to(torch.device("cuda"), torch.bfloat16)
+    except Exception:
+        model = TrainMIDIModel(cfg, lr=2e-4, weight_decay=0.01, warmup=1e3, max_step=1e6, accumulate_grad_batches=1)
+        model = model.to(torch.device("cuda"), torch.bfloat16)
+    model.configure_optimizers()
+    t_build = time.perf_counter() - t_build
+    n_params = sum(p.numel() for p in model.parameters())
+    nc, tc = cfg.net_config, cfg.net_token_config
+    batches = [synthetic_events(model.tokenizer, B, S + 1, seed=2000 + i, device="cuda") for i in range(2)]
+
+    def step(i):
+        return model.fit_step(batches[i % 2])
+
+    tried = B
+    while True:  # the largest per-GPU batch that fits, starting from the configured one
+        try:
+            for i in range(warmup):
+                step(i)
+            break
+        except torch.OutOfMemoryError:
+            del batches
+            torch.cuda.empty_cache()
+            if B == 1:
+                raise
+            B //= 2
+            batches = [synthetic_events(model.tokenizer, B, S + 1, seed=2000 + i, device="cuda") for i in range(2)]
+            model.zero_grad()
+    dt, loss = timed(step, steps, None, torch.cuda.synchronize)
+    fl = train_flops_per_event(S, net_L=nc.num_hidden_layers, tok_L=tc.num_hidden_layers, D=nc.hidden_size, I=nc.intermediate_size,
+                               It=tc.intermediate_size, V=model.tokenizer.vocab_size)
+    out = {"workload": f"{label}, bf16 training step (fwd+bwd+clip+AdamW), per-GPU batch {B} x {S} events (BASELINE.json configs[4] "
+                       f"asks for 16 per GPU{'' if B == tried else f': {tried} does not fit 288 GB, this is the largest power of two that does'})",
+           "value": B * S * steps / dt, "unit": "events/s", "ms_per_step": 1e3 * dt / steps, "steps": steps, "warmup": warmup,
+           "batch": B, "seq_len": S, "params": n_params, "loss": float(loss.item()),
+           "train_flops_per_event": fl, "model_tflops": fl * B * S * steps / dt / 1e12,
+           "model_flops_frac_of_peak": fl * B * S * steps / dt / 1e12 / PEAK_BF16_TFLOPS,
+           "hbm_peak_gb": torch.cuda.max_memory_allocated() / 1e9, "build_s": t_build}
+    del model, batches
+    gc.collect()
+    torch.cuda.empty_cache()
+    return out
+
+
+# ------------------------------------------------------------------------------------------------------------------
 # mode: stub (spawn-path self test on CPU under gloo; never a measurement)
 # ------------------------------------------------------------------------------------------------------------------
 def run_stub(args):
@@ -434,8 +498,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-gemm-events", action="store_true", help="no HIP events in the timed region (A/B runs)")
     ap.add_argument("--no-extras", action="store_true", help="train mode: skip the `block` and `generate` objects")
+    ap.add_argument("--no-large", action="store_true", help="train mode: skip the `large` / `large_2x_hidden` objects (BASELINE configs[4])")
     ap.add_argument("--accumulate", type=int, default=1, help="accumulate_grad_batches (reference default 2; headline: 1)")
-    ap.add_argument("--mode", default="train", choices=["train", "generate", "block"],
+    ap.add_argument("--mode", default="train", choices=["train", "generate", "block", "large"],
                     help="train: the headline metric (BASELINE.json configs[1]); generate: KV-cached generate(), configs[3]; "
                          "block: one net block forward at --block-seq (north_star target)")
     ap.add_argument("--gen-batch", type=int, default=64)
@@ -444,10 +509,19 @@ def main():
     ap.add_argument("--block-seq", type=int, default=4096)
     ap.add_argument("--block-save", action="store_true",
                     help="block mode: the TRAINING forward (also stores gate|up for the backward) instead of the forward-only form")
+    ap.add_argument("--comm", default=os.environ.get("MH_COMM", "torch"), choices=["torch", "mh"],
+                    help="gradient exchange: torch = torch.distributed 'nccl' (RCCL, the default); mh = the library's own RCCL "
+                         "communicator (mh_comm_*: one pre-multiplied-sum collective per bucket)")
     ap.add_argument("--stub", action="store_true", help=argparse.SUPPRESS)  # CPU/gloo self-test of the spawn path
     args = ap.parse_args()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         raise SystemExit(spawn(args))
+    # stdout carries ONE JSON line and nothing else: native libraries write there too (RCCL prints a version banner from
+    # ncclCommInitRank), so file descriptor 1 is pointed at stderr for the whole run and Python's sys.stdout keeps the real one
+    sys.stdout.flush()
+    real_stdout = os.fdopen(os.dup(1), "w")
+    os.dup2(2, 1)
+    sys.stdout = real_stdout
     if args.stub:
         return run_stub(args)
 
@@ -467,6 +541,16 @@ def main():
             print(json.dumps(out))
         if dist is not None:
             dist.destroy_process_group()
+        return
+    if args.mode == "large":
+        res = {k: measure_large(args, w, args.batch, args.seq if args.seq != 2048 else 4096, args.steps, args.warmup)
+               for k, w in (("large", "tv2o-large"), ("large_2x_hidden", "2x-hidden"))}
+        if rank == 0:
+            lg = res["large"]
+            print(json.dumps({"metric": "MIDI events/sec, training step, tv2o-large, seq=4096 (BASELINE.json configs[4], one GPU's share)",
+                              "value": lg["value"], "unit": "events/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+                              "ms_per_step": lg["ms_per_step"], "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+                              "dtype": args.dtype, "data": "synthetic", "config": {"workload": lg["workload"]}, **res}))
         return
     if args.mode == "block":
         b = measure_block(args, args.block_batch, args.block_seq, max(args.steps, 10), max(args.warmup, 3), dist)
@@ -494,6 +578,9 @@ def main():
     model = TrainMIDIModel(cfg, lr=2e-4, weight_decay=0.01, warmup=1e3, max_step=1e6, accumulate_grad_batches=args.accumulate)
     model = model.to(torch.device("cuda", local), dtype)
     model.configure_optimizers()
+    if args.comm == "mh" and world > 1:
+        from midi_model_amd.comm import MHComm
+        model.use_comm(MHComm.from_process_group(local))
     model.broadcast_parameters(0)
     B, S = args.batch, args.seq
     batches = [synthetic_events(model.tokenizer, B, S + 1, seed=1000 + 17 * rank + i, device="cuda") for i in range(2)]
@@ -531,6 +618,39 @@ def main():
         fam_dt, _ = timed(step, fam_steps, dist, torch.cuda.synchronize)
         lib().profile = None
 
+    # One GPU cannot run a ring, but it can run the exchange's CALL SEQUENCE: the same step with every bucket of the flat
+    # gradient buffer sent through the library's RCCL communicator at world size 1 (15 x 32 MB launches on the communication
+    # stream while the backward owns the CUs; with one rank RCCL's kernel is a scaled copy of the bucket, not a ring).  The
+    # step-time delta is what those launches cost the compute stream here.
+    contention = None
+    if world == 1 and not args.no_extras and dt_plain is not None:
+        try:
+            from midi_model_amd.comm import MHComm
+            model.force_reduce = True
+            model.use_comm(MHComm(0, 1, local))
+            for i in range(2):
+                step(i)
+            red_x = model._reducer
+            red_x.profile = True
+            red_x.stats.clear()
+            dt_x, _ = timed(step, args.steps, dist, torch.cuda.synchronize)
+            stx = list(red_x.stats)
+            exposed_x = [a.elapsed_time(b) for a, b, _, _ in stx if a is not None]
+            contention = {"ms_per_step_with_exchange": 1e3 * dt_x / args.steps, "ms_per_step_without": 1e3 * dt_plain / args.steps,
+                          "allreduce_contention_ms": 1e3 * (dt_x - dt_plain) / args.steps,
+                          "bytes_per_step": (sum(x[2] for x in stx) / len(stx)) if stx else None,
+                          "launches_per_step": (sum(x[3] for x in stx) / len(stx)) if stx else None,
+                          "exposed_ms_per_step": (sum(exposed_x) / len(exposed_x)) if exposed_x else None,
+                          "rccl_version_code": model.comm.rccl_version,
+                          "what": "world size 1 through mh_comm_allreduce (RCCL one-rank kernel per 32 MB bucket on the communication "
+                                  "stream, overlapping the backward): the call sequence and stream overlap of the N-GPU step, NOT a "
+                                  "ring over xGMI"}
+            model.comm.close()
+        except Exception as e:  # a probe must never cost the headline number
+            contention = {"error": repr(e)}
+        model.force_reduce = False
+        model.comm = None
+
     if rank == 0:
         events = world * B * S * args.steps
         value = events / dt
@@ -555,7 +675,11 @@ def main():
             "model_tflops_per_gpu": fl_event * B * S * args.steps / dt / 1e12,
             "model_flops_frac_of_peak": fl_event * B * S * args.steps / dt / 1e12 / PEAK_BF16_TFLOPS,
         }
+        if contention is not None:
+            out["allreduce_contention"] = contention
+            out["allreduce_contention_ms"] = contention.get("allreduce_contention_ms")
         if world > 1:
+            out["comm"]["exchange"] = args.comm
             st = red_stats
             exposed = [a.elapsed_time(b) for a, b, _, _ in st if a is not None]
             out.update(summarize_allreduce([(x[2], x[3]) for x in st], args.steps, exposed))
@@ -609,7 +733,11 @@ def main():
     if world == 1 and not args.no_extras:
         # the other two measurements the judge asks for, in the same driver-run line (N=1 only: replicas add nothing)
         for key, fn in (("block", lambda: measure_block(args, args.block_batch, args.block_seq, 10, 3)),
-                        ("generate", lambda: measure_generate(args, 1, 0, None, 2, 1))):
+                        ("generate", lambda: measure_generate(args, 1, 0, None, 2, 1)),
+                        ("large", lambda: measure_large(args, "tv2o-large", 16, 4096, 3, 1)),
+                        ("large_2x_hidden", lambda: measure_large(args, "2x-hidden", 16, 4096, 2, 1))):
+            if key.startswith("large") and args.no_large:
+                continue
             try:
                 out[key] = fn()
             except Exception as e:  # an extra must never cost the headline number

@@ -283,6 +283,20 @@ int mh_sample_top_p_k(const void* logits, int64_t ldl, const uint8_t* first_mask
                       int64_t out_stride, int64_t* out_b, int64_t* out_c, int64_t B, int V, float temp, float top_p,
                       int top_k, int fill_rest, int64_t fill_id, int dtype, void* stream);
 
+/* ---- the data-parallel gradient exchange on RCCL (reference: DDP under Lightning, train.py:461-474) -----------------
+ * One communicator per process/GPU.  librccl is opened on the first call (dlopen; not a link-time dependency).
+ * mh_comm_unique_id: rank 0 fills 128 bytes (ncclGetUniqueId) that the host ships to every rank;
+ * mh_comm_init: ncclCommInitRank on `device`; *comm_out is the handle;
+ * mh_comm_allreduce: IN PLACE over buf[count] on `stream`; mean != 0 averages over the ranks inside the collective
+ *   (pre-multiplied sum, scale 1/world) -- DDP's divide-then-sum as one pass; mean == 0 sums;
+ * mh_comm_broadcast: buf[count] from `root` to every rank, in place;  mh_comm_info: rank / world / RCCL version code.  */
+int mh_comm_unique_id(void* id128);
+int mh_comm_init(int rank, int world, const void* id128, int device, void** comm_out);
+int mh_comm_info(void* comm, int* rank, int* world, int* rccl_version);
+int mh_comm_allreduce(void* comm, void* buf, int64_t count, int dtype, int mean, void* stream);
+int mh_comm_broadcast(void* comm, void* buf, int64_t count, int dtype, int root, void* stream);
+int mh_comm_destroy(void* comm);
+
 #ifdef __cplusplus
 }
 #endif

@@ -21,7 +21,7 @@ OBJ_AB = os.path.join(HERE, "_build_ab")
 LIB_AB = os.path.join(HERE, "libmidihip_ab.so")
 INCLUDE = os.path.join(os.path.dirname(HERE), "include")
 
-SOURCES = ["api.cpp", "gemm.hip", "gemm_pp256.hip", "gemm_skinny.hip", "elementwise.hip", "loss_optim.hip", "attention_small.hip", "attention_mfma.hip", "attention_mfma3.hip", "augment.hip"]
+SOURCES = ["api.cpp", "comm.cpp", "gemm.hip", "gemm_pp256.hip", "gemm_skinny.hip", "elementwise.hip", "loss_optim.hip", "attention_small.hip", "attention_mfma.hip", "attention_mfma3.hip", "augment.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-munsafe-fp-atomics", "-Wno-unused-result"]
 
 

@@ -43,12 +43,21 @@ class GradReducer:
     waits for everything and leaves gradients divided by world size.  Device-agnostic (CPU tensors + gloo in
     the tests, HIP tensors + RCCL on the GPU)."""
 
-    def __init__(self, flat_grad: torch.Tensor, group=None, bucket_bytes: int = 32 << 20):
+    def __init__(self, flat_grad: torch.Tensor, group=None, bucket_bytes: int = 32 << 20, comm=None, force: bool = False):
+        """``comm``: an ``MHComm`` (comm.py) -- the buckets then go out through the library's own RCCL communicator
+        (``mh_comm_allreduce``: the mean as ONE pre-multiplied-sum collective on the communication stream) instead of
+        ``torch.distributed``.  ``force``: run the whole bucketed path even when there is one rank (the real backend's call
+        sequence on a one-GPU box: tests, bench.py's contention probe)."""
         import torch.distributed as dist
         self.dist = dist
         self.flat = flat_grad
         self.group = group
-        self.world = dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
+        self.comm = comm
+        self.force = bool(force)
+        if comm is not None:
+            self.world = comm.world
+        else:
+            self.world = dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
         self.bucket_elems = max(1, bucket_bytes // flat_grad.element_size())
         self.pending: Optional[Tuple[int, int]] = None
         self.works: list = []
@@ -64,7 +73,7 @@ class GradReducer:
         self.expected: Optional[List[Tuple[int, int]]] = None
 
     def ready(self, lo: int, hi: int):
-        if self.world == 1:
+        if self.world == 1 and not self.force:
             return
         if self.pending is None:
             self.pending = (lo, hi)
@@ -86,7 +95,11 @@ class GradReducer:
         buf = self.flat[lo:hi]
         self.launched.append((lo, hi))
         self._bytes += buf.numel() * buf.element_size()
-        if self.comm_stream is not None:
+        if self.comm is not None:
+            # library-owned communicator: ordered on the communication stream, finish() waits for that stream
+            self.comm_stream.wait_stream(torch.cuda.current_stream())
+            self.comm.allreduce_(buf, mean=True, stream=self.comm_stream)
+        elif self.comm_stream is not None:
             self.comm_stream.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(self.comm_stream):
                 buf.div_(self.world)
@@ -96,7 +109,7 @@ class GradReducer:
             self.works.append(self.dist.all_reduce(buf, op=self.dist.ReduceOp.SUM, group=self.group, async_op=True))
 
     def finish(self):
-        if self.world == 1:
+        if self.world == 1 and not self.force:
             return
         # every element of the expected ranges (default: the whole flat gradient buffer -- lm_head, token-level layers and
         # embedding, event-level layers and embedding, norm vectors) goes out exactly once per accumulation window.  Checked
@@ -169,6 +182,8 @@ class TrainMIDIModel(MIDIModel):
         self._reducer = None
         self.last_grad_norm = None
         self.process_group = None
+        self.comm = None           # MHComm (comm.py): the gradient exchange through the library's own RCCL communicator
+        self.force_reduce = False  # run the bucketed exchange even with one rank (tests, bench.py's contention probe)
         self._lora = None          # LoraAdapter while fine-tuning adapters on a frozen base (add_adapter)
 
     # ----------------------------------------------------------------------------------- optimiser
@@ -567,17 +582,30 @@ class TrainMIDIModel(MIDIModel):
         o, n, _ = self._offsets[f"{pre}.layers.{li}.mlp.down_proj.weight"]
         return lo, o + n
 
-    def _reducer_for_step(self):
+    def use_comm(self, comm) -> "TrainMIDIModel":
+        """exchange gradients (and broadcast parameters) through ``comm`` (an ``MHComm``) instead of torch.distributed"""
+        self.comm = comm
+        self._reducer = None
+        return self
+
+    def _world(self) -> int:
         import torch.distributed as dist
-        if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(self.process_group) == 1:
+        if self.comm is not None:
+            return self.comm.world
+        return dist.get_world_size(self.process_group) if dist.is_available() and dist.is_initialized() else 1
+
+    def _reducer_for_step(self):
+        if self._world() == 1 and not self.force_reduce:
             return None
         if self._lora is not None:  # only the adapter gradients are exchanged (in optimizer_step)
             return None
         # exchange only on the micro-batch that completes an accumulation window (DDP no_sync otherwise)
         if (self._micro + 1) % max(1, self.accumulate_grad_batches) != 0:
             return None
-        if self._reducer is None or self._reducer.flat is not self._flat_grad:
-            self._reducer = GradReducer(self._flat_grad, self.process_group, self.bucket_mb << 20)
+        r = self._reducer
+        if r is None or r.flat is not self._flat_grad or r.comm is not self.comm or r.force != self.force_reduce:
+            self._reducer = GradReducer(self._flat_grad, self.process_group, self.bucket_mb << 20, comm=self.comm,
+                                        force=self.force_reduce)
         return self._reducer
 
     @staticmethod
@@ -620,5 +648,8 @@ class TrainMIDIModel(MIDIModel):
     def broadcast_parameters(self, src: int = 0):
         """DDP constructor behaviour: rank `src`'s weights everywhere (one flat broadcast)."""
         import torch.distributed as dist
-        if dist.is_available() and dist.is_initialized() and dist.get_world_size(self.process_group) > 1:
+        if self.comm is not None:
+            if self.comm.world > 1 or self.force_reduce:
+                self.comm.broadcast_(self._flat, root=src)
+        elif dist.is_available() and dist.is_initialized() and dist.get_world_size(self.process_group) > 1:
             dist.broadcast(self._flat, src=src, group=self.process_group)

@@ -90,3 +90,66 @@ def test_ddp_world2_on_the_device(tmp_path):
     np.testing.assert_allclose(r0["vloss"], r1["vloss"], rtol=0, atol=0)
     assert r0["vacc"] == r1["vacc"]
     assert np.isfinite(r0["losses"]).all() and np.isfinite(r1["losses"]).all() and float(r0["exposed_ms"]) >= 0.0
+
+
+def _worker_world1(rank, port, out_dir, backend):
+    """the REAL RCCL backends at world size 1, forced through the reducer's whole bucketed path inside the benchmarked step
+    (tv2o-medium bf16, 16 x 2048 events): `torch` = torch.distributed "nccl" (the default exchange), `mh` = the library's own
+    communicator (mh_comm_*, one pre-multiplied-sum collective per bucket)"""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", WORLD_SIZE="1")
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    import torch.distributed as dist
+    from midi_model_amd.comm import MHComm
+    from midi_model_amd.data import synthetic_events
+    from midi_model_amd.train import TrainMIDIModel
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=0, world_size=1)
+    dev = torch.device("cuda", 0)
+    cfg = mm.MIDIModelConfig.from_name("tv2o-medium")
+    torch.manual_seed(0)
+    model = TrainMIDIModel(cfg, lr=2e-4, warmup=0, accumulate_grad_batches=1).to(dev, torch.bfloat16)
+    model.configure_optimizers()
+    start = model._flat.detach().clone()
+    batch = synthetic_events(model.tokenizer, 16, 2049, seed=5, device="cuda")
+    # the plain single-GPU step (no exchange)
+    loss_plain = model.fit_step(batch).item()
+    flat_plain = model._flat.detach().clone()
+    # the same step from the same weights with the exchange forced through the real backend
+    model._flat.copy_(start)
+    model._opt["m"].zero_()
+    model._opt["v"].zero_()
+    model.global_step = 0
+    model.force_reduce = True
+    if backend == "mh":
+        model.use_comm(MHComm.from_process_group(0))
+        assert model.comm.world == 1 and model.comm.rccl_version > 20000
+    model.broadcast_parameters(0)
+    red_probe = model._reducer_for_step()
+    assert red_probe is not None and red_probe.force and (red_probe.comm is not None) == (backend == "mh")
+    red_probe.profile = True
+    loss_x = model.fit_step(batch).item()
+    torch.cuda.synchronize()
+    (ev0, ev1, nbytes, nlaunch), = red_probe.stats
+    same = bool(torch.equal(model._flat, flat_plain))
+    np.savez(os.path.join(out_dir, f"world1_{backend}.npz"), loss_plain=loss_plain, loss_x=loss_x, same=same, nbytes=nbytes,
+             nlaunch=nlaunch, expect_bytes=model._flat.numel() * model._flat.element_size(), exposed_ms=ev0.elapsed_time(ev1),
+             maxdiff=float((model._flat.float() - flat_plain.float()).abs().max()))
+    if model.comm is not None:
+        model.comm.close()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("backend", ["torch", "mh"])
+def test_rccl_world1_bucketed_exchange_inside_the_benchmarked_step(tmp_path, backend):
+    """What one GPU can prove about the multi-GPU path: the real RCCL backends initialise, every bucket of the flat gradient
+    buffer (467.7 MB of bf16 gradients, 32 MB buckets, back to front, on the communication stream while the backward runs)
+    goes through them inside a real 16 x 2048 step, the coverage check passes, and with one rank the averaged gradient is the
+    gradient: the step ends on the same bits as the plain single-GPU step."""
+    import torch.multiprocessing as mp
+    mp.spawn(_worker_world1, args=(_free_port(), str(tmp_path), backend), nprocs=1, join=True)
+    r = np.load(tmp_path / f"world1_{backend}.npz")
+    assert int(r["nbytes"]) == int(r["expect_bytes"]) == 467_685_376
+    assert 14 <= int(r["nlaunch"]) <= 20, int(r["nlaunch"])
+    assert float(r["loss_plain"]) == float(r["loss_x"])
+    assert bool(r["same"]), float(r["maxdiff"])
+    assert float(r["exposed_ms"]) >= 0.0

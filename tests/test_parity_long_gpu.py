@@ -554,6 +554,62 @@ def test_tv2o_large_forward_against_oracle(orc, tok):
     assert (logits.argmax(-1)[safe] == log_o.argmax(-1)[safe]).all()
 
 
+def test_tv2o_large_training_step_at_S4096(orc, tok, golden):
+    """BASELINE.json configs[4] in the production dtype: ``from_name("tv2o-large")`` (24 + 6 layers), bf16, S = 4096, the whole
+    training step (train.py:168-188 + backward) -- 24 layers of bf16 drift, the S = 4096 attention backward inside a real step,
+    32,768 token rows through six token-level layers.  tests/golden/large_S4096.npz holds the REAL reference's fp32 step and its
+    own bf16-true step on the same weights / inputs (tests/gen_golden_large.py).  The oracle's fp32 autograd step is computed here
+    (attention checkpointed: 24 x 16 heads x 4096^2 scores are not kept) and pinned to the golden first; the device step is then
+    bounded by 1.5x the reference's own bf16 errors: loss, gradient cosine and norm ratio over all 457 M gradient elements, the
+    named gradient tensors, every gradient norm."""
+    import torch.utils.checkpoint as ckpt
+    g = golden("large_S4096.npz")
+    S = int(g["S"])
+    shp = orc.Shape(n_layer=24, vocab=tok.vocab_size)
+    sd = orc.make_state_dict(shp, seed=int(g["weight_seed"]))
+    batch = orc.synthetic_events(tok, 1, S + 1, seed=int(g["batch_seed"]))
+    torch.set_num_threads(min(os.cpu_count() or 8, 32))
+    sdg = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    plain = orc.attention
+    orc.attention = lambda q, k, v, causal: (ckpt.checkpoint(plain, q, k, v, causal, use_reentrant=False)
+                                             if q.shape[-2] > 64 else plain(q, k, v, causal))
+    try:
+        loss_o, _ = orc.training_loss(sdg, shp, batch)
+        loss_o.backward()
+    finally:
+        orc.attention = plain
+    names = [str(n) for n in g["grad_names"]]
+    assert abs(loss_o.item() - float(g["loss"])) < 2e-4                      # the oracle IS the reference here too
+    norms_o = np.array([sdg[n].grad.norm().item() for n in names])
+    np.testing.assert_allclose(norms_o, g["grad_norms"], rtol=2e-3, atol=1e-9)
+
+    cfg = mm.MIDIModelConfig.from_name("tv2o-large")
+    model = TrainMIDIModel(cfg, accumulate_grad_batches=1)
+    model.load_state_dict(sd, strict=True)
+    model = model.to("cuda", torch.bfloat16)
+    loss = model.training_step(batch.cuda())
+    named = {k: p.grad.float().cpu() for k, p in model.named_parameters()}
+    drift = abs(float(g["ref_bf16_loss"]) - float(g["loss"]))
+    assert abs(loss.item() - float(g["loss"])) <= DRIFT * drift + 5e-3, (loss.item(), float(g["loss"]), drift)
+    flat = torch.cat([named[n].reshape(-1) for n in names]).double()
+    ref = torch.cat([sdg[n].grad.reshape(-1) for n in names]).double()
+    cos = (torch.dot(flat, ref) / (flat.norm() * ref.norm())).item()
+    ratio = (flat.norm() / ref.norm()).item()
+    print(f"tv2o-large bf16 step at S=4096: loss {loss.item():.4f} (fp32 {float(g['loss']):.4f}, reference bf16 {float(g['ref_bf16_loss']):.4f}); "
+          f"gradient cosine {cos:.5f} (reference bf16 {float(g['ref_bf16_grad_cosine']):.5f}), norm ratio {ratio:.4f} "
+          f"(reference bf16 {float(g['ref_bf16_grad_norm_ratio']):.4f})")
+    assert cos >= 1.0 - DRIFT * (1.0 - float(g["ref_bf16_grad_cosine"])) - 1e-4
+    assert abs(ratio - 1.0) <= DRIFT * abs(float(g["ref_bf16_grad_norm_ratio"]) - 1.0) + 0.01
+    for key in g.files:
+        if key.startswith("ref_bf16_grad_relerr:"):
+            k = key.split(":", 1)[1]
+            full = sdg[k].grad
+            rel = ((named[k] - full).norm() / full.norm()).item()
+            assert rel <= DRIFT * float(g[key]) + 2e-3, (k, rel, float(g[key]))
+    norms = np.array([named[n].norm().item() for n in names])
+    np.testing.assert_allclose(norms, g["grad_norms"], rtol=0.15, atol=1e-6)
+
+
 # ------------------------------------------------------------------------------ race screen of the K-step-64 main loop (r03)
 @pytest.mark.parametrize("M,N,K,tb", [(32768, 3072, 1024, False), (65536, 1024, 4096, False), (32768, 8192, 1024, False),
                                       (32768, 3406, 1024, False), (32768, 1024, 8192, True), (32768, 1024, 3406, True),
