@@ -10,6 +10,9 @@ import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from midi_model_amd import ops  # noqa: E402
 
+_AB = ops.ab_library()  # a measurement tool: the compared kernel forms live in libmidihip_ab.so (build.py, -DMH_AB_BUILDS)
+_AB.__enter__()
+
 SHAPES = [  # (M, N, K, ta, tb, calls per step)
     (32768, 3072, 1024, 0, 0, 12), (32768, 1024, 1024, 0, 0, 12), (32768, 8192, 1024, 0, 0, 12), (32768, 1024, 4096, 0, 0, 12),
     (262144, 3072, 1024, 0, 0, 3), (262144, 1024, 1024, 0, 0, 6), (262144, 2048, 1024, 0, 0, 3), (32768, 3406, 1024, 0, 0, 8),

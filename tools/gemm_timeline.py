@@ -9,6 +9,9 @@ import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from midi_model_amd import ops  # noqa: E402
+
+_AB = ops.ab_library()  # a measurement tool: the compared kernel forms live in libmidihip_ab.so (build.py, -DMH_AB_BUILDS)
+_AB.__enter__()
 from midi_model_amd.lib import lib  # noqa: E402
 
 variants = [1]
