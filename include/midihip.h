@@ -254,6 +254,17 @@ int mh_attn_decode(const void* qkv, const void* kcache, const void* vcache, void
 int mh_attn_decode_append(const void* qkv, const float* cos_t, const float* sin_t, void* kcache, void* vcache, void* o,
                           int64_t B, int H, int hd, int64_t Lmax, int64_t pos, float scale, const int32_t* pos_dev,
                           int dtype, void* stream);
+/* A chunk of q_len > 1 new positions behind n cached ones (a cache-carrying forward, midi_model.py:137-150 with a non-empty
+ * DynamicCache; TF:integrations/sdpa_attention.py:79-166): mh_kv_store_rows appends the chunk's rotated K and V at cache rows
+ * [pos0, pos0 + S); mh_kv_gather_rows copies cache rows [0, n) into the K and V columns of rows [b*Stot, b*Stot + n) of a fused
+ * qkv buffer [B*Stot, 3*H*hd] (q columns zeroed); mh_attn_fwd_tail is mh_attn_fwd over that buffer computing only the query
+ * rows >= q_start (whole query tiles: rows of the first tile below q_start are written too and are not meaningful).        */
+int mh_kv_store_rows(const void* qkv, void* kcache, void* vcache, int64_t B, int64_t S, int H, int hd, int64_t Lmax,
+                     int64_t pos0, int dtype, void* stream);
+int mh_kv_gather_rows(const void* kcache, const void* vcache, void* qkv, int64_t B, int64_t n, int64_t Stot, int H, int hd,
+                      int64_t Lmax, int dtype, void* stream);
+int mh_attn_fwd_tail(const void* qkv, void* o, float* lse, int64_t B, int64_t S, int H, float scale, int64_t q_start,
+                     int dtype, void* stream);
 /* copy rotated K and V of a prefill (qkv[B*S,3*H*hd]) into the cache rows [0,S).                           */
 int mh_kv_store_prefill(const void* qkv, void* kcache, void* vcache, int64_t B, int64_t S, int H, int hd,
                         int64_t Lmax, int dtype, void* stream);

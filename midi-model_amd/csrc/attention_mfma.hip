@@ -427,16 +427,17 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const bf16* __rest
 extern thread_local int g_attn_v3;  // attention_mfma3.hip: the third form of the three kernels (bit 0 forward, bit 1 dQ, bit 2 dK/dV, bit 3
                        // transpose reads in the backward pair instead of the prepared copies)
 int mh_attn_fwd_mfma3(const void* qkv, const void* vt, void* o, float* lse, int64_t B, int64_t S, int H, float scale,
-                      hipStream_t st);
+                      hipStream_t st, int64_t q_start = 0);
 int mh_attn_bwd_mfma3(const void* qkv, const void* dout, const float* lse, const float* delta, const void* qt, const void* kt,
                       const void* dot, void* dqkv, int64_t B, int64_t S, int H, float scale, const float* cos_t,
                       const float* sin_t, int which, hipStream_t st, const void* o = nullptr);
 
 int mh_attn_fwd_mfma(const void* qkv, const void* vt, void* o, float* lse, int64_t B, int64_t S, int H, float scale,
-                     hipStream_t st) {
+                     hipStream_t st, int64_t q_start) {
   MH_REQUIRE(S < (1 << 24), "attn_fwd: sequence too long");
   if ((g_attn_v3 & 1) && (vt != nullptr || (g_attn_v3 & 16)))  // (vt == NULL + bit 4: V through transpose reads)
-    return mh_attn_fwd_mfma3(qkv, vt, o, lse, B, S, H, scale, st);
+    return mh_attn_fwd_mfma3(qkv, vt, o, lse, B, S, H, scale, st, q_start);
+  MH_REQUIRE(q_start == 0, "attn_fwd_tail: served by the third form of the forward kernel only");
 #ifndef MH_AB_BUILDS
   MH_REQUIRE(false, "attn_fwd(bf16): option attn_v3 = %d selects the first form of the kernel, which is only in the A/B test "
              "library (libmidihip_ab.so)", g_attn_v3);

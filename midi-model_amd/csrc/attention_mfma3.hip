@@ -160,7 +160,9 @@ __device__ inline void fwd3_tile(const char* tK, const char* tV, const int (&tro
 template <int WPS, bool TR, int NS = 2 /* K/V stages in LDS: tile kt + NS - 1 is requested while tile kt is computed */>
 __global__ __launch_bounds__(256, WPS) void attn_fwd3_kernel(const bf16* __restrict__ qkv, const bf16* __restrict__ vt,
                                                           bf16* __restrict__ o, float* __restrict__ lse, int S, int Sp, int H,
-                                                          float sc /* scale*log2(e) */, int BH, int nqt) {
+                                                          float sc /* scale*log2(e) */, int BH, int nqt,
+                                                          int nqt_all /* 128-row query tiles of the sequence; the launch covers the
+                                                                         LAST nqt of them (mh_attn_fwd_tail: a chunk behind cached rows) */) {
   extern __shared__ __attribute__((aligned(16))) char smem[];  // 4 tiles = [stage][K | V^T] (dynamic: see attn_fwd_kernel)
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -170,7 +172,7 @@ __global__ __launch_bounds__(256, WPS) void attn_fwd3_kernel(const bf16* __restr
   const int64_t b = bh / H;
   const int h = (int)(bh - b * H);
   const int64_t D = (int64_t)H * HD, D3 = 3 * D;
-  const int q0 = (nqt - 1 - tile_) * 128;  // heavy (late) query tiles first
+  const int q0 = (nqt_all - 1 - tile_) * 128;  // heavy (late) query tiles first
   const int qw0 = q0 + wave * 32;
   const int li = lane & 31, hi = lane >> 5;
   const int qrow = qw0 + li;
@@ -725,17 +727,19 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv3_kernel(const bf16* __res
 }
 
 int mh_attn_fwd_mfma3(const void* qkv, const void* vt, void* o, float* lse, int64_t B, int64_t S, int H, float scale,
-                      hipStream_t st) {
+                      hipStream_t st, int64_t q_start) {
   MH_REQUIRE(S * 3 * H * HD < (int64_t(1) << 31), "attn_fwd: sequence too long (32-bit panel offsets)");
+  MH_REQUIRE(q_start >= 0 && q_start < S, "attn_fwd: q_start %ld outside the sequence", (long)q_start);
   const int64_t Sp = (S + 63) / 64 * 64;
-  const int nt = (int)((S + 127) / 128), BH = (int)(B * H);
+  const int nt_all = (int)((S + 127) / 128), BH = (int)(B * H);
+  const int nt = nt_all - (int)(q_start / 128);  // query tiles holding rows >= q_start (the first of them may start below it)
   const unsigned grid = (unsigned)(nt * 8 * ((BH + 7) / 8));
 #define MH_FWD(WPS, TR_)                                                                                                    \
   attn_fwd3_kernel<WPS, TR_><<<grid, 256, 4 * TILE64, st>>>((const bf16*)qkv, (const bf16*)vt, (bf16*)o, lse, (int)S, (int)Sp, H, \
-                                                          scale * LOG2E, BH, nt)
+                                                          scale * LOG2E, BH, nt, nt_all)
 #define MH_FWD3S(WPS, TR_)                                                                                                  \
   attn_fwd3_kernel<WPS, TR_, 3><<<grid, 256, 6 * TILE64, st>>>((const bf16*)qkv, (const bf16*)vt, (bf16*)o, lse, (int)S, (int)Sp, \
-                                                             H, scale * LOG2E, BH, nt)
+                                                             H, scale * LOG2E, BH, nt, nt_all)
   const bool tr = (vt == nullptr);  // no prepared V^T copy: transpose reads
   // (register budget: with transpose reads the 256-register build measured 1-2 % ahead, with the prepared copy the
   //  168-register one; both fit three waves per SIMD -- profiles/r02_run18_attn_forms_ab.txt)

@@ -386,7 +386,7 @@ extern "C" int mh_kv_append(void* qkv, const float* cos_t, const float* sin_t, v
 template <typename T>
 __global__ __launch_bounds__(256) void kv_store_prefill_kernel(const T* __restrict__ qkv, T* __restrict__ kc,
                                                                T* __restrict__ vc, int64_t B, int64_t S, int H, int hd,
-                                                               int64_t Lmax) {
+                                                               int64_t Lmax, int64_t pos0) {
   constexpr int N = Pack<T>::N;
   const int cph = hd / N;
   const int64_t total = B * S * H * cph;
@@ -398,20 +398,64 @@ __global__ __launch_bounds__(256) void kv_store_prefill_kernel(const T* __restri
     r /= H;
     const int64_t s = r % S, b = r / S;
     const T* row = qkv + (b * S + s) * 3 * D + (int64_t)h * hd + c * N;
-    const int64_t dst = ((b * H + h) * Lmax + s) * hd + c * N;
+    const int64_t dst = ((b * H + h) * Lmax + pos0 + s) * hd + c * N;
     st16(kc + dst, ld16(row + D));
     st16(vc + dst, ld16(row + 2 * D));
   }
 }
 
-extern "C" int mh_kv_store_prefill(const void* qkv, void* kcache, void* vcache, int64_t B, int64_t S, int H, int hd,
-                                   int64_t Lmax, int dtype, void* stream) {
-  MH_REQUIRE(B > 0 && S > 0 && S <= Lmax && hd % 8 == 0, "kv_store_prefill: bad args");
+extern "C" int mh_kv_store_rows(const void* qkv, void* kcache, void* vcache, int64_t B, int64_t S, int H, int hd, int64_t Lmax,
+                                int64_t pos0, int dtype, void* stream) {
+  MH_REQUIRE(B > 0 && S > 0 && pos0 >= 0 && pos0 + S <= Lmax && hd % 8 == 0, "kv_store_rows: bad args");
   const int64_t total = B * S * H * (hd / (dtype == MH_BF16 ? 8 : 4));
   int64_t g = (total + 255) / 256;
   if (g > 16384) g = 16384;
   DISPATCH_T(dtype, (kv_store_prefill_kernel<T><<<(int)g, 256, 0, (hipStream_t)stream>>>((const T*)qkv, (T*)kcache,
-                                                                                         (T*)vcache, B, S, H, hd, Lmax)));
+                                                                                         (T*)vcache, B, S, H, hd, Lmax, pos0)));
+  MH_LAUNCH_CHECK();
+  return MH_OK;
+}
+
+extern "C" int mh_kv_store_prefill(const void* qkv, void* kcache, void* vcache, int64_t B, int64_t S, int H, int hd,
+                                   int64_t Lmax, int dtype, void* stream) {
+  return mh_kv_store_rows(qkv, kcache, vcache, B, S, H, hd, Lmax, 0, dtype, stream);
+}
+
+// cache rows [0, n) of every (sequence, head) back into the K and V columns of rows [b * Stot, b * Stot + n) of a fused
+// qkv buffer [B * Stot, 3 H hd] (their q columns are zeroed: those query rows are never used); the inverse of kv_store_rows
+template <typename T>
+__global__ __launch_bounds__(256) void kv_gather_rows_kernel(const T* __restrict__ kc, const T* __restrict__ vc,
+                                                             T* __restrict__ qkv, int64_t B, int64_t n, int64_t Stot, int H, int hd,
+                                                             int64_t Lmax) {
+  constexpr int N = Pack<T>::N;
+  const int cph = hd / N;
+  const int64_t total = B * n * H * cph;
+  const int64_t D = (int64_t)H * hd;
+  Pack<T> z;
+#pragma unroll
+  for (int i = 0; i < N; ++i) z.set(i, 0.f);
+  for (int64_t it = (int64_t)blockIdx.x * 256 + threadIdx.x; it < total; it += (int64_t)gridDim.x * 256) {
+    const int c = (int)(it % cph);
+    int64_t r = it / cph;
+    const int h = (int)(r % H);
+    r /= H;
+    const int64_t s = r % n, b = r / n;
+    T* row = qkv + (b * Stot + s) * 3 * D + (int64_t)h * hd + c * N;
+    const int64_t src = ((b * H + h) * Lmax + s) * hd + c * N;
+    st16(row, z);
+    st16(row + D, ld16(kc + src));
+    st16(row + 2 * D, ld16(vc + src));
+  }
+}
+
+extern "C" int mh_kv_gather_rows(const void* kcache, const void* vcache, void* qkv, int64_t B, int64_t n, int64_t Stot, int H,
+                                 int hd, int64_t Lmax, int dtype, void* stream) {
+  MH_REQUIRE(B > 0 && n > 0 && n <= Stot && n <= Lmax && hd % 8 == 0, "kv_gather_rows: bad args");
+  const int64_t total = B * n * H * (hd / (dtype == MH_BF16 ? 8 : 4));
+  int64_t g = (total + 255) / 256;
+  if (g > 16384) g = 16384;
+  DISPATCH_T(dtype, (kv_gather_rows_kernel<T><<<(int)g, 256, 0, (hipStream_t)stream>>>((const T*)kcache, (const T*)vcache,
+                                                                                       (T*)qkv, B, n, Stot, H, hd, Lmax)));
   MH_LAUNCH_CHECK();
   return MH_OK;
 }
@@ -643,13 +687,14 @@ constexpr int AHD = 64;
 
 template <typename T>
 __global__ __launch_bounds__(64) void attn_plain_fwd_kernel(const T* __restrict__ qkv, T* __restrict__ o,
-                                                            float* __restrict__ lse, int64_t S, int H, float scale) {
+                                                            float* __restrict__ lse, int64_t S, int H, float scale,
+                                                            int first_block /* query blocks below it are not computed */) {
   __shared__ float ks[32][AHD], vs[32][AHD];
   const int64_t bh = blockIdx.y;
   const int64_t b = bh / H;
   const int h = (int)(bh - b * H);
   const int64_t D = (int64_t)H * AHD, D3 = 3 * D;
-  const int64_t q0 = (int64_t)blockIdx.x * 64;
+  const int64_t q0 = (int64_t)(blockIdx.x + first_block) * 64;
   const int64_t qi = q0 + threadIdx.x;
   const bool valid = qi < S;
   float q[AHD], acc[AHD];
@@ -914,7 +959,7 @@ extern "C" int mh_attn_prep_bwd(const void* qkv, const void* o, const void* dout
 
 // entry points shared with attention_mfma.hip (bf16 goes there)
 int mh_attn_fwd_mfma(const void* qkv, const void* vt, void* o, float* lse, int64_t B, int64_t S, int H, float scale,
-                     hipStream_t st);
+                     hipStream_t st, int64_t q_start);
 int mh_attn_bwd_mfma(const void* qkv, const void* dout, const float* lse, const float* delta, const void* qt,
                      const void* kt, const void* dot, void* dqkv, int64_t B, int64_t S, int H, float scale,
                      const float* cos_t, const float* sin_t, hipStream_t st);
@@ -923,9 +968,11 @@ int mh_attn_bwd_o_mfma(const void* qkv, const void* o, const void* dout, const f
                        int64_t S, int H, float scale, const float* cos_t, const float* sin_t, hipStream_t st);
 
 template <typename T>
-static int attn_plain_fwd(const void* qkv, void* o, float* lse, int64_t B, int64_t S, int H, float scale, hipStream_t st) {
-  dim3 grid((unsigned)((S + 63) / 64), (unsigned)(B * H));
-  attn_plain_fwd_kernel<T><<<grid, 64, 0, st>>>((const T*)qkv, (T*)o, lse, S, H, scale);
+static int attn_plain_fwd(const void* qkv, void* o, float* lse, int64_t B, int64_t S, int H, float scale, hipStream_t st,
+                          int64_t q_start = 0) {
+  const int first = (int)(q_start / 64);
+  dim3 grid((unsigned)((S + 63) / 64 - first), (unsigned)(B * H));
+  attn_plain_fwd_kernel<T><<<grid, 64, 0, st>>>((const T*)qkv, (T*)o, lse, S, H, scale, first);
   MH_LAUNCH_CHECK();
   return MH_OK;
 }
@@ -958,9 +1005,22 @@ extern "C" int mh_attn_bwd_plain(const void* qkv, const void* dout, const float*
 extern "C" int mh_attn_fwd(const void* qkv, const void* vt, void* o, float* lse, int64_t B, int64_t S, int H, float scale,
                            int dtype, void* stream) {
   MH_REQUIRE(B > 0 && S > 0 && H > 0 && B * H < 65536, "attn_fwd: bad shape");
-  if (dtype == MH_BF16) return mh_attn_fwd_mfma(qkv, vt, o, lse, B, S, H, scale, (hipStream_t)stream);
+  if (dtype == MH_BF16) return mh_attn_fwd_mfma(qkv, vt, o, lse, B, S, H, scale, (hipStream_t)stream, 0);
   if (dtype == MH_F32) return attn_plain_fwd<float>(qkv, o, lse, B, S, H, scale, (hipStream_t)stream);
   mh_set_error("attn_fwd: bad dtype");
+  return MH_ERR_ARG;
+}
+
+// A chunk of new positions behind cached ones (a cache-carrying forward with q_len > 1, TF:integrations/sdpa_attention.py:79-166
+// with a non-empty DynamicCache): the rows of qkv hold the whole sequence so far -- K, V of the cached positions gathered back
+// from the cache (mh_kv_gather_rows), q | k | v of the new ones -- and only the query rows >= q_start are computed (whole
+// 128-row / 64-row query tiles: rows of the first tile below q_start are computed too and ignored by the caller).
+extern "C" int mh_attn_fwd_tail(const void* qkv, void* o, float* lse, int64_t B, int64_t S, int H, float scale, int64_t q_start,
+                                int dtype, void* stream) {
+  MH_REQUIRE(B > 0 && S > 0 && H > 0 && B * H < 65536 && q_start >= 0 && q_start < S, "attn_fwd_tail: bad shape");
+  if (dtype == MH_BF16) return mh_attn_fwd_mfma(qkv, nullptr, o, lse, B, S, H, scale, (hipStream_t)stream, q_start);
+  if (dtype == MH_F32) return attn_plain_fwd<float>(qkv, o, lse, B, S, H, scale, (hipStream_t)stream, q_start);
+  mh_set_error("attn_fwd_tail: bad dtype");
   return MH_ERR_ARG;
 }
 

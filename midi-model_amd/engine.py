@@ -266,6 +266,58 @@ def stack_prefill(spec: StackSpec, W: StackTensors, x: torch.Tensor, nseq: int, 
     return y
 
 
+def stack_extend(spec: StackSpec, W: StackTensors, x: torch.Tensor, nseq: int, slen: int, rope: RopeTable, kv: KVState):
+    """A chunk of ``slen`` > 1 new positions per sequence behind ``kv.len`` cached ones (a cache-carrying forward with q_len > 1:
+    chunked prefill, TF:models/llama/modeling_llama.py:386-389 position offset + TF:integrations/sdpa_attention.py:79-166).
+    Per layer: the chunk's q|k|v projection rotated at positions [n, n + slen), K/V appended to the cache, the cached K/V rows
+    gathered in front of the chunk's rows, and the flash forward over the n + slen rows computing the chunk's query tiles only --
+    the same ~9 launches per layer whatever ``slen`` is (the event-by-event form this replaces took 5 x slen).  Event-level
+    stack (heads of 64)."""
+    _check_heads(spec)
+    assert spec.kind == "event"
+    M, D = x.shape
+    assert M == nseq * slen
+    n, H, I, hd = kv.len, spec.H, spec.I, spec.hd
+    stot = n + slen
+    kv.reserve(stot)
+    rope.ensure(stot)
+    for li, lw in enumerate(W.layers):
+        h1 = _empty((M, D), x)
+        ops.rmsnorm_fwd(x, lw.n1, h1, None, spec.eps)
+        qkv = _empty((M, 3 * D), x)
+        if ops.rope_fused_ok(h1, hd):
+            ops.gemm_rope(h1, lw.wqkv, qkv, rope.fused(), slen, n, hd)
+        else:
+            ops.gemm_nt(h1, lw.wqkv, qkv)
+            ops.rope_(qkv, rope.cos, rope.sin, slen, n, H, hd, +1)
+        ops.kv_store_rows(qkv, kv.k[li], kv.v[li], nseq, slen, H, hd, kv.cap, n)
+        full = _empty((nseq * stot, 3 * D), x)
+        ops.kv_gather_rows(kv.k[li], kv.v[li], full, nseq, n, stot, H, hd, kv.cap)
+        full.view(nseq, stot, 3 * D)[:, n:].copy_(qkv.view(nseq, slen, 3 * D))
+        o_full = _empty((nseq * stot, D), x)
+        lse = _empty((nseq * H * ops.round_up(stot, 64),), x, torch.float32)
+        ops.attn_fwd_tail(full, o_full, lse, nseq, stot, H, spec.scale, n)
+        o = o_full.view(nseq, stot, D)[:, n:].reshape(M, D)
+        x2 = _empty((M, D), x)
+        ops.gemm_nt(o, lw.wo, x2, beta=1.0, res=x)
+        h2 = _empty((M, D), x)
+        ops.rmsnorm_fwd(x2, lw.n2, h2, None, spec.eps)
+        a = _empty((M, I), x)
+        if ops.swiglu_fused_ok(h2, I):
+            ops.gemm_swiglu(h2, lw.wgu, None, a)
+        else:
+            gu = _empty((M, 2 * I), x)
+            ops.gemm_nt(h2, lw.wgu, gu)
+            ops.swiglu_fwd(gu, a)
+        x3 = _empty((M, D), x)
+        ops.gemm_nt(a, lw.wd, x3, beta=1.0, res=x2)
+        x = x3
+    kv.len = stot
+    y = _empty((M, D), x)
+    ops.rmsnorm_fwd(x, W.norm, y, None, spec.eps)
+    return y
+
+
 def fold_norm_weights(W: StackTensors, out=None):
     """[(wqkv * n1, wgu * n2) per layer]: the RMSNorm weights folded into the projections that follow them, for the
     decode path's one-launch norm + projection (mh_gemm_skinny with norm_eps).  Derived data: with ``out`` (a list this

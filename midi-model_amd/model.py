@@ -302,7 +302,7 @@ class MIDIModel(nn.Module):
         Without ``cache`` the call is differentiable (an autograd node that runs the explicit backward
         schedule).  With ``cache`` (any object; HF DynamicCache instances are accepted) K/V go to
         preallocated buffers attached to it: an empty cache is prefilled causally, afterwards one event per
-        call is decoded."""
+        call is decoded, or a chunk of S > 1 events is appended in one pass (``engine.stack_extend``)."""
         self._require_gpu()
         if x.dim() != 3:
             raise ValueError(f"expected (batch, events, tokens) ids, got shape {tuple(x.shape)}")
@@ -326,11 +326,10 @@ class MIDIModel(nn.Module):
                 return y.view(B, S, spec.D)
             if st.B != B:
                 raise ValueError(f"cache was built for batch {st.B}, got {B}")
-            outs = []
-            for s in range(S):  # chunked continuation: one event at a time
-                xs = e.view(B, S, spec.D)[:, s].contiguous() if S > 1 else e
-                outs.append(engine.stack_decode(spec, self._W["net"], xs, self.rope("net"), st))
-            return outs[0].view(B, 1, spec.D) if S == 1 else torch.stack(outs, dim=1)
+            if S == 1:  # one event per call: the decode step
+                return engine.stack_decode(spec, self._W["net"], e, self.rope("net"), st).view(B, 1, spec.D)
+            # chunked continuation: the S new events attend to the cached ones and causally to each other
+            return engine.stack_extend(spec, self._W["net"], e, B, S, self.rope("net"), st).view(B, S, spec.D)
 
     def forward_token(self, hidden_state=None, x=None, cache=None) -> torch.Tensor:
         """hidden_state (N, n_embd) and/or x (N, t) int64 -> logits (N, [1]+t, vocab)   [midi_model.py:116-135]"""

@@ -504,6 +504,22 @@ def attn_decode_append(qkv, cos_t, sin_t, kc, vc, o, B: int, H: int, hd: int, Lm
     return o
 
 
+def kv_store_rows(qkv, kc, vc, B: int, S: int, H: int, hd: int, Lmax: int, pos0: int):
+    """the rotated K, V of a chunk of S positions -> cache rows [pos0, pos0 + S)"""
+    lib().call("mh_kv_store_rows", _p(qkv), _p(kc), _p(vc), B, S, H, hd, Lmax, pos0, dt(qkv), _stream())
+
+
+def kv_gather_rows(kc, vc, qkv, B: int, n: int, Stot: int, H: int, hd: int, Lmax: int):
+    """cache rows [0, n) -> K, V columns of rows [b*Stot, b*Stot + n) of qkv [B*Stot, 3*H*hd] (their q columns zeroed)"""
+    lib().call("mh_kv_gather_rows", _p(kc), _p(vc), _p(qkv), B, n, Stot, H, hd, Lmax, dt(qkv), _stream())
+
+
+def attn_fwd_tail(qkv, o, lse, B: int, S: int, H: int, scale: float, q_start: int):
+    """attn_fwd computing only the query rows >= q_start (whole query tiles)"""
+    lib().call("mh_attn_fwd_tail", _p(qkv), _p(o), _p(lse), B, S, H, scale, q_start, dt(qkv), _stream())
+    return o
+
+
 def kv_store_prefill(qkv, kc, vc, B: int, S: int, H: int, hd: int, Lmax: int):
     lib().call("mh_kv_store_prefill", _p(qkv), _p(kc), _p(vc), B, S, H, hd, Lmax, dt(qkv), _stream())
 

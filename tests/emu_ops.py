@@ -431,6 +431,29 @@ def attn_decode_append(qkv, cos_t, sin_t, kc, vc, o, B, H, hd, Lmax, pos, scale,
     return attn_decode(tmp, kc, vc, o, B, H, hd, Lmax, pos + 1, scale)
 
 
+def kv_store_rows(qkv, kc, vc, B, S, H, hd, Lmax, pos0):
+    D = H * hd
+    kc[:, :, pos0:pos0 + S] = qkv[:, D:2 * D].view(B, S, H, hd).transpose(1, 2)
+    vc[:, :, pos0:pos0 + S] = qkv[:, 2 * D:].view(B, S, H, hd).transpose(1, 2)
+
+
+def kv_gather_rows(kc, vc, qkv, B, n, Stot, H, hd, Lmax):
+    D = H * hd
+    rows = qkv.view(B, Stot, 3 * D)
+    rows[:, :n, :D] = 0
+    rows[:, :n, D:2 * D] = kc[:, :, :n].transpose(1, 2).reshape(B, n, D)
+    rows[:, :n, 2 * D:] = vc[:, :, :n].transpose(1, 2).reshape(B, n, D)
+
+
+def attn_fwd_tail(qkv, o, lse, B, S, H, scale, q_start):
+    """only rows >= q_start are meaningful (the device also writes the rest of the first query tile: not modelled)"""
+    full = torch.empty_like(o)
+    attn_fwd(qkv, full, lse, B, S, H, scale)
+    D = o.shape[1]
+    o.view(B, S, D)[:, q_start:] = full.view(B, S, D)[:, q_start:]
+    return o
+
+
 def kv_store_prefill(qkv, kc, vc, B, S, H, hd, Lmax):
     D = H * hd
     kc[:, :, :S] = qkv[:, D:2 * D].view(B, S, H, hd).transpose(1, 2)

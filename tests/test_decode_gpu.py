@@ -165,6 +165,45 @@ def test_greedy_generate_600_events_fp32_follows_the_oracle_id_for_id(orc, tok):
     print(f"greedy generate, {L} events x {B}: {checked}/{N * T} sampling positions checked against the oracle's arg-max, all equal")
 
 
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16], ids=["fp32", "bf16"])
+def test_chunked_continuation_of_a_cached_forward(orc, tok, golden, dtype):
+    """``MIDIModel.forward(x, cache)`` with a NON-EMPTY cache and q_len > 1 (midi_model.py:137-150; chunked prefill): tv2o-medium,
+    a 300-event prefill, a 212-event chunk (its first query tile starts below the cached length: 300 is not a multiple of 128), a
+    129-event chunk, then one event -- against the oracle's cached forward fed the same chunks, and against the uncached forward
+    over all 642 events.  fp32: rtol 1e-3 on every hidden state; bf16: within 1.5x the reference's own bf16 drift."""
+    from midi_model_amd.engine import KVState
+    shp = orc.Shape(vocab=tok.vocab_size)
+    sd = orc.make_state_dict(shp, seed=0)
+    m = mm.MIDIModel(mm.MIDIModelConfig.from_name("tv2o-medium"))
+    m.load_state_dict(sd, strict=True)
+    m = m.to("cuda", dtype).eval()
+    B, cuts = 2, (0, 300, 512, 641, 642)
+    x = orc.synthetic_events(tok, B, cuts[-1], seed=91)
+    torch.set_num_threads(min(os.cpu_count() or 8, 32))
+
+    class AnyCache:
+        pass
+
+    cache, kv_o = AnyCache(), orc.KV()
+    outs, outs_o = [], []
+    with torch.no_grad():
+        for a, b in zip(cuts, cuts[1:]):
+            outs.append(m.forward(x[:, a:b].cuda(), cache=cache).float().cpu())
+            outs_o.append(orc.midi_forward(sd, shp, x[:, a:b], kv_o))
+        full_o = orc.midi_forward(sd, shp, x)
+    assert isinstance(cache._mh_state, KVState) and cache._mh_state.len == cuts[-1]
+    got, want = torch.cat(outs, 1), torch.cat(outs_o, 1)
+    assert (want - full_o).abs().max() < 2e-4          # the oracle's cached chunks = its uncached forward
+    err = (got - want).abs()
+    if dtype == torch.float32:
+        assert (err <= 1e-3 * want.abs() + 3e-4).all(), err.max().item()
+    else:
+        g = golden("medium_long_S2048.npz")
+        bound = DRIFT * float(g["ref_bf16_hidden_maxerr"])
+        assert err.max().item() <= bound, (err.max().item(), bound)
+        assert err.pow(2).mean().sqrt().item() <= DRIFT * float(g["ref_bf16_hidden_rmserr"])
+
+
 def test_fused_sampler_inside_graphs_equals_oracle_chain_on_same_noise(orc, tok, medium_bf16):
     """Seeded sampling through the captured graphs (temp 1, top_p 0.98, top_k 20): after every token step, feed the
     oracle's sampling chain (softmax * mask -> sort -> top-p -> top-k -> renormalise -> argmax(p / q), midi_model.py:152-165
