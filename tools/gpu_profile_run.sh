@@ -22,9 +22,8 @@ timeout 300 python tools/bench_attn_forms.py > $O/${T}_attn_forms_ab.txt 2>&1
 timeout 300 python bench.py --mode block > $O/${T}_block_bench.json 2>/dev/null
 (cd /tmp && rm -rf /tmp/profb_$T && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/profb_$T -o block -- python $R/bench.py --mode block > /dev/null 2>&1)
 cp $(find /tmp/profb_$T -name "*kernel_stats.csv" | head -1) $O/${T}_block_rocprofv3_kernel_stats.csv 2>/dev/null
-timeout 600 python bench.py --config tv2o-large --seq 4096 --batch 4 --steps 3 --warmup 1 --no-cpu-baseline --no-extras > $O/${T}_tv2o_large_seq4096_bench.json 2>/dev/null
-timeout 600 python tools/check_big_config.py > $O/${T}_two_times_hidden_config.txt 2>&1
-timeout 300 python tools/bench_hipblaslt_torch.py > $O/${T}_hipblaslt_same_gpu.txt 2>&1
+# (BASELINE configs[4] -- tv2o-large and the 2x-hidden shape at 16 x 4096 per GPU -- are the `large` / `large_2x_hidden` objects of
+#  the default bench line above since r04; the vendor-library comparison of r03 is profiles/r03_run3_hipblaslt_same_gpu.txt)
 python - <<PY
 import json
 d=json.loads(open("$O/${T}_bench.json").read().strip().splitlines()[-1]); a=d['attention']; b=d.get('block',{}); g=d.get('generate',{})
