@@ -38,7 +38,12 @@ from .engine import KVState, RopeTable
 
 # One capture at a time per process, and in thread-local error mode: generators of other threads (app.py runs up to 10 on
 # one model) keep launching and allocating while a new session is being captured.
-_CAPTURE_LOCK = threading.Lock()
+# Replays of graphs that carry a registered generator state (the noise graph; the per-step graphs of the unfused sampler) take the
+# same lock: torch's replay prologue asserts that NO capture is active, and under HIP a capture on another thread's stream makes
+# that check fire ("Cannot prepare for replay during capturing stage", seen once in ~3 runs of the whole GPU suite in
+# test_concurrent_generators_on_one_model, r04).  Captures are rare (a session is captured once and pooled), so the replays of
+# other generators wait a few hundred milliseconds at most.
+_CAPTURE_LOCK = threading.RLock()
 _NOISE_INLINE = os.environ.get("MH_DECODE_NOISE_INLINE", "0") == "1"
 _COPY_PAGEABLE = os.environ.get("MH_DECODE_COPY_PAGEABLE", "0") == "1"
 
@@ -263,8 +268,9 @@ class DecodeSession:
         self._noise_read = False
         if self.gen is not None:
             src = generator if generator is not None else torch.cuda.default_generators[self.model.device.index or 0]
-            self.gen.set_state(src.get_state())
-            self._off = self.gen.get_offset()
+            with _CAPTURE_LOCK:
+                self.gen.set_state(src.get_state())
+                self._off = self.gen.get_offset()
 
     def end(self) -> None:
         """hand the advanced random stream back to the caller's generator"""
@@ -272,10 +278,12 @@ class DecodeSession:
             if self._noise_pending:  # draws made ahead for an event that was never sampled: not consumed
                 self.noise_stream.synchronize()
                 self._noise_pending = False
-            self.gen.set_offset(self._off)
+            with _CAPTURE_LOCK:
+                self.gen.set_offset(self._off)
         if self.gen is not None:
             dst = self._user_gen if self._user_gen is not None else torch.cuda.default_generators[self.model.device.index or 0]
-            dst.set_state(self.gen.get_state())
+            with _CAPTURE_LOCK:
+                dst.set_state(self.gen.get_state())
         self._user_gen = None
 
     def net_step(self) -> None:
@@ -308,7 +316,11 @@ class DecodeSession:
                 self._noise_read = True
             if self.g_noise is not None and self._noise_pending:
                 torch.cuda.current_stream().wait_event(self.noise_done)
-            self.g_tok[i].replay()
+            if self.fused_sampler:
+                self.g_tok[i].replay()
+            else:  # (the step graph of the unfused sampler carries the generator state)
+                with _CAPTURE_LOCK:
+                    self.g_tok[i].replay()
             self._steps_recorded = False
         else:
             self._tok_body(i, self._user_gen)
@@ -327,14 +339,17 @@ class DecodeSession:
             self.noise_stream.wait_event(self.steps_done)
         else:
             self.noise_stream.wait_stream(torch.cuda.current_stream())
-        self.gen.set_offset(self._off)
         self._noise_read = False
         if _NOISE_INLINE:  # (A/B: the draws on the caller's stream, no cross-stream dependency)
-            self.g_noise.replay()
+            with _CAPTURE_LOCK:  # (generator-state calls assert "not capturing" as well)
+                self.gen.set_offset(self._off)
+                self.g_noise.replay()
             self.noise_done.record(torch.cuda.current_stream())
         else:
             with torch.cuda.stream(self.noise_stream):
-                self.g_noise.replay()
+                with _CAPTURE_LOCK:
+                    self.gen.set_offset(self._off)
+                    self.g_noise.replay()
                 self.noise_done.record(self.noise_stream)
         self._noise_pending = True
 

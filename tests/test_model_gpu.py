@@ -306,24 +306,26 @@ def test_concurrent_generators_on_one_model(tiny, tok):
     model = build(mm.MIDIModel, tiny_config(), sd, dtype=torch.bfloat16)
     want = [model.generate(None, batch_size=2 + i, max_len=12, ban_eos=True,
                            generator=torch.Generator(device="cuda").manual_seed(40 + i)) for i in range(2)]
-    model._sessions.idle.clear()  # force both threads to build and capture new sessions
-    got, errs = [None, None], []
+    for rep in range(8):  # (r04: one thread's noise-graph replay inside the other's capture window raised under HIP about once
+        #                      in three runs of the whole suite; several rounds of fresh captures make the window likely here)
+        model._sessions.idle.clear()  # force both threads to build and capture new sessions
+        got, errs = [None, None], []
 
-    def work(i):
-        try:
-            with torch.cuda.stream(torch.cuda.Stream()):
-                got[i] = model.generate(None, batch_size=2 + i, max_len=12, ban_eos=True,
-                                        generator=torch.Generator(device="cuda").manual_seed(40 + i))
-                torch.cuda.current_stream().synchronize()
-        except Exception as e:  # noqa: BLE001
-            errs.append(e)
+        def work(i):
+            try:
+                with torch.cuda.stream(torch.cuda.Stream()):
+                    got[i] = model.generate(None, batch_size=2 + i, max_len=12, ban_eos=True,
+                                            generator=torch.Generator(device="cuda").manual_seed(40 + i))
+                    torch.cuda.current_stream().synchronize()
+            except Exception as e:  # noqa: BLE001
+                errs.append(e)
 
-    ths = [threading.Thread(target=work, args=(i,)) for i in range(2)]
-    [t.start() for t in ths]
-    [t.join() for t in ths]
-    assert not errs, errs
-    for i in range(2):
-        assert (got[i] == want[i]).all()
+        ths = [threading.Thread(target=work, args=(i,)) for i in range(2)]
+        [t.start() for t in ths]
+        [t.join() for t in ths]
+        assert not errs, (rep, errs)
+        for i in range(2):
+            assert (got[i] == want[i]).all(), rep
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
