@@ -310,12 +310,12 @@ def test_concurrent_generators_on_one_model(tiny, tok):
         #                      in three runs of the whole suite; several rounds of fresh captures make the window likely here)
         model._sessions.idle.clear()  # force both threads to build and capture new sessions
         got, errs = [None, None], []
+        gens = [torch.Generator(device="cuda").manual_seed(40 + i) for i in range(2)]  # (seeded before any capture can be active)
 
         def work(i):
             try:
                 with torch.cuda.stream(torch.cuda.Stream()):
-                    got[i] = model.generate(None, batch_size=2 + i, max_len=12, ban_eos=True,
-                                            generator=torch.Generator(device="cuda").manual_seed(40 + i))
+                    got[i] = model.generate(None, batch_size=2 + i, max_len=12, ban_eos=True, generator=gens[i])
                     torch.cuda.current_stream().synchronize()
             except Exception as e:  # noqa: BLE001
                 errs.append(e)
