@@ -47,46 +47,52 @@ __global__ __launch_bounds__(NW * 64) void gemm_skinny_kernel(const bf16* __rest
                                                           const bf16* __restrict__ W, int64_t ldw, bf16* __restrict__ C,
                                                           int64_t ldc, const bf16* __restrict__ R, int64_t ldr, int M, int N,
                                                           int K, float norm_eps, const int64_t* __restrict__ row_ids,
-                                                          const int64_t* __restrict__ res_ids) {
+                                                          const int64_t* __restrict__ res_ids, int vec_store) {
   constexpr int NB = NBT * 16;
   constexpr int MR = MB * 16;  // rows of this workgroup
-  __shared__ float red[NW][MR][NB + 1];
+  // rows padded to NB + 4 floats: 16-byte aligned, so a lane's four accumulator values go in with one ds_write_b128 and a writer's
+  // group comes out with one ds_read_b128 per wave (r04: 4 + 32 scalar LDS instructions per thread before)
+  constexpr int NBP = NB + 4;
+  __shared__ __attribute__((aligned(16))) float red[NW][MR][NBP];
   __shared__ float ssq[RSTD ? NW : 1][MR];
   // (8 waves x 64 rows x 32 columns, the largest form instantiated, is 69.6 KiB: more than the 64 KiB every other CDNA part
   // gives a workgroup, two workgroups per CU on gfx950 -- the only target; anything larger is a mistake in the launcher's table)
-  static_assert(sizeof(float) * NW * MR * (NB + 1) + sizeof(float) * (RSTD ? NW : 1) * MR <= 72 * 1024,
+  static_assert(sizeof(float) * NW * MR * (NB + 4) + sizeof(float) * (RSTD ? NW : 1) * MR <= 80 * 1024,
                 "gemm_skinny: static LDS of this form exceeds what the launcher's tilings were sized for");
   // all kernel arguments in one batch of scalar loads at entry (hipcc otherwise sinks each s_load into the block that first
   // uses it: a scalar-cache miss and a wait per block)
   asm volatile("" ::"s"(A), "s"(lda), "s"(W), "s"(ldw), "s"(C), "s"(ldc), "s"(R), "s"(ldr));
-  asm volatile("" ::"s"(M), "s"(N), "s"(K), "s"(norm_eps), "s"(row_ids), "s"(res_ids));
+  asm volatile("" ::"s"(M), "s"(N), "s"(K), "s"(norm_eps), "s"(row_ids), "s"(res_ids), "s"(vec_store));
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int fi = lane & 15, fg = lane >> 4;
   const int nc_w = K / (32 * NW);  // chunks of 32 per wave (wave w takes chunks w, w+NW, ...); a multiple of BCH
   const int m0 = blockIdx.y * MR;
 
-  // indirections first (their results are addresses): A rows / residual row through the id tables
-  int64_t arow_i[MB];
+  // indirections first (their results are addresses): A rows / residual row through the id tables.
+  // Every address is a wave-uniform base + a 32-bit element offset (the host checks that A, W, R and the tables span fewer than
+  // 2^31 elements): the loads take the SGPR-base form and the prologue loses its 64-bit multiply-adds (r04, ISA of the r02 form:
+  // ~60 VALU instructions of 64-bit address arithmetic sat between the argument fetch and the first operand request).
+  unsigned arow_i[MB];
 #pragma unroll
   for (int mb = 0; mb < MB; ++mb) {
     const int m = m0 + mb * 16 + fi;
-    arow_i[mb] = (m < M) ? m : M - 1;
+    arow_i[mb] = (unsigned)((m < M) ? m : M - 1);
   }
   constexpr int CPT = (MODE == 1) ? 4 : NB / 4;  // output columns per writing thread (four threads per row)
   const int ml = threadIdx.x >> 2;               // row within the workgroup (threads < MR * 4 write)
   const int cw0 = (threadIdx.x & 3) * CPT;
   const bool writer = threadIdx.x < MR * 4 && m0 + ml < M;
-  int64_t rrow_i = writer ? m0 + ml : 0;
+  unsigned rrow_i = writer ? (unsigned)(m0 + ml) : 0u;
   if (row_ids != nullptr) {  // (uniform)
 #pragma unroll
-    for (int mb = 0; mb < MB; ++mb) arow_i[mb] = row_ids[arow_i[mb]];
+    for (int mb = 0; mb < MB; ++mb) arow_i[mb] = (unsigned)row_ids[arow_i[mb]];
   }
-  if (MODE == 0 && res_ids != nullptr) rrow_i = res_ids[rrow_i];
+  if (MODE == 0 && res_ids != nullptr) rrow_i = (unsigned)res_ids[rrow_i];
 
-  const bf16* arow[MB];
-  const bf16* wrow[NBT];
+  const unsigned ulda = (unsigned)lda, uldw = (unsigned)ldw, uldr = (unsigned)ldr;
+  unsigned aoff[MB], woff[NBT];
 #pragma unroll
-  for (int mb = 0; mb < MB; ++mb) arow[mb] = A + arow_i[mb] * lda + fg * 8;  // row_ids: A rows gathered from a table
+  for (int mb = 0; mb < MB; ++mb) aoff[mb] = arow_i[mb] * ulda + (unsigned)(fg * 8);  // row_ids: A rows gathered from a table
 #pragma unroll
   for (int nb = 0; nb < NBT; ++nb) {
     int n, nmax;
@@ -97,7 +103,7 @@ __global__ __launch_bounds__(NW * 64) void gemm_skinny_kernel(const bf16* __rest
       n = blockIdx.x * NB + nb * 16 + fi;
       nmax = N - 1;
     }
-    wrow[nb] = W + (int64_t)(n < nmax ? n : nmax) * ldw + fg * 8;
+    woff[nb] = (unsigned)(n < nmax ? n : nmax) * uldw + (unsigned)(fg * 8);
   }
 
   // The residual values are REQUESTED here and left raw (no conversion = no wait) until the epilogue: read after the
@@ -108,7 +114,8 @@ __global__ __launch_bounds__(NW * 64) void gemm_skinny_kernel(const bf16* __rest
   const bool res_full = blockIdx.x * NB + cw0 + CPT <= N;  // the whole group is inside the row (always, but for a ragged last block)
   {
     const bool use_r = MODE == 0 && R != nullptr;
-    const bf16* rsrc = use_r ? R + rrow_i * ldr + (res_full ? blockIdx.x * NB + cw0 : 0) : W;
+    const unsigned roff = use_r ? rrow_i * uldr + (unsigned)(res_full ? blockIdx.x * NB + cw0 : 0) : 0u;
+    const bf16* rsrc = (use_r ? R : W) + roff;  // (pointer + j: the CPT element loads merge into one request)
 #pragma unroll
     for (int j = 0; j < CPT; ++j) rraw[j] = rsrc[j];
   }
@@ -126,26 +133,26 @@ __global__ __launch_bounds__(NW * 64) void gemm_skinny_kernel(const bf16* __rest
     bf16x8 wf[BCH][NBT], xf[BCH][MB];
 #pragma unroll
     for (int i = 0; i < BCH; ++i) {
-      const int k = (wave + NW * (c0 + i)) * 32;
+      const unsigned k = (unsigned)((wave + NW * (c0 + i)) * 32);
 #pragma unroll
-      for (int nb = 0; nb < NBT; ++nb) wf[i][nb] = *reinterpret_cast<const bf16x8*>(wrow[nb] + k);
+      for (int nb = 0; nb < NBT; ++nb) wf[i][nb] = *reinterpret_cast<const bf16x8*>(W + (woff[nb] + k));
 #pragma unroll
-      for (int mb = 0; mb < MB; ++mb) xf[i][mb] = *reinterpret_cast<const bf16x8*>(arow[mb] + k);
+      for (int mb = 0; mb < MB; ++mb) xf[i][mb] = *reinterpret_cast<const bf16x8*>(A + (aoff[mb] + k));
     }
     __builtin_amdgcn_sched_barrier(0);  // every load of the batch is in flight before the first use
 #pragma unroll
     for (int i = 0; i < BCH; ++i) {
-      if constexpr (RSTD) {
-#pragma unroll
-        for (int mb = 0; mb < MB; ++mb)
-#pragma unroll
-          for (int e = 0; e < 8; ++e) ss[mb] += (float)xf[i][mb][e] * (float)xf[i][mb][e];
-      }
 #pragma unroll
       for (int nb = 0; nb < NBT; ++nb)
 #pragma unroll
         for (int mb = 0; mb < MB; ++mb)
           acc[mb][nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[i][nb], xf[i][mb], acc[mb][nb], 0, 0, 0);
+      if constexpr (RSTD) {  // (behind the MFMAs in program order: the squares run while the matrix pipe works)
+#pragma unroll
+        for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+          for (int e = 0; e < 8; ++e) ss[mb] += (float)xf[i][mb][e] * (float)xf[i][mb][e];
+      }
     }
   }
 
@@ -154,8 +161,7 @@ __global__ __launch_bounds__(NW * 64) void gemm_skinny_kernel(const bf16* __rest
   for (int mb = 0; mb < MB; ++mb)
 #pragma unroll
     for (int nb = 0; nb < NBT; ++nb)
-#pragma unroll
-      for (int e = 0; e < 4; ++e) red[wave][mb * 16 + fi][nb * 16 + 4 * fg + e] = acc[mb][nb][e];
+      *reinterpret_cast<f32x4*>(&red[wave][mb * 16 + fi][nb * 16 + 4 * fg]) = acc[mb][nb];
   if constexpr (RSTD) {
 #pragma unroll
     for (int mb = 0; mb < MB; ++mb) {  // the four lane groups hold different k of the same row
@@ -175,34 +181,48 @@ __global__ __launch_bounds__(NW * 64) void gemm_skinny_kernel(const bf16* __rest
     for (int w = 1; w < NW; ++w) t += ssq[w][ml];
     rs = rsqrtf(t / (float)K + norm_eps);
   }
-  auto total = [&](int c) {
-    float t = red[0][ml][c];
+  // The writer's CPT (gate|up: 2 x 4) sums of the waves' partials are read in ONE batch, and the group goes out as one 8- / 16-byte
+  // store when it lies inside the row and the output is aligned for it (r04, ISA of the r02 form: the per-element `n < N` test
+  // made every element its own sequence of eight ds_read + wait + a 2-byte store -- four LDS round trips and four store
+  // instructions in a row on the launch's critical path; tools/persist_probe.hip: 4.52 us per dependent launch against 3.70 for
+  // a bare tile).
+  constexpr int NT = (MODE == 1) ? 8 : CPT;
+  float tot[NT];
 #pragma unroll
-    for (int w = 1; w < NW; ++w) t += red[w][ml][c];
-    return t * rs;
-  };
+  for (int j4 = 0; j4 < NT; j4 += 4) {  // four consecutive columns per 16-byte LDS read, the waves' partials added in wave order
+    const int c = (MODE == 1) ? ((j4 >> 2) * 16 + (threadIdx.x & 3) * 4) : cw0 + j4;
+    f32x4 t = *reinterpret_cast<const f32x4*>(&red[0][ml][c]);
+#pragma unroll
+    for (int w = 1; w < NW; ++w) t += *reinterpret_cast<const f32x4*>(&red[w][ml][c]);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) tot[j4 + e] = t[e] * rs;
+  }
+  constexpr int NO = (MODE == 1) ? 4 : CPT;  // outputs of this thread
+  const int nbase = (MODE == 1) ? blockIdx.x * 16 + (threadIdx.x & 3) * 4 : blockIdx.x * NB + cw0;
+  bf16 outv[NO];
   if constexpr (MODE == 1) {
-    const int c0 = (threadIdx.x & 3) * 4;  // 16 output columns per workgroup, 4 per thread
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-      const int n = blockIdx.x * 16 + c0 + j;
-      if (n < N) {
-        const float g = (float)(bf16)total(c0 + j), u = (float)(bf16)total(16 + c0 + j);
-        const float s = (float)(bf16)mh_silu(g);
-        C[(int64_t)m * ldc + n] = (bf16)(s * u);
-      }
+      const float g = (float)(bf16)tot[j], u = (float)(bf16)tot[4 + j];
+      const float sg = (float)(bf16)mh_silu(g);
+      outv[j] = (bf16)(sg * u);
     }
   } else {
-    const int c0 = cw0;
 #pragma unroll
     for (int j = 0; j < CPT; ++j) {
-      const int n = blockIdx.x * NB + c0 + j;
-      if (n < N) {
-        float r = (MODE == 0 && R != nullptr) ? (float)rraw[j] : 0.f;
-        if (MODE == 0 && R != nullptr && !res_full) r = (float)R[rrow_i * ldr + n];  // (ragged last block only)
-        C[(int64_t)m * ldc + n] = (bf16)(total(c0 + j) + r);
-      }
+      float r = (R != nullptr) ? (float)rraw[j] : 0.f;
+      if (R != nullptr && !res_full && nbase + j < N) r = (float)R[rrow_i * uldr + (unsigned)(nbase + j)];  // (ragged last block only)
+      outv[j] = (bf16)(tot[j] + r);
     }
+  }
+  bf16* crow = C + ((unsigned)m * (unsigned)ldc + (unsigned)nbase);
+  if (vec_store && nbase + NO <= N) {
+    if constexpr (NO == 4) *reinterpret_cast<uint64_t*>(crow) = *reinterpret_cast<const uint64_t*>(outv);
+    else *reinterpret_cast<bf16x8*>(crow) = *reinterpret_cast<const bf16x8*>(outv);
+  } else {
+#pragma unroll
+    for (int j = 0; j < NO; ++j)
+      if (nbase + j < N) crow[j] = outv[j];
   }
 }
 
@@ -218,6 +238,11 @@ extern "C" int mh_gemm_skinny(const void* A, int64_t lda, const void* W, int64_t
   MH_REQUIRE(lda % 8 == 0 && ldw % 8 == 0 && ((uintptr_t)A & 15) == 0 && ((uintptr_t)W & 15) == 0,
              "gemm_skinny: A/W rows must be 16-byte aligned");
   MH_REQUIRE(mode != MH_SKINNY_GATEUP || R == nullptr, "gemm_skinny: the gate|up epilogue takes no residual");
+  // (32-bit element offsets inside the kernel; with row_ids / res_ids the TABLES must stay below 2^31 elements too -- the caller's
+  //  contract: the embedding tables of this model are 3.5 M elements)
+  MH_REQUIRE((mode == MH_SKINNY_GATEUP ? 2 * N : N) * ldw < (int64_t(1) << 31) && 64 * lda < (int64_t(1) << 31) && 64 * ldc < (int64_t(1) << 31) &&
+                 (R == nullptr || 64 * ldr < (int64_t(1) << 31)) && lda < (int64_t(1) << 24) && ldr < (int64_t(1) << 24),
+             "gemm_skinny: operands too large for 32-bit element offsets");
   hipStream_t st = (hipStream_t)stream;
   // Tiling (r02, tools/decode_probe.py section 1b, profiles/r02_*decode_probe*): a launch spends its time in the TA/L1 path
   // of the CUs (64 B/clk each) and in fixed latencies, so the best tile is the LARGEST one that still puts about one
@@ -235,10 +260,13 @@ extern "C" int mh_gemm_skinny(const void* A, int64_t lda, const void* W, int64_t
   }
   if (mb > row_blocks) mb = row_blocks >= 4 ? 4 : (row_blocks >= 2 ? 2 : 1);
   const int gy = (row_blocks + mb - 1) / mb;
+  // a writer thread's outputs (4, or 8 with two column blocks) leave as one store when every row of C keeps them aligned
+  const int group_bytes = ((mode == MH_SKINNY_GATEUP || nbt == 1) ? 4 : 8) * 2;
+  const int vec = (((uintptr_t)C % group_bytes) == 0 && (ldc * 2) % group_bytes == 0) ? 1 : 0;
 #define MH_SK4(MODE_, NBT_, NW_, GRID_, RSTD_, MB_, BCH_)                                                                  \
   gemm_skinny_kernel<MODE_, NBT_, NW_, RSTD_, MB_, BCH_><<<dim3((unsigned)(GRID_), (unsigned)gy), NW_ * 64, 0, st>>>(      \
       (const bf16*)A, lda, (const bf16*)W, ldw, (bf16*)C, ldc, (const bf16*)R, ldr, (int)M, (int)N, (int)K, norm_eps,      \
-      row_ids, res_ids)
+      row_ids, res_ids, vec)
 #define MH_SK3(MODE_, NBT_, NW_, GRID_, RSTD_, MB_)                                                                        \
   do {                                                                                                                    \
     const int ncw_ = (int)(K / (32 * NW_)); /* chunks per wave; batches of the largest of 8 / 4 / 1 that divides it */    \
