@@ -270,7 +270,10 @@ extern "C" int mh_gemm_skinny(const void* A, int64_t lda, const void* W, int64_t
 #define MH_SK3(MODE_, NBT_, NW_, GRID_, RSTD_, MB_)                                                                        \
   do {                                                                                                                    \
     const int ncw_ = (int)(K / (32 * NW_)); /* chunks per wave; batches of the largest of 8 / 4 / 1 that divides it */    \
-    if (ncw_ % 8 == 0 && (NBT_ + MB_) <= 4) MH_SK4(MODE_, NBT_, NW_, GRID_, RSTD_, MB_, 8);                                \
+    /* (r04, tools/skinny_chain.py: ONE batch where the registers allow it -- the 64-row gate|up form 10.15 -> 9.38 us per     \
+       dependent launch on cold weights, the K = 4096 projection 10.9 -> 10.7) */                                         \
+    if (ncw_ == 16 && (NBT_ + MB_) <= 2) MH_SK4(MODE_, NBT_, NW_, GRID_, RSTD_, MB_, 16);                                  \
+    else if (ncw_ % 8 == 0 && (NBT_ + MB_) <= 6) MH_SK4(MODE_, NBT_, NW_, GRID_, RSTD_, MB_, 8);                           \
     else if (ncw_ % 4 == 0) MH_SK4(MODE_, NBT_, NW_, GRID_, RSTD_, MB_, 4);                                                \
     else MH_SK4(MODE_, NBT_, NW_, GRID_, RSTD_, MB_, 1);                                                                   \
   } while (0)

@@ -133,8 +133,7 @@ class DecodeSession:
         spec = m._specs["net"]
         e = torch.empty((self.B, spec.D), dtype=m.dtype, device=m.device)
         ops.embed_sum_fwd(self.seq, m._W["net"].embed, e)  # the event sampled last
-        y = engine.stack_decode(spec, m._W["net"], e, self.rope1, self.kv1, pos_dev=self.pos, folded=self.fold1)
-        self.hidden.copy_(y)
+        engine.stack_decode(spec, m._W["net"], e, self.rope1, self.kv1, pos_dev=self.pos, folded=self.fold1, out=self.hidden)
         self.pos.add_(1)
 
     def _noise_body(self, generator=None):

@@ -331,7 +331,7 @@ def fold_norm_weights(W: StackTensors, out=None):
 
 
 def stack_decode(spec: StackSpec, W: StackTensors, x: torch.Tensor, rope: RopeTable, kv: KVState, pos_dev=None,
-                 folded=None, final_norm: bool = True, x_ids=None):
+                 folded=None, final_norm: bool = True, x_ids=None, out: Optional[torch.Tensor] = None):
     """x [B, D]: one new position per sequence at index kv.len (q_len == 1 => no causal mask,
     TF:integrations/sdpa_attention.py:120).
 
@@ -407,6 +407,6 @@ def stack_decode(spec: StackSpec, W: StackTensors, x: torch.Tensor, rope: RopeTa
         kv.len = pos + 1
     if not final_norm:
         return x
-    y = _empty((B, D), x)
+    y = out if out is not None else _empty((B, D), x)  # (`out`: the caller's buffer -- a decode session's `hidden` -- no copy)
     ops.rmsnorm_fwd(x, W.norm, y, None, spec.eps)
     return y
