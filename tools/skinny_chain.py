@@ -110,3 +110,15 @@ def pair(cold):
 
 pair(False)
 pair(True)
+
+if os.environ.get("SWEEP"):
+    print("-- tilings (skinny_mb = 16-row blocks per workgroup, skinny_nbt = 16-column blocks; 0 = the launcher's choice)")
+    for name, N, K, mode, rstd in (("q|k|v", 3072, 1024, P, True), ("lm_head", 3406, 1024, P, True), ("o / down", 1024, 1024, P, False),
+                                   ("token gate|up", 1024, 1024, G, True), ("event gate|up", 4096, 1024, G, True)):
+        for nbt in ((0, 1, 2) if mode == P else (0,)):
+            for mb in (0, 1, 2, 4):
+                ops.set_option("skinny_mb", mb)
+                ops.set_option("skinny_nbt", nbt)
+                chain(f"{name} mb={mb} nbt={nbt}", N, K, mode, rstd, mode == P and not rstd, True, ld_out=3456 if N == 3406 else None)
+    ops.set_option("skinny_mb", 0)
+    ops.set_option("skinny_nbt", 0)
