@@ -244,6 +244,8 @@ def gemm_skinny(a: torch.Tensor, w: torch.Tensor, out: torch.Tensor, *, mode: in
     assert w.shape[0] == (2 * N if mode == SKINNY_GATEUP else N), (a.shape, w.shape, out.shape, mode)
     for t in (row_ids, res_ids):
         assert t is None or (t.dtype == torch.int64 and t.is_contiguous() and t.numel() == M)
+    # (the kernel addresses with 32-bit element offsets: the tables behind row_ids / res_ids must stay below 2^31 elements)
+    assert a.shape[0] * _rowmajor(a) < 2 ** 31 and (res is None or res.shape[0] * _rowmajor(res) < 2 ** 31), "gemm_skinny: table too large"
     lib().call("mh_gemm_skinny", _p(a), _rowmajor(a), _p(w), _rowmajor(w), _p(out), _rowmajor(out), _p(res),
                _rowmajor(res) if res is not None else 0, mode, norm_eps, _p(row_ids), _p(res_ids), M, N, K, dt(out),
                _stream())
