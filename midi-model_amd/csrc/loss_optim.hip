@@ -439,6 +439,12 @@ __global__ __launch_bounds__(256) void sample_top_p_k_kernel(const T* __restrict
   __shared__ float sel_v[SAMPLE_MAX_K];
   __shared__ int sel_i[SAMPLE_MAX_K];
   __shared__ float part_m[4], part_s[4];
+  // Long mask ranges (TMAX > 2: `bpm`, `duration`) are spread over the block's four waves (r04): wave w keeps candidate slots
+  // [w TW, (w + 1) TW) of every lane and finds ITS top_k in top_k rounds of a register arg-max over TW values (8 instead of
+  // 32 for the 2048-id range) + one DPP ladder; wave 0 then ranks the 4 x top_k survivors by counting, as it ranks a short range.
+  constexpr bool SPLIT = TMAX > 2;
+  constexpr int TW = SPLIT ? TMAX / 4 : TMAX;  // candidate slots per lane of one wave
+  __shared__ unsigned long long wl[SPLIT ? 4 : 1][SAMPLE_MAX_K];
   // (every kernel argument fetched at entry in one batch: see attn_decode_kernel)
   asm volatile("" ::"s"(logits), "s"(ldl), "s"(first_mask), "s"(ban_mask), "s"(lo_tab), "s"(hi_tab), "s"(tab_stride), "s"(ev));
   asm volatile("" ::"s"(pos), "s"(first_lo), "s"(first_hi), "s"(q), "s"(out), "s"(out_stride), "s"(out_b), "s"(out_c));
@@ -447,10 +453,11 @@ __global__ __launch_bounds__(256) void sample_top_p_k_kernel(const T* __restrict
   const int64_t b = blockIdx.x;
   const T* row = logits + b * ldl;
   // ---- wave 0: everything that does not need the softmax statistics, requested first
-  float qv = 1.f, zc[TMAX];
+  float qv = 1.f, zc[TW];
   int l = first_lo, h = first_hi;
-  if (wave == 0) {
-    if (lane < top_k) qv = q[b * (int64_t)V + lane];
+  const int t0 = SPLIT ? wave * TW : 0;  // this wave's first candidate slot
+  if (SPLIT || wave == 0) {
+    if (wave == 0 && lane < top_k) qv = q[b * (int64_t)V + lane];
     if (pos > 0) {
       const int64_t e = ev[b];
       l = lo_tab[e * tab_stride + pos];
@@ -460,19 +467,19 @@ __global__ __launch_bounds__(256) void sample_top_p_k_kernel(const T* __restrict
     // every load unconditional on a clamped index, all requested before the first use: a per-element "load or constant"
     // select makes hipcc branch around each load and wait for it -- one memory round trip per element (r02: the first form
     // of this kernel took 19-38 us that way; cdna_hip_programming.md 5 trap (c))
-    T zraw[TMAX];
-    uint8_t fm[TMAX], bm[TMAX];
+    T zraw[TW];
+    uint8_t fm[TW], bm[TW];
 #pragma unroll
-    for (int t = 0; t < TMAX; ++t) {
-      int c = l + lane + 64 * t;
+    for (int t = 0; t < TW; ++t) {
+      int c = l + lane + 64 * (t0 + t);
       c = c < V ? c : V - 1;
       zraw[t] = row[c];
       fm[t] = first_mask[c];
       bm[t] = ban_mask[c];  // (always a real mask: an optional pointer costs a branch + wait per element here)
     }
 #pragma unroll
-    for (int t = 0; t < TMAX; ++t) {
-      const int c = l + lane + 64 * t;
+    for (int t = 0; t < TW; ++t) {
+      const int c = l + lane + 64 * (t0 + t);
       const bool ok = c < h && (pos > 0 || fm[t] != 0) && bm[t] == 0;
       zc[t] = ok ? rnd<T>(to_f(zraw[t]) / temp) : -INFINITY;  // -inf: not a candidate
     }
@@ -518,15 +525,15 @@ __global__ __launch_bounds__(256) void sample_top_p_k_kernel(const T* __restrict
     sel_i[lane] = 0x7fffffff;
   }
   __syncthreads();
-  if (wave != 0) return;
+  if (!SPLIT && wave != 0) return;
   const float mx = fmaxf(fmaxf(part_m[0], part_m[1]), fmaxf(part_m[2], part_m[3]));
   float tot = 0.f;
 #pragma unroll
   for (int w = 0; w < 4; ++w) tot += part_s[w] * __expf(part_m[w] - mx);
   const float inv = 1.f / tot;
-  float pv[TMAX];
+  float pv[TW];
 #pragma unroll
-  for (int t = 0; t < TMAX; ++t) pv[t] = (zc[t] > -INFINITY) ? __expf(zc[t] - mx) * inv : -1.f;  // -1: not a candidate
+  for (int t = 0; t < TW; ++t) pv[t] = (zc[t] > -INFINITY) ? __expf(zc[t] - mx) * inv : -1.f;  // -1: not a candidate
 
   // ---- the top_k largest candidates in the order of torch's stable descending sort (value descending, id ascending):
   // rank j -> sel_v[j], sel_i[j]
@@ -559,27 +566,77 @@ __global__ __launch_bounds__(256) void sample_top_p_k_kernel(const T* __restrict
         sel_i[rank[t]] = l + lane + 64 * t;
       }
   } else {
+    // this wave's top_k, in order, into wl[wave][.] (0 = the wave has fewer candidates)
+    if constexpr (TW <= 2) {
+      // at most 128 candidates per wave: ranked by counting (the short-range method above), no rounds
+      wl[wave][lane] = 0ull;
+      uint64_t key[TW];
+      int rank[TW];
+#pragma unroll
+      for (int t = 0; t < TW; ++t) {
+        key[t] = pv[t] >= 0.f ? ((uint64_t)__float_as_uint(pv[t]) << 32) | (uint32_t)(0x7fffffff - (l + lane + 64 * (t0 + t))) : 0ull;
+        rank[t] = 0;
+      }
+      for (int sl = 0; sl < 64; ++sl) {
+#pragma unroll
+        for (int u = 0; u < TW; ++u) {
+          const uint32_t ohi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(key[u] >> 32), sl);
+          const uint32_t olo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)key[u], sl);
+          const uint64_t ok = ((uint64_t)ohi << 32) | olo;
+#pragma unroll
+          for (int t = 0; t < TW; ++t) rank[t] += (int)(ok > key[t]);
+        }
+      }
+#pragma unroll
+      for (int t = 0; t < TW; ++t)
+        if (key[t] != 0ull && rank[t] < top_k) wl[wave][rank[t]] = key[t];
+    } else {
     uint32_t taken = 0;
     for (int j = 0; j < top_k; ++j) {
       float bv = -1.f;
-      int bt = TMAX;
+      int bt = TW;
 #pragma unroll
-      for (int t = 0; t < TMAX; ++t)
+      for (int t = 0; t < TW; ++t)
         if (!((taken >> t) & 1u) && pv[t] > bv) {  // ascending t = ascending id: the lowest id of equal values stays
           bv = pv[t];
           bt = t;
         }
       // key = (probability bits, 0x7fffffff - id): larger probability first, lower id among equal probabilities; a lane
       // without candidates left offers key 0 (below every candidate, whose low word is positive)
-      const uint64_t mykey = (bt < TMAX) ? ((uint64_t)__float_as_uint(bv) << 32) | (uint32_t)(0x7fffffff - (l + lane + 64 * bt)) : 0ull;
+      const uint64_t mykey = (bt < TW) ? ((uint64_t)__float_as_uint(bv) << 32) | (uint32_t)(0x7fffffff - (l + lane + 64 * (t0 + bt))) : 0ull;
       const uint64_t wkey = wave_max_u64_fast(mykey);
       const int wi = (wkey != 0ull) ? 0x7fffffff - (int)(uint32_t)wkey : 0x7fffffff;
-      if (lane == 0 && wkey != 0ull) {
-        sel_v[j] = __uint_as_float((uint32_t)(wkey >> 32));
-        sel_i[j] = wi;
-      }
-      if (wi != 0x7fffffff && ((wi - l) & 63) == lane) taken |= 1u << ((wi - l) >> 6);
+      if (lane == 0) wl[wave][j] = wkey;
+      if (wi != 0x7fffffff && ((wi - l) & 63) == lane) taken |= 1u << (((wi - l) >> 6) - t0);
     }
+    }
+    __syncthreads();  // (every wave of a SPLIT block gets here: none returned above)
+    if (wave != 0) return;
+    // rank the 4 x top_k survivors by counting: lane j < top_k holds entry j of each wave's list; keys are distinct (distinct
+    // ids) or 0, so the ranks of the non-zero keys are a permutation and the first top_k of them are the block's top_k
+    uint64_t key[4];
+    int rank[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      key[u] = lane < top_k ? wl[u][lane] : 0ull;
+      rank[u] = 0;
+    }
+    for (int sl = 0; sl < top_k; ++sl) {
+#pragma unroll
+      for (int v = 0; v < 4; ++v) {
+        const uint32_t ohi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(key[v] >> 32), sl);
+        const uint32_t olo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)key[v], sl);
+        const uint64_t ok = ((uint64_t)ohi << 32) | olo;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) rank[u] += (int)(ok > key[u]);
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+      if (key[u] != 0ull && rank[u] < top_k) {
+        sel_v[rank[u]] = __uint_as_float((uint32_t)(key[u] >> 32));
+        sel_i[rank[u]] = 0x7fffffff - (int)(uint32_t)key[u];
+      }
   }
   __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0): the LDS writes of this wave are done (one wave, in-order LDS queue)
   __builtin_amdgcn_wave_barrier();

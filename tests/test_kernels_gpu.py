@@ -690,7 +690,7 @@ def test_sample_top_p_k_fused(ops, dtype, top_p, top_k):
     fm = torch.tensor(first, dtype=torch.uint8)
     lo_tab, hi_tab = torch.tensor(lo_t, dtype=torch.int32), torch.tensor(hi_t, dtype=torch.int32)
     q = torch.empty((B, V)).exponential_(1.0, generator=g)
-    for pos in (0, 1, 2, 4, 5):  # 0 = event id position (first_mask), else a parameter position of the row's event
+    for pos in (0, 1, 2, 4, 5, 7):  # 0 = event id position (first_mask), else a parameter position of the row's event (4: `bpm`, 384 ids; 7: `duration`, 2048 ids -- the ranges spread over the four waves)
         want = emu.sample_top_p_k(logits, fm, lo_tab, hi_tab, ev, pos, q, torch.empty((B,), dtype=torch.int64), V, 0.9,
                                   top_p, top_k)
         buf = torch.full((B, 8), -7, dtype=torch.int64, device="cuda")
