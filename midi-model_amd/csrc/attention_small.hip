@@ -502,6 +502,9 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(const T* __restrict__ 
   constexpr int KPW = 64 / LPK;     // keys per wave per iteration
   __shared__ float sh_m[4], sh_l[4];
   __shared__ float sh_o[4][HD];
+  // APPEND: the new position's rotated k row and v row, as the cache holds them -- the block attends to them from here instead of
+  // reading its own stores back through L2 (r04: a write -> read round trip on the critical path of every decode attention launch)
+  __shared__ __attribute__((aligned(16))) T sh_kn[APPEND ? HD : 8], sh_vn[APPEND ? HD : 8];
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const int64_t bh = blockIdx.x;
   const int64_t b = bh / H;
@@ -520,10 +523,16 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(const T* __restrict__ 
       const float k1 = to_f(qrow[D + i]), k2 = to_f(qrow[D + i + half]);
       T* kd = kc + (bh * Lmax + pos) * HD;
       T* vd = vc + (bh * Lmax + pos) * HD;
-      kd[i] = from_f<T>(k1 * c - k2 * sn);
-      kd[i + half] = from_f<T>(k2 * c + k1 * sn);
-      vd[i] = qrow[2 * D + i];
-      vd[i + half] = qrow[2 * D + i + half];
+      const T ka = from_f<T>(k1 * c - k2 * sn), kb2 = from_f<T>(k2 * c + k1 * sn);
+      const T va = qrow[2 * D + i], vb2 = qrow[2 * D + i + half];
+      kd[i] = ka;
+      kd[i + half] = kb2;
+      vd[i] = va;
+      vd[i + half] = vb2;
+      sh_kn[i] = ka;
+      sh_kn[i + half] = kb2;
+      sh_vn[i] = va;
+      sh_vn[i + half] = vb2;
     }
     const int base = ch * N;  // this lane's q elements and their rotation partners (i, i + half)
     Pack<T> qp = ld16(qrow + (base + half) % HD);
@@ -552,7 +561,8 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(const T* __restrict__ 
   // instead of three to five dependent ds_bpermute round trips (same additions in the same order: identical bits).
   constexpr int UNR = 4;
   constexpr int STEP = 4 * KPW * UNR;
-  const int ilen = (int)len;                 // (<= Lmax < 2^24: 32-bit key indices and element offsets from the uniform bases)
+  const int ilen = APPEND ? (int)len - 1 : (int)len;  // (<= Lmax < 2^24: 32-bit key indices and element offsets from the uniform bases;
+                                                      //  APPEND: the rows read from the cache; the new one comes from LDS below)
   const int lane_off = ch * N;
   Pack<T> kvA[UNR], vvA[UNR], kvB[UNR], vvB[UNR];
   bool okA[UNR], okB[UNR];
@@ -599,6 +609,23 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(const T* __restrict__ 
       __builtin_amdgcn_sched_barrier(0);
       reduce(kvB, vvB, okB);
       if (j0 >= ilen) break;
+    }
+  }
+  if constexpr (APPEND) {  // the new position's key / value: lane group 0 of wave 0
+    if (wv == 0) {
+      const Pack<T> kn = ld16(sh_kn + lane_off), vn = ld16(sh_vn + lane_off);
+      float sdot = 0.f;
+#pragma unroll
+      for (int e = 0; e < N; ++e) sdot += q[e] * kn.get(e);
+      sdot = group_sum<LPK>(sdot);
+      if (grp == 0) {
+        const float nm = fmaxf(m, sdot);
+        const float a = __expf(m - nm), p = __expf(sdot - nm);
+        l = l * a + p;
+#pragma unroll
+        for (int e = 0; e < N; ++e) acc[e] = acc[e] * a + p * vn.get(e);
+        m = nm;
+      }
     }
   }
   // merge the KPW lane groups of the wave (lanes with equal `ch`)
