@@ -7,6 +7,7 @@ from __future__ import annotations
 from typing import Optional
 
 import os
+import threading
 
 import torch
 
@@ -45,10 +46,15 @@ def round_up(x: int, m: int) -> int:
 
 
 # ---------------------------------------------------------------------------------------------- GEMM
-_gemm_variant = None
+class _OptionCache(threading.local):
+    """per-thread mirrors of mh_get_option values (the C-ABI's options are thread-local, so are their caches)"""
+    gemm_variant = None
+    attn_v3 = None  # which forms of the event-level attention kernels run (attn_bwd)
 
 
-_attn_v3 = None  # cached mh_get_option("attn_v3"): which forms of the event-level attention kernels run (attn_bwd)
+_tl = _OptionCache()
+
+
 
 
 class ab_library:
@@ -56,49 +62,44 @@ class ab_library:
     kernels, the 128x128 bf16 GEMM and the ablation builds; the cached option values follow the library in use"""
 
     def __enter__(self):
-        global _gemm_variant, _attn_v3
         from .lib import use_ab
         self._ctx = use_ab()
         self._ctx.__enter__()
-        self._saved = (_gemm_variant, _attn_v3)
-        _gemm_variant = _attn_v3 = None
+        self._saved = (_tl.gemm_variant, _tl.attn_v3)
+        _tl.gemm_variant = _tl.attn_v3 = None
         return self
 
     def __exit__(self, *exc):
-        global _gemm_variant, _attn_v3
         self._ctx.__exit__(*exc)
-        _gemm_variant, _attn_v3 = self._saved
+        _tl.gemm_variant, _tl.attn_v3 = self._saved
         return False
 
 
 def set_option(name: str, value: int) -> None:
     """runtime kernel selection (see mh_set_option in include/midihip.h)"""
-    global _gemm_variant, _attn_v3
     lib().call("mh_set_option", name.encode(), int(value))
     if name == "gemm":
-        _gemm_variant = int(value)
+        _tl.gemm_variant = int(value)
     if name == "attn_v3":
-        _attn_v3 = int(value)
+        _tl.attn_v3 = int(value)
 
 
 def get_option(name: str) -> int:
-    global _gemm_variant
     if name == "gemm":
-        if _gemm_variant is None:
-            _gemm_variant = lib().cdll.mh_get_option(b"gemm")
-        return _gemm_variant
+        if _tl.gemm_variant is None:
+            _tl.gemm_variant = lib().cdll.mh_get_option(b"gemm")
+        return _tl.gemm_variant
     return lib().cdll.mh_get_option(name.encode())
 
 
 def _pick_splitk(M: int, N: int, K: int) -> int:
     """Split the contraction when the output has too few tiles to fill 256 CUs (the weight-gradient shapes):
     aim at >= 512 workgroups, keep >= 512 contraction elements per slice."""
-    global _gemm_variant
-    if _gemm_variant is None:
-        _gemm_variant = lib().cdll.mh_get_option(b"gemm")
-    bm = bn = 256 if _gemm_variant != 0 else 128
+    if _tl.gemm_variant is None:
+        _tl.gemm_variant = lib().cdll.mh_get_option(b"gemm")
+    bm = bn = 256 if _tl.gemm_variant != 0 else 128
     tiles = ((M + bm - 1) // bm) * ((N + bn - 1) // bn)
-    per_cu = 1 if _gemm_variant != 0 else 2   # resident workgroups per CU of the active kernel
+    per_cu = 1 if _tl.gemm_variant != 0 else 2   # resident workgroups per CU of the active kernel
     if tiles >= 192 * per_cu or K < 1024:
         return 1
     # fill the 256 CUs once (or twice for the two-per-CU kernel) but never spill a few workgroups into an extra
@@ -391,17 +392,17 @@ def attn_fwd(qkv, o, lse, B: int, S: int, H: int, scale: float):
     """Event-level causal flash attention.  bf16: the third form of the MFMA kernels (attention_mfma3.hip) reads V^T out of
     the row-major V tile with transpose reads; only the first form (mh_set_option("attn_v3", 0), kept for A/B runs) needs
     the prepared [B,H,64,Sp] copy.  fp32: the plain verification kernel."""
-    global _attn_env_read, _attn_v3
+    global _attn_env_read
     if not _attn_env_read:  # (A/B runs: MH_ATTN_V3 = bits 1 forward, 2 dQ, 4 dK/dV, 8 / 16 transpose reads; MH_ATTN_V3_WPS)
         _attn_env_read = True
         if "MH_ATTN_V3" in os.environ:
             set_option("attn_v3", int(os.environ["MH_ATTN_V3"]))
         if "MH_ATTN_V3_WPS" in os.environ:
             set_option("attn_v3_wps", int(os.environ["MH_ATTN_V3_WPS"]))
-    if _attn_v3 is None:
-        _attn_v3 = get_option("attn_v3")
+    if _tl.attn_v3 is None:
+        _tl.attn_v3 = get_option("attn_v3")
     vt = None
-    if qkv.dtype == torch.bfloat16 and (_attn_v3 & 17) != 17:
+    if qkv.dtype == torch.bfloat16 and (_tl.attn_v3 & 17) != 17:
         Sp = round_up(S, 64)
         vt = torch.empty((B * H * 64 * Sp,), dtype=qkv.dtype, device=qkv.device)
         lib().call("mh_attn_prep_fwd", _p(qkv), _p(vt), B, S, H, dt(qkv), _stream())
@@ -411,11 +412,10 @@ def attn_fwd(qkv, o, lse, B: int, S: int, H: int, scale: float):
 
 def attn_bwd(qkv, o, dout, lse, dqkv, B: int, S: int, H: int, scale: float, cos_t=None, sin_t=None):
     """cos_t/sin_t: return the gradient with respect to the UNROTATED q, k (see mh_attn_bwd)"""
-    global _attn_v3
-    if _attn_v3 is None:
-        _attn_v3 = get_option("attn_v3")
+    if _tl.attn_v3 is None:
+        _tl.attn_v3 = get_option("attn_v3")
     Sp = round_up(S, 64)
-    fused = qkv.dtype == torch.bfloat16 and (_attn_v3 & 14) == 14 and (_attn_v3 & 32) != 0
+    fused = qkv.dtype == torch.bfloat16 and (_tl.attn_v3 & 14) == 14 and (_tl.attn_v3 & 32) != 0
     delta = torch.empty(((2 if fused else 1) * B * H * Sp,), dtype=torch.float32, device=qkv.device)
     if fused:
         # (default) one call: the dQ kernel computes delta from its own rows and hands it (and -lse * log2 e) to the dK/dV kernel
@@ -425,7 +425,7 @@ def attn_bwd(qkv, o, dout, lse, dqkv, B: int, S: int, H: int, scale: float, cos_
     qt = kt = dot = None
     # (third form with transpose reads, the default: dQ and dK/dV take Q^T, K^T, dO^T out of the row-major tiles in LDS --
     #  no [B,H,64,Sp] copies, mh_attn_prep_bwd only computes delta)
-    if qkv.dtype == torch.bfloat16 and (_attn_v3 & 14) != 14:
+    if qkv.dtype == torch.bfloat16 and (_tl.attn_v3 & 14) != 14:
         n = B * H * 64 * Sp
         buf = torch.empty((3, n), dtype=qkv.dtype, device=qkv.device)
         qt, kt, dot = buf[0], buf[1], buf[2]
