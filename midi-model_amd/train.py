@@ -343,8 +343,16 @@ class TrainMIDIModel(MIDIModel):
             self.grad_buffer().copy_(state["mh_grad"].to(self._flat.device, self._flat.dtype))
         elif self._micro > 0:
             raise RuntimeError("load_training_state: the checkpoint was taken inside an accumulation window but holds no gradient")
-        hp = state.get("hyper_parameters") or {}
-        for k in ("lr", "weight_decay", "warmup", "max_step"):
+        # the schedule continues from the checkpoint's base learning rate (LambdaLR.state_dict()["base_lrs"]: the lambdas
+        # themselves -- warm-up length, last step -- are not pickled by torch and stay as this object was constructed)
+        sched = (state.get("lr_schedulers") or [{}])[0] or {}
+        if sched.get("base_lrs"):
+            self.lr = float(sched["base_lrs"][0])
+        decay = [g.get("weight_decay") for g in groups if g.get("weight_decay")]
+        if decay:
+            self.weight_decay = float(decay[0])
+        hp = state.get("hyper_parameters") or {}  # (ours: training_state() writes the schedule's shape too)
+        for k in ("warmup", "max_step"):
             if k in hp:
                 setattr(self, k, hp[k])
         return self
