@@ -551,6 +551,8 @@ def main():
                               "value": lg["value"], "unit": "events/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
                               "ms_per_step": lg["ms_per_step"], "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
                               "dtype": args.dtype, "data": "synthetic", "config": {"workload": lg["workload"]}, **res}))
+        if dist is not None:
+            dist.destroy_process_group()
         return
     if args.mode == "block":
         b = measure_block(args, args.block_batch, args.block_seq, max(args.steps, 10), max(args.warmup, 3), dist)

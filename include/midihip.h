@@ -9,7 +9,10 @@
  *  - plain C: raw DEVICE pointers + sizes, no torch types; the caller owns all memory.
  *  - `dtype`: MH_F32 (parity/verification mode) or MH_BF16 (production); statistics (rstd, lse,
  *    losses, norms) and optimiser scalars are always fp32.
- *  - `stream` is a hipStream_t (NULL = default stream).  Calls only enqueue work.
+ *  - `stream` is a hipStream_t (NULL = default stream).  Calls only enqueue work.  The calling thread's CURRENT
+ *    DEVICE must be the device `stream` and the buffers belong to (hipSetDevice before the call; torch keeps it so).
+ *    The library holds no device memory of its own; what it caches (function attributes, one symbol address) is
+ *    cached per device, so one process may drive several GPUs from several threads.
  *  - return 0 on success, <0 on error; mh_last_error() gives the message (thread-local).
  *  - token ids are int64 (torch.long), as on the reference API.
  *  - row-major everywhere; "ld*" are leading dimensions in ELEMENTS.

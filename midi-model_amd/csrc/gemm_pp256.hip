@@ -838,20 +838,34 @@ template <bool TA, bool TB, int ABL, int EPI = 0, int ML = 0>
 int launch_one(const void* A, int64_t lda, const void* B, int64_t ldb, void* C, int64_t ldc, const void* R, int64_t ldr,
                int64_t M, int64_t N, int64_t K, float alpha, float beta, int splitk, void* workspace, hipStream_t st) {
   constexpr int LDSB = LDS_BYTES + ((ABL & 128) ? P8_DBG_BYTES : 0);
-  static bool attr_set = false;
-  static void* zero16 = nullptr;  // 16 zero bytes in device memory: the source of out-of-range LDS-DMA chunks
-  if (zero16 == nullptr && hipGetSymbolAddress(&zero16, HIP_SYMBOL(g_zero16)) != hipSuccess) {
-    mh_set_error("gemm_pp256: hipGetSymbolAddress(g_zero16) failed");
+  // Both caches are PER DEVICE (a symbol's address and a function attribute belong to the device that is current when they
+  // are asked for): a host that drives several GPUs from one process gets each device's own, keyed by the calling thread's
+  // current device -- which is the device of `st`, as for every entry point (include/midihip.h).  Racing first calls write
+  // the same values.
+  constexpr int MAX_DEV = 64;
+  static void* zero16_of[MAX_DEV] = {};  // 16 zero bytes in device memory: the source of out-of-range LDS-DMA chunks
+  static bool attr_set_of[MAX_DEV] = {};
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= MAX_DEV) {
+    mh_set_error("gemm_pp256: no current device (or ordinal %d beyond %d)", dev, MAX_DEV - 1);
     return MH_ERR_LAUNCH;
   }
-  if (!attr_set) {
+  void* zero16 = __atomic_load_n(&zero16_of[dev], __ATOMIC_ACQUIRE);
+  if (zero16 == nullptr) {
+    if (hipGetSymbolAddress(&zero16, HIP_SYMBOL(g_zero16)) != hipSuccess) {
+      mh_set_error("gemm_pp256: hipGetSymbolAddress(g_zero16) failed");
+      return MH_ERR_LAUNCH;
+    }
+    __atomic_store_n(&zero16_of[dev], zero16, __ATOMIC_RELEASE);
+  }
+  if (!__atomic_load_n(&attr_set_of[dev], __ATOMIC_ACQUIRE)) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_pp256_kernel<TA, TB, ABL, EPI, ML>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, LDSB);
     if (e != hipSuccess) {
       mh_set_error("gemm_pp256: cannot raise dynamic LDS to %d bytes: %s", LDSB, hipGetErrorString(e));
       return MH_ERR_LAUNCH;
     }
-    attr_set = true;
+    __atomic_store_n(&attr_set_of[dev], true, __ATOMIC_RELEASE);
   }
   const int64_t tiles_m = (M + QBM - 1) / QBM, tiles_n = (EPI == 2) ? N / 256 : (N + QBN - 1) / QBN;  // (EPI 2: I / 128)
   const int nwg = (int)(tiles_m * tiles_n);
