@@ -55,6 +55,12 @@ class _Lib:
                 f"{path} is missing: the HIP kernels are the only implementation of this path. "
                 "Build them with `python -c 'import __graft_entry__ as g; g.build()'` (needs hipcc).")
         self.path = path
+        # ONE HIP runtime per process.  PyTorch-ROCm carries its own libamdhip64 / ROCr; were this library loaded first, the
+        # loader would bind it to /opt/rocm's copies, `import torch` would bring a second runtime, and whichever of the two
+        # initialises second finds no device ("no ROCm-capable device is detected" at the first launch).  With torch imported
+        # first the library's DT_NEEDED sonames resolve to the copies torch already holds.  (A host without torch links
+        # /opt/rocm's runtime and has nothing to order: INTEGRATION.md.)
+        import torch  # noqa: F401
         self.cdll = ctypes.CDLL(path)
         self.protos = parse_header()
         for name, (ret, args) in self.protos.items():

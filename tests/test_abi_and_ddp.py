@@ -11,6 +11,8 @@ import torch
 
 import midi_model_amd as mm
 
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
 
 def test_abi_exports_every_declared_symbol():
     from midi_model_amd import lib as L
@@ -77,6 +79,24 @@ def test_missing_library_is_a_hard_error(monkeypatch, tmp_path):
     monkeypatch.setattr(L, "_lib", None)
     with pytest.raises(RuntimeError, match="only implementation"):
         L.lib()
+
+
+def test_build_then_use_keeps_one_hip_runtime_in_the_process():
+    """build() in a fresh interpreter (nothing imported yet) must leave exactly one libamdhip64 / ROCr mapped: PyTorch-ROCm ships
+    its own copies, and a library loaded BEFORE torch binds to /opt/rocm's -- the second runtime to initialise then reports
+    "no ROCm-capable device is detected" at the first launch (seen on the GPU box with build() followed by smoke())."""
+    import subprocess
+    import sys
+    code = ("import sys; sys.path.insert(0, %r)\n"
+            "import __graft_entry__ as g\n"
+            "g.build()\n"
+            "import torch\n"
+            "m = sorted(set(l.split()[-1] for l in open('/proc/self/maps') if 'libamdhip64' in l or 'libhsa-runtime64' in l))\n"
+            "print('MAPPED', len([x for x in m if 'libamdhip64' in x]), len([x for x in m if 'libhsa-runtime64' in x]), m)\n") % ROOT
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = [l for l in r.stdout.splitlines() if l.startswith("MAPPED")][-1]
+    assert line.split()[1:3] == ["1", "1"], line
 
 
 def test_grad_reducer_bucketing_single_process():
