@@ -129,6 +129,17 @@ int mh_embed_scatter_bwd(const int64_t* tok, int64_t ldtok, int T, const void* d
  * seg_start[v+1])} dout[src_rows[i]*ld ...]; id `pad_id` is skipped.  n_occ = seg_start[V] = length of src_rows. */
 int mh_embed_segment_bwd(const int64_t* src_rows, const int64_t* seg_start, const void* dout, int64_t ld,
                          float* dtable_f32, int64_t V, int D, int64_t n_occ, int64_t pad_id, int dtype, void* stream);
+/* Index preparation of mh_embed_segment_bwd: a counting sort of the occurrences of the id matrix tok[n_rows, n_cols] (row
+ * stride ldtok) by token id (replaces the reference's implicit scatter of nn.Embedding's backward, TF:models/llama/
+ * modeling_llama.py:353; midi_model.py:126-131,143-145 are the two embeddings).  seg_start[v] (V + 1 entries) = occurrences
+ * with id < v; src_rows[p] = r * row_mul + j * col_mul + add for the occurrence (r, j) placed at p -- the row of the gradient
+ * matrix it reads: (1, 0, 0) for the summed event embedding, (T, 1, 1) for the token-sequence embedding.  Ids outside [0, V)
+ * are a caller error (nn.Embedding raises); they are grouped behind seg_start[V], nothing is written out of bounds.
+ * `work`: int32 scratch of (ceil(n_rows * n_cols / mh_token_segments_chunk()) + 1) * (V + 1) elements.  The order inside a
+ * segment is unspecified. */
+int mh_token_segments_chunk(void);
+int mh_token_segments(const int64_t* tok, int64_t ldtok, int64_t n_rows, int n_cols, int64_t V, int64_t row_mul,
+                      int64_t col_mul, int64_t add, int64_t* src_rows, int64_t* seg_start, int32_t* work, void* stream);
 /* dst[i] (dtype) = (accumulate ? dst[i] : 0) + src_f32[i] */
 int mh_cast_from_f32(const float* src, void* dst, int64_t n, int accumulate, int dtype, void* stream);
 /* strided row copy: dst[m,:] = src[m*src_ld ...] (+ optional accumulate) — takes d(hidden) out of d(token seq). */

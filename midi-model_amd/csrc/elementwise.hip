@@ -259,6 +259,118 @@ extern "C" int mh_embed_segment_bwd(const int64_t* src_rows, const int64_t* seg_
   return MH_OK;
 }
 
+// ---- token segments: the index preparation of embed_segment_bwd as a counting sort (r04; it was torch.sort + searchsorted +
+// five index-arithmetic launches, ~25 library launches per call in the timed region of the training step).
+// Occurrence i of the [n_rows, n_cols] id matrix (row r = i / n_cols, column j = i % n_cols) is grouped by token id:
+// seg_start[v] = number of occurrences with id < v (v = 0 .. V; ids outside [0, V) -- a caller error, nn.Embedding raises -- are
+// grouped AFTER seg_start[V] so that nothing is written out of bounds), src_rows[p] = r * row_mul + j * col_mul + add for the
+// occurrence placed at p (the row of the gradient matrix that occurrence reads).  Three launches: per-chunk histograms in LDS,
+// a running sum over the chunks per id, placement (LDS cursor per id; the order inside a segment is whatever order the LDS
+// atomics return -- embed_segment_bwd adds a segment's rows with fp32 atomics across waves, so no order was ever promised).
+// Integer work, HBM-bound and tiny: 8 bytes read + 8 written per occurrence.
+constexpr int SEG_CH = 2048;  // occurrences per workgroup
+
+__device__ inline int seg_bucket(int64_t id, int V) { return (id >= 0 && id < V) ? (int)id : V; }
+
+__global__ __launch_bounds__(256) void token_hist_kernel(const int64_t* __restrict__ tok, int64_t ld, int64_t n, int ncol, int V,
+                                                         int32_t* __restrict__ cnt) {
+  extern __shared__ int seg_lds[];  // V + 1 counters
+  for (int v = threadIdx.x; v <= V; v += 256) seg_lds[v] = 0;
+  __syncthreads();
+  const int64_t i0 = (int64_t)blockIdx.x * SEG_CH;
+#pragma unroll
+  for (int s = 0; s < SEG_CH / 256; ++s) {
+    const int64_t i = i0 + s * 256 + threadIdx.x;
+    if (i < n) {
+      const int64_t r = i / ncol;
+      atomicAdd(&seg_lds[seg_bucket(tok[r * ld + (i - r * ncol)], V)], 1);
+    }
+  }
+  __syncthreads();
+  int32_t* out = cnt + (int64_t)blockIdx.x * (V + 1);
+  for (int v = threadIdx.x; v <= V; v += 256) out[v] = seg_lds[v];
+}
+
+// cnt[b][v] -> number of occurrences of id v in the chunks before b; tot[v] = all of them
+__global__ __launch_bounds__(256) void token_colscan_kernel(int32_t* __restrict__ cnt, int nb, int V, int32_t* __restrict__ tot) {
+  const int v = blockIdx.x * 256 + threadIdx.x;
+  if (v > V) return;
+  int run = 0;
+  for (int b = 0; b < nb; ++b) {
+    int32_t* p = cnt + (int64_t)b * (V + 1) + v;
+    const int c = *p;
+    *p = run;
+    run += c;
+  }
+  tot[v] = run;
+}
+
+__global__ __launch_bounds__(256) void token_place_kernel(const int64_t* __restrict__ tok, int64_t ld, int64_t n, int ncol, int V,
+                                                          const int32_t* __restrict__ cnt, const int32_t* __restrict__ tot,
+                                                          int64_t row_mul, int64_t col_mul, int64_t add,
+                                                          int64_t* __restrict__ src_rows, int64_t* __restrict__ seg_start) {
+  extern __shared__ int seg_lds[];  // V + 1 cursors: next position of id v for this chunk
+  __shared__ int wsum[4];
+  // exclusive scan of tot over the ids (every workgroup repeats it: V + 1 values, cheaper than a launch of its own)
+  const int per = (V + 1 + 255) / 256, v0 = threadIdx.x * per;
+  int mine = 0;
+  for (int k = 0; k < per; ++k)
+    if (v0 + k <= V) mine += tot[v0 + k];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  int inc = mine;
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    const int o = __shfl_up(inc, d);
+    if (lane >= d) inc += o;
+  }
+  if (lane == 63) wsum[wave] = inc;
+  __syncthreads();
+  int start = inc - mine;
+  for (int w = 0; w < wave; ++w) start += wsum[w];
+  const int32_t* mycnt = cnt + (int64_t)blockIdx.x * (V + 1);
+  for (int k = 0; k < per; ++k) {
+    const int v = v0 + k;
+    if (v <= V) {
+      if (blockIdx.x == 0) seg_start[v] = start;
+      seg_lds[v] = start + mycnt[v];
+      start += tot[v];
+    }
+  }
+  __syncthreads();
+  const int64_t i0 = (int64_t)blockIdx.x * SEG_CH;
+#pragma unroll
+  for (int s = 0; s < SEG_CH / 256; ++s) {
+    const int64_t i = i0 + s * 256 + threadIdx.x;
+    if (i < n) {
+      const int64_t r = i / ncol;
+      const int64_t j = i - r * ncol;
+      const int p = atomicAdd(&seg_lds[seg_bucket(tok[r * ld + j], V)], 1);
+      src_rows[p] = r * row_mul + j * col_mul + add;
+    }
+  }
+}
+
+extern "C" int mh_token_segments_chunk(void) { return SEG_CH; }
+
+extern "C" int mh_token_segments(const int64_t* tok, int64_t ldtok, int64_t n_rows, int n_cols, int64_t V, int64_t row_mul,
+                                 int64_t col_mul, int64_t add, int64_t* src_rows, int64_t* seg_start, int32_t* work,
+                                 void* stream) {
+  MH_REQUIRE(tok && src_rows && seg_start && work, "token_segments: null argument");
+  MH_REQUIRE(n_rows > 0 && n_cols > 0 && ldtok >= n_cols && V > 0 && V < 16000, "token_segments: bad shape rows=%ld cols=%d V=%ld",
+             (long)n_rows, n_cols, (long)V);
+  const int64_t n = n_rows * n_cols;
+  MH_REQUIRE(n < (1ll << 31), "token_segments: %ld occurrences (positions are 32-bit)", (long)n);
+  const int nb = (int)((n + SEG_CH - 1) / SEG_CH);
+  int32_t* tot = work + (int64_t)nb * (V + 1);
+  const size_t lds = (size_t)(V + 1) * sizeof(int);
+  hipStream_t st = (hipStream_t)stream;
+  token_hist_kernel<<<nb, 256, lds, st>>>(tok, ldtok, n, n_cols, (int)V, work);
+  token_colscan_kernel<<<(int)((V + 1 + 255) / 256), 256, 0, st>>>(work, nb, (int)V, tot);
+  token_place_kernel<<<nb, 256, lds, st>>>(tok, ldtok, n, n_cols, (int)V, work, tot, row_mul, col_mul, add, src_rows, seg_start);
+  MH_LAUNCH_CHECK();
+  return MH_OK;
+}
+
 template <typename T>
 __global__ __launch_bounds__(256) void cast_from_f32_kernel(const float* __restrict__ src, T* __restrict__ dst, int64_t n,
                                                             int accumulate) {

@@ -332,12 +332,26 @@ def embed_scatter_bwd(tok: torch.Tensor, T: int, dout: torch.Tensor, rows_per_m:
                pad_id, dt(dout), _stream())
 
 
-def token_segments(tok_flat: torch.Tensor, V: int):
-    """Index preparation for embed_segment_bwd: (order, seg_start) with `order` the occurrence indices sorted by
-    token id and seg_start[v] the first sorted position of id v (length V+1)."""
-    sorted_tok, order = torch.sort(tok_flat)
-    seg = torch.searchsorted(sorted_tok, torch.arange(V + 1, device=tok_flat.device, dtype=tok_flat.dtype))
-    return order, seg.contiguous()
+def token_segments(tok: torch.Tensor, V: int, row_mul: Optional[int] = None, col_mul: int = 1, add: int = 0):
+    """Index preparation for embed_segment_bwd (mh_token_segments: a counting sort on the device, three launches): tok is the id
+    matrix [n_rows, n_cols] (int64, unit column stride, any row stride -- a column slice of a wider matrix is fine) or a flat
+    vector.  -> (src_rows, seg_start): seg_start[v] (V + 1 entries) = occurrences with id < v, src_rows[p] = r * row_mul +
+    j * col_mul + add for the occurrence (row r, column j) placed at p.  The default mapping (row_mul = n_cols, 1, 0) makes
+    src_rows the occurrence indices grouped by id (`order`)."""
+    if tok.dim() == 1:
+        tok = tok.view(-1, 1)
+    assert tok.dim() == 2 and tok.dtype == torch.int64 and tok.stride(1) == 1
+    n_rows, n_cols = tok.shape
+    if row_mul is None:
+        row_mul = n_cols
+    n = n_rows * n_cols
+    chunk = lib().cdll.mh_token_segments_chunk()
+    work = torch.empty((((n + chunk - 1) // chunk) + 1) * (V + 1), dtype=torch.int32, device=tok.device)
+    src = torch.empty(n, dtype=torch.int64, device=tok.device)
+    seg = torch.empty(V + 1, dtype=torch.int64, device=tok.device)
+    lib().call("mh_token_segments", _p(tok), tok.stride(0), n_rows, n_cols, V, row_mul, col_mul, add, _p(src), _p(seg), _p(work),
+               _stream())
+    return src, seg
 
 
 def embed_segment_bwd(src_rows: torch.Tensor, seg_start: torch.Tensor, dout: torch.Tensor, ld: int,

@@ -554,9 +554,8 @@ class TrainMIDIModel(MIDIModel):
                                      self.rope("net_token"), accumulate, tok_done)
         del dh, ctx_tok
         acc32 = torch.zeros((V, D), dtype=torch.float32, device=dev)
-        order, seg = ops.token_segments(y_t[:, : T - 1].reshape(-1), V)
-        src = torch.div(order, T - 1, rounding_mode="floor") * T + order % (T - 1) + 1  # row of dseq per occurrence
-        ops.embed_segment_bwd(src.contiguous(), seg, dseq, D, acc32, tok.pad_id)
+        src, seg = ops.token_segments(y_t[:, : T - 1], V, row_mul=T, col_mul=1, add=1)  # row of dseq per occurrence
+        ops.embed_segment_bwd(src, seg, dseq, D, acc32, tok.pad_id)
         ops.cast_from_f32(acc32, self._G["net_token"].embed, accumulate)
         o, n, _ = self._offsets["net_token.embed_tokens.weight"]
         self._announce(red, o, o + n)
@@ -576,8 +575,8 @@ class TrainMIDIModel(MIDIModel):
         dx = engine.stack_backward(spec, Wn, self._G["net"], ctx_net, dhidden, self.rope("net"),
                                    accumulate, net_done)
         acc32.zero_()
-        order, seg = ops.token_segments(x.view(-1), V)
-        ops.embed_segment_bwd(torch.div(order, T, rounding_mode="floor").contiguous(), seg, dx, D, acc32, tok.pad_id)
+        src, seg = ops.token_segments(x.view(-1, T), V, row_mul=1, col_mul=0, add=0)  # every token of an event reads the event's row
+        ops.embed_segment_bwd(src, seg, dx, D, acc32, tok.pad_id)
         ops.cast_from_f32(acc32, self._G["net"].embed, accumulate)
         o, n, _ = self._offsets["net.embed_tokens.weight"]
         self._announce(red, o, o + n)

@@ -209,10 +209,16 @@ def embed_scatter_bwd(tok, T, dout, rows_per_m, jstride, j0, dtable_f32, pad_id)
         dtable_f32.index_add_(0, ids[keep], d[rows[keep]])
 
 
-def token_segments(tok_flat, V):
-    sorted_tok, order = torch.sort(tok_flat, stable=True)
-    seg = torch.searchsorted(sorted_tok, torch.arange(V + 1, dtype=tok_flat.dtype))
-    return order, seg.contiguous()
+def token_segments(tok, V, row_mul=None, col_mul=1, add=0):
+    if tok.dim() == 1:
+        tok = tok.view(-1, 1)
+    n_rows, n_cols = tok.shape
+    if row_mul is None:
+        row_mul = n_cols
+    sorted_tok, order = torch.sort(tok.reshape(-1), stable=True)
+    seg = torch.searchsorted(sorted_tok, torch.arange(V + 1, dtype=tok.dtype))
+    src = torch.div(order, n_cols, rounding_mode="floor") * row_mul + (order % n_cols) * col_mul + add
+    return src, seg.contiguous()
 
 
 def embed_segment_bwd(src_rows, seg_start, dout, ld, dtable_f32, pad_id):

@@ -276,6 +276,38 @@ def test_gemm_dswiglu(ops, main_loop, M, I, K):
     cmp(fused, two.cpu(), dt, k=8, what="gemm_dswiglu vs two launches")
 
 
+@pytest.mark.parametrize("n_rows,n_cols,ld,V", [(5, 7, 8, 3406), (293, 7, 8, 3406), (4096, 8, 8, 3406), (32768, 7, 8, 3406), (1, 1, 1, 5),
+                                                (3000, 3, 5, 17)])
+def test_token_segments_is_a_grouping_of_the_occurrences_by_id(ops, n_rows, n_cols, ld, V):
+    """mh_token_segments (counting sort on the device) against torch.sort + searchsorted: identical segment starts, the
+    placement is a permutation of the occurrences with every position inside its id's segment, and the row mapping
+    r * row_mul + j * col_mul + add is applied to the placed occurrence (the order inside a segment is unspecified)."""
+    g = torch.Generator().manual_seed(n_rows * 31 + n_cols)
+    wide = torch.randint(0, V, (n_rows, ld), generator=g)
+    wide[: n_rows // 2, 0] = 3 % V  # one heavily repeated id
+    tok = wide[:, :n_cols]  # a column slice: row stride ld
+    flat = tok.reshape(-1)
+    sorted_tok, _ = torch.sort(flat)
+    seg_ref = torch.searchsorted(sorted_tok, torch.arange(V + 1))
+    order, seg = ops.token_segments(tok.cuda(), V)
+    torch.cuda.synchronize()
+    order, seg = order.cpu(), seg.cpu()
+    assert torch.equal(seg, seg_ref)
+    assert torch.equal(torch.sort(order)[0], torch.arange(flat.numel()))  # a permutation of the occurrence indices
+    assert torch.equal(flat[order], sorted_tok)                           # grouped by id, ids ascending
+    src, seg2 = ops.token_segments(tok.cuda(), V, row_mul=ld, col_mul=1, add=1)
+    src = src.cpu()
+    assert torch.equal(seg2.cpu(), seg_ref)
+    # decode the mapping back to (r, j) and compare the id found there with the segment the position lies in
+    r, j = (src - 1) // ld, (src - 1) % ld
+    assert int(j.max()) < n_cols
+    assert torch.equal(wide[r, j], sorted_tok)
+    assert torch.equal(torch.sort(r * n_cols + j)[0], torch.arange(flat.numel()))
+    src1, _ = ops.token_segments(tok.cuda(), V, row_mul=1, col_mul=0, add=0)  # the summed event embedding: every token reads row r
+    counts = torch.bincount(src1.cpu(), minlength=n_rows)
+    assert torch.equal(counts, torch.full((n_rows,), n_cols))
+
+
 # ------------------------------------------------------------------------------------------ embeddings
 @pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("D,M", [(256, 77), (1024, 700), (2048, 150)])
