@@ -81,6 +81,25 @@ def test_missing_library_is_a_hard_error(monkeypatch, tmp_path):
         L.lib()
 
 
+def test_header_is_plain_c_and_a_c_host_can_call_the_library(tmp_path):
+    """include/midihip.h is the boundary for hosts in ANY language: it must compile as strict C99 (no C++isms, no torch types),
+    and a C program must be able to open the library, find every declared symbol and use the error / option entry points."""
+    import shutil
+    import subprocess
+    from midi_model_amd import lib as L
+    gcc = shutil.which("gcc")
+    assert gcc, "gcc is part of the image"
+    exe = str(tmp_path / "host")
+    r = subprocess.run([gcc, "-std=c99", "-Wall", "-Wextra", "-Werror", "-pedantic", "-I", os.path.join(ROOT, "include"),
+                        os.path.join(ROOT, "tests", "c_host", "host.c"), "-o", exe, "-ldl"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    names = sorted(L.parse_header())
+    for path, ab in ((L.LIB_PATH, 0), (L.AB_LIB_PATH, 1)):
+        r = subprocess.run([exe, path] + names, capture_output=True, text=True, timeout=120)
+        assert r.returncode == 0, (r.returncode, r.stdout, r.stderr)
+        assert f"A/B library {ab}" in r.stdout and f"{len(names)} symbols" in r.stdout, r.stdout
+
+
 def test_build_then_use_keeps_one_hip_runtime_in_the_process():
     """build() in a fresh interpreter (nothing imported yet) must leave exactly one libamdhip64 / ROCr mapped: PyTorch-ROCm ships
     its own copies, and a library loaded BEFORE torch binds to /opt/rocm's -- the second runtime to initialise then reports
