@@ -71,6 +71,10 @@ def _load_oracle():
 def cpu_baseline(sample_S: int, seed: int = 0):
     """The oracle's training step (fwd + autograd bwd + clip + AdamW, fp32) on the host cores, B=1."""
     orc = _load_oracle()
+    # attention through torch's fused scaled_dot_product_attention, the call the reference makes (TF:integrations/sdpa_attention.py):
+    # with the oracle's explicit scores / softmax the timed step was 2x slower than the REAL reference on the same cores, with it
+    # the two agree (tools/cpu_reference_vs_port.py ran both in the build container: profiles/r04_cpu_reference_vs_port.txt)
+    orc.FUSED_SDPA = True
     import midi_model_amd as mm
     # With one thread per core of the GPU box's 256-core host the step collapsed to 2.4 events/s (421 s for
     # 1024 events: oversubscribed GEMMs, profiles/r01_run1_bench.json); the baseline is therefore bounded to
@@ -92,7 +96,9 @@ def cpu_baseline(sample_S: int, seed: int = 0):
             orc.adamw_step(p, p.grad * coef, m[k], v2[k], 1, 2e-4, 0.01 if orc.decays(k) else 0.0)
     dt = time.perf_counter() - t0
     return {"value": sample_S / dt, "unit": "events/s", "cores": cores, "kind": "port",
-            "sample": f"1 training step (fwd+bwd+clip+AdamW) of the CPU oracle, fp32, batch 1 x {sample_S} events, {dt:.1f} s",
+            "sample": f"1 training step (fwd+bwd+clip+AdamW) of the CPU oracle (attention through torch SDPA, as the reference), fp32, "
+                      f"batch 1 x {sample_S} events, {dt:.1f} s; in the build container the REAL reference and this form agree within run-to-run "
+                      f"noise (214-255 vs 214-247 events/s on 8 cores, profiles/r04_cpu_reference_vs_port.txt)",
             "loss": float(loss.detach())}
 
 

@@ -69,11 +69,22 @@ def rope(x: Tensor, cos: Tensor, sin: Tensor) -> Tensor:
     return x * cos + rot * sin
 
 
+# bench.py's cpu_baseline leg sets this: the attention of an un-cached forward then runs through
+# torch.nn.functional.scaled_dot_product_attention(is_causal=True) -- the very call the reference makes
+# (TF:integrations/sdpa_attention.py:79-166) -- instead of the explicit scores / softmax / product below, which
+# materialises B x H x T x T scores and made the TIMED step 2x slower than the reference on the same cores
+# (tools/cpu_reference_vs_port.py, profiles/r04_cpu_reference_vs_port.txt).  Parity tests keep the explicit form;
+# tests/test_oracle_golden.py pins the fused form to it.
+FUSED_SDPA = False
+
+
 def attention(q: Tensor, k: Tensor, v: Tensor, causal: bool) -> Tensor:
     """q: (B,H,Tq,hd), k/v: (B,H,Tk,hd).  With a cache Tk >= Tq and query i sits at absolute
     position Tk-Tq+i.  The reference passes no padding mask, so the only mask is the causal one,
     applied when Tq > 1 (sdpa_attention.py:120)."""
     hd = q.shape[-1]
+    if FUSED_SDPA and q.shape[-2] == k.shape[-2]:
+        return torch.nn.functional.scaled_dot_product_attention(q, k, v, is_causal=causal and q.shape[-2] > 1)
     s = torch.matmul(q, k.transpose(-1, -2)) * (hd ** -0.5)
     tq, tk = q.shape[-2], k.shape[-2]
     if causal and tq > 1:

@@ -32,7 +32,11 @@ def test_forward_and_cache(orc, tiny, golden):
     np.testing.assert_allclose(h.numpy(), g["hidden_cached"], rtol=1e-4, atol=2e-5)
 
 
-def test_loss_logits_grads(orc, tiny, golden):
+@pytest.mark.parametrize("fused_sdpa", [False, True])
+def test_loss_logits_grads(orc, tiny, golden, fused_sdpa, monkeypatch):
+    """(fused_sdpa: the form bench.py's cpu_baseline times -- attention through torch's scaled_dot_product_attention, the call the
+    reference itself makes -- is pinned to the same reference outputs as the explicit form)"""
+    monkeypatch.setattr(orc, "FUSED_SDPA", fused_sdpa)
     shp, sd, batch = tiny
     g = golden("tiny_train.npz")
     sd = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
