@@ -313,7 +313,9 @@ int mh_sample_top_p_k(const void* logits, int64_t ldl, const uint8_t* first_mask
  * mh_comm_unique_id: rank 0 fills 128 bytes (ncclGetUniqueId) that the host ships to every rank;
  * mh_comm_init: ncclCommInitRank on `device`; *comm_out is the handle;
  * mh_comm_allreduce: IN PLACE over buf[count] on `stream`; mean != 0 averages over the ranks inside the collective
- *   (pre-multiplied sum, scale 1/world) -- DDP's divide-then-sum as one pass; mean == 0 sums;
+ *   (pre-multiplied sum, scale 1/world) -- DDP's divide-then-sum as one pass; mean == 0 sums.  The scale is 1/world rounded
+ *   to the buffer's dtype: exact for power-of-two worlds (1, 2, 4, 8 GPUs of a node); for other worlds a bf16 contribution is
+ *   multiplied by bf16(1/world) where DDP divides by world -- a difference of one rounding of the scale;
  * mh_comm_broadcast: buf[count] from `root` to every rank, in place;  mh_comm_info: rank / world / RCCL version code.  */
 int mh_comm_unique_id(void* id128);
 int mh_comm_init(int rank, int world, const void* id128, int device, void** comm_out);
