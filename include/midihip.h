@@ -101,7 +101,11 @@ int mh_gemm_splitk_reduce(const void* workspace, void* C, int64_t ldc, const voi
  * K a multiple of 256.  norm_eps > 0: every row of the product is scaled by rsqrt(mean_k A[m,k]^2 + norm_eps) before
  * the epilogue -- with the RMSNorm weight folded into W by the caller this is LlamaRMSNorm (:62-67) + projection.
  * row_ids / res_ids (optional, int64 [M]): row m of A / of R is row ids[m] of the given table (nn.Embedding lookup of
- * the token just sampled, midi_model.py:126-131, without a launch of its own).                                   */
+ * the token just sampled, midi_model.py:126-131, without a launch of its own).
+ * LIMITS (32-bit element offsets inside the kernel): N * ldw (2 N * ldw for GATEUP), 64 * lda, 64 * ldc, 64 * ldr < 2^31 are
+ * checked by the entry point; with row_ids / res_ids the ids live in device memory, so the CALLER guarantees
+ * (max id + 1) * lda < 2^31 and (max id + 1) * ldr < 2^31 elements (a gathered table of at most 2^31 - 1 bf16 elements = 4 GiB;
+ * this model's embedding tables hold 3.5 M).  A larger table needs the lookup done by the caller (mh_copy_rows). */
 #define MH_SKINNY_PLAIN 0
 #define MH_SKINNY_GATEUP 1
 int mh_gemm_skinny(const void* A, int64_t lda, const void* W, int64_t ldw, void* C, int64_t ldc, const void* R,
@@ -316,7 +320,9 @@ int mh_sample_top_p_k(const void* logits, int64_t ldl, const uint8_t* first_mask
  *   (pre-multiplied sum, scale 1/world) -- DDP's divide-then-sum as one pass; mean == 0 sums.  The scale is 1/world rounded
  *   to the buffer's dtype: exact for power-of-two worlds (1, 2, 4, 8 GPUs of a node); for other worlds a bf16 contribution is
  *   multiplied by bf16(1/world) where DDP divides by world -- a difference of one rounding of the scale;
- * mh_comm_broadcast: buf[count] from `root` to every rank, in place;  mh_comm_info: rank / world / RCCL version code.  */
+ * mh_comm_broadcast: buf[count] from `root` to every rank, in place;  mh_comm_info: rank / world / RCCL version code.
+ * mh_comm_init leaves the calling thread's current device as it found it.  Handles are tracked: a call on a handle that was
+ * never returned by mh_comm_init, or was already destroyed, returns MH_ERR_ARG (it is not dereferenced).              */
 int mh_comm_unique_id(void* id128);
 int mh_comm_init(int rank, int world, const void* id128, int device, void** comm_out);
 int mh_comm_info(void* comm, int* rank, int* world, int* rccl_version);

@@ -80,6 +80,11 @@ class MHComm:
             self._h = None
 
     def __del__(self):
+        # (not during interpreter teardown: ncclCommDestroy would run against a HIP runtime / librccl that may already be
+        #  finalising; the process exit frees the communicator)
+        import sys
+        if sys is None or sys.is_finalizing():
+            return
         try:
             self.close()
         except Exception:

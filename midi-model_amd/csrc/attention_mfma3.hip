@@ -31,13 +31,21 @@
 //  * the forward keeps three K/V stages in LDS (bit 6; counted vmcnt wait): a tile's requests get two tile times to land.
 // Bound: VALU issue slots and per-wave serialisation at head_dim 64, not the matrix pipe (39 % busy) -- DESIGN.md section 4,
 // "the SIMD issue model".
+#include <stdlib.h>
+
 #include "attn_mfma_common.h"
 
-thread_local int g_attn_v3 = 127;     // mh_set_option("attn_v3", bits): 1 forward, 2 dQ, 4 dK/dV, 8 transpose reads in dQ + dK/dV (needs 2 | 4),
+// (both start from the environment in EVERY host thread -- MH_ATTN_V3, MH_ATTN_V3_WPS, as MH_GEMM does in api.cpp -- so an A/B run
+// selected by the environment also reaches launches made from other threads, e.g. autograd's backward thread)
+static int attn_env_int(const char* name, int dflt) {
+  const char* v = getenv(name);
+  return (v && *v) ? atoi(v) : dflt;
+}
+thread_local int g_attn_v3 = attn_env_int("MH_ATTN_V3", 127);     // mh_set_option("attn_v3", bits): 1 forward, 2 dQ, 4 dK/dV, 8 transpose reads in dQ + dK/dV (needs 2 | 4),
                         // 16 transpose reads in the forward (needs 1; the caller then passes no V^T copy), 32 the host side
                         // calls mh_attn_bwd_o (delta computed inside the dQ kernel; needs 2 | 4 | 8), 64 three K/V stages
                         // in the forward (needs 1 | 16)
-thread_local int g_attn_v3_wps = 0;  // mh_set_option("attn_v3_wps", n): register budget (waves per SIMD) override for A/B runs, 0 = default
+thread_local int g_attn_v3_wps = attn_env_int("MH_ATTN_V3_WPS", 0);  // mh_set_option("attn_v3_wps", n): register budget (waves per SIMD) override for A/B runs, 0 = default
 
 __device__ inline bf16x8 ldsv(const char* p) { return *reinterpret_cast<const bf16x8*>(p); }
 // eight consecutive accumulator registers -> one bf16 operand fragment, as four explicit two-element conversions (each one

@@ -22,6 +22,7 @@
 #include <string.h>
 
 #include <mutex>
+#include <set>
 
 #include "common.h"
 
@@ -98,9 +99,19 @@ struct Comm {
 };
 constexpr uint32_t MAGIC = 0x4d48434du;  // "MHCM"
 
+// Live handles: a handle is only dereferenced while it is in this set, so a second mh_comm_destroy, or any call after destroy,
+// is refused instead of reading freed memory.
+std::mutex g_live_mu;
+std::set<void*> g_live;
+
 Comm* as_comm(void* h) {
+  if (h == nullptr) return nullptr;
+  {
+    std::lock_guard<std::mutex> lk(g_live_mu);
+    if (g_live.find(h) == g_live.end()) return nullptr;
+  }
   Comm* c = static_cast<Comm*>(h);
-  return (c && c->magic == MAGIC) ? c : nullptr;
+  return (c->magic == MAGIC) ? c : nullptr;
 }
 
 }  // namespace
@@ -119,8 +130,17 @@ extern "C" int mh_comm_init(int rank, int world, const void* id128, int device, 
   MH_REQUIRE(comm_out != nullptr && id128 != nullptr, "comm_init: null argument");
   MH_REQUIRE(world >= 1 && rank >= 0 && rank < world, "comm_init: rank %d of %d", rank, world);
   if (!api_ready()) return MH_ERR_UNSUPPORTED;
+  // ncclCommInitRank binds the communicator to the CURRENT device: switch for the call and give the caller's device back
+  int prev_dev = -1;
+  (void)hipGetDevice(&prev_dev);
   hipError_t e = hipSetDevice(device);
   MH_REQUIRE(e == hipSuccess, "comm_init: hipSetDevice(%d): %s", device, hipGetErrorString(e));
+  struct Restore {
+    int d;
+    ~Restore() {
+      if (d >= 0) (void)hipSetDevice(d);
+    }
+  } restore{prev_dev};
   Comm* c = new Comm();
   c->magic = MAGIC;
   c->rank = rank;
@@ -149,6 +169,10 @@ extern "C" int mh_comm_init(int rank, int world, const void* id128, int device, 
     return MH_ERR_LAUNCH;
   }
   c->have_mean = true;
+  {
+    std::lock_guard<std::mutex> lk(g_live_mu);
+    g_live.insert(c);
+  }
   *comm_out = c;
   return MH_OK;
 }
@@ -186,7 +210,11 @@ extern "C" int mh_comm_broadcast(void* comm, void* buf, int64_t count, int dtype
 
 extern "C" int mh_comm_destroy(void* comm) {
   Comm* c = as_comm(comm);
-  MH_REQUIRE(c != nullptr, "comm_destroy: not a communicator handle");
+  MH_REQUIRE(c != nullptr, "comm_destroy: not a (live) communicator handle");
+  {
+    std::lock_guard<std::mutex> lk(g_live_mu);
+    g_live.erase(comm);
+  }
   if (c->have_mean) {
     g_api.RedOpDestroy(c->mean_bf16, c->comm);
     g_api.RedOpDestroy(c->mean_f32, c->comm);

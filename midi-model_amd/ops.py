@@ -399,20 +399,13 @@ def rope_(qkv: torch.Tensor, cos_t: torch.Tensor, sin_t: torch.Tensor, S: int, p
 
 
 # ----------------------------------------------------------------------------------------- attention
-_attn_env_read = False
-
-
 def attn_fwd(qkv, o, lse, B: int, S: int, H: int, scale: float):
     """Event-level causal flash attention.  bf16: the third form of the MFMA kernels (attention_mfma3.hip) reads V^T out of
     the row-major V tile with transpose reads; only the first form (mh_set_option("attn_v3", 0), kept for A/B runs) needs
     the prepared [B,H,64,Sp] copy.  fp32: the plain verification kernel."""
-    global _attn_env_read
-    if not _attn_env_read:  # (A/B runs: MH_ATTN_V3 = bits 1 forward, 2 dQ, 4 dK/dV, 8 / 16 transpose reads; MH_ATTN_V3_WPS)
-        _attn_env_read = True
-        if "MH_ATTN_V3" in os.environ:
-            set_option("attn_v3", int(os.environ["MH_ATTN_V3"]))
-        if "MH_ATTN_V3_WPS" in os.environ:
-            set_option("attn_v3_wps", int(os.environ["MH_ATTN_V3_WPS"]))
+    # (A/B runs: the environment variables MH_ATTN_V3 / MH_ATTN_V3_WPS set every host thread's initial value inside the
+    #  library; set_option / mh_set_option act on the CALLING thread only -- autograd's backward runs on its own thread, so an
+    #  A/B of a backward kernel through loss.backward() goes by the environment, or calls ops.attn_bwd directly)
     if _tl.attn_v3 is None:
         _tl.attn_v3 = get_option("attn_v3")
     vt = None

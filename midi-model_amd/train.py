@@ -55,9 +55,14 @@ class GradReducer:
         self.comm = comm
         self.force = bool(force)
         if comm is not None:
+            if not flat_grad.is_cuda:
+                raise ValueError("GradReducer: an MHComm (RCCL) communicator needs the flat gradient buffer on the device")
             self.world = comm.world
         else:
             self.world = dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
+            if self.force and not (dist.is_available() and dist.is_initialized()):
+                raise RuntimeError("GradReducer(force=True) runs the real collective at world size 1: it needs `comm` or an "
+                                   "initialised torch.distributed process group")
         self.bucket_elems = max(1, bucket_bytes // flat_grad.element_size())
         self.pending: Optional[Tuple[int, int]] = None
         self.works: list = []
@@ -118,16 +123,19 @@ class GradReducer:
         cover = sorted(self.launched + ([self.pending] if self.pending is not None else []))
         problem = None
         if cover:
-            want = self.expected if self.expected is not None else [(0, self.flat.numel())]
-            merged = []
-            for a in cover:
-                if merged and merged[-1][1] == a[0]:
-                    merged[-1] = (merged[-1][0], a[1])
-                else:
-                    merged.append(a)
+            def merge(ranges):  # adjacent ranges fused: [(0, 40), (40, 100)] and [(0, 100)] are the same cover
+                out = []
+                for a in sorted(ranges):
+                    if out and out[-1][1] == a[0]:
+                        out[-1] = (out[-1][0], a[1])
+                    else:
+                        out.append(tuple(a))
+                return out
+            want = merge(self.expected if self.expected is not None else [(0, self.flat.numel())])
+            merged = merge(cover)
             overlap = any(a[1] > b[0] for a, b in zip(cover, cover[1:]))
-            if overlap or merged != sorted(want):
-                problem = (f"GradReducer: the announced ranges do not tile the expected ranges {sorted(want)[:4]}: "
+            if overlap or merged != want:
+                problem = (f"GradReducer: the announced ranges do not tile the expected ranges {want[:4]}: "
                            f"merged {merged[:6]}, overlap={overlap}")
         if problem is not None:
             self.pending = None

@@ -40,6 +40,37 @@ def golden():
     return _load
 
 
+TRAINED_SHAPE = dict(n_layer=4, n_head=4, n_embd=256, n_inner=1024)   # tests/gen_golden_trained.py: SHAPE
+
+
+def trained_config():
+    import midi_model_amd as mm
+    s = TRAINED_SHAPE
+    return mm.MIDIModelConfig.get_config("v2", True, s["n_layer"], s["n_head"], s["n_embd"], s["n_inner"])
+
+
+def load_trained(orc):
+    """tests/golden/tiny_trained.npz (tests/gen_golden_trained.py): the tiny model TRAINED with the real reference on a structured
+    corpus -- peaked next-token distributions -- with weights snapped to values fp32 / bf16 / fp16 all hold exactly.
+    Returns (shape, fp32 state dict, the npz)."""
+    import numpy as np
+    import torch
+    g = np.load(os.path.join(GOLDEN, "tiny_trained.npz"), allow_pickle=False)
+    sd = {}
+    for k in g.files:
+        if k.startswith("q8:"):
+            sd[k[3:]] = torch.from_numpy(g[k].astype(np.float32)) * 2.0 ** int(g["e:" + k[3:]])
+        elif k.startswith("b16:"):
+            sd[k[4:]] = torch.from_numpy(g[k].copy()).view(torch.bfloat16).float()
+    shp = orc.Shape(vocab=3406, **TRAINED_SHAPE)
+    return shp, sd, g
+
+
+@pytest.fixture(scope="session")
+def trained(orc):
+    return load_trained(orc)
+
+
 def has_gpu():
     try:
         import torch

@@ -43,14 +43,17 @@ def _n_steps(tok, ids):
 
 
 @pytest.mark.parametrize("B,P,n_events,cap,rows", [(4, 65, 8, 256, None), (64, 17, 4, 256, None),
-                                                      (64, 1001, 8, 2048, (0, 9, 18, 27, 36, 45, 54, 63))],
-                         ids=["b4", "b64_benchmarked_batch", "b64_cap2048_depth1000_benchmarked_session"])
+                                                      (64, 1001, 8, 2048, (0, 9, 18, 27, 36, 45, 54, 63)),
+                                                      (64, 1001, 1, 2048, None)],
+                         ids=["b4", "b64_benchmarked_batch", "b64_cap2048_depth1000_benchmarked_session",
+                              "b64_cap2048_depth1000_all_64_rows_one_event"])
 def test_production_decode_session_matches_oracle(orc, tok, medium_bf16, golden, B, P, n_events, cap, rows):
     """(B = 64: the batch bench.py --mode generate runs, where mh_gemm_skinny takes its 64-row tilings.  The third case is the
     session bench.py --mode generate checks out -- BASELINE configs[3]: capacity 2048, batch 64 -- at the DEPTH it runs to:
     a 1001-event prefill, then 8 events decoded by the replayed graphs with pos_dev = 1001..1008, i.e. attn_decode_kernel<64>
     over 1000+ cached keys at 64 x 16 heads.  Sequences are independent, so the oracle follows 8 of the 64 rows (every row
-    of the device batch still goes through the 64-row tilings; midi_model.py:195-248).)
+    of the device batch still goes through the 64-row tilings; midi_model.py:195-248).  The fourth case follows ALL 64 rows
+    through one event at that depth -- one oracle prefill of 64 x 1001 events.)
     64-event prompt prefill + 8 decoded events, greedy (top_k = 1): after every replayed graph the session's hidden
     state / logits are within the reference's own bf16 drift (x1.5) of the oracle's cached fp32 forward on the SAME
     tokens, and the greedy id equals the oracle's masked arg-max wherever the oracle's top-2 margin exceeds twice that

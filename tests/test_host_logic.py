@@ -294,6 +294,23 @@ def test_grad_accumulation_averages_micro_batches(orc, tiny, tok):
     np.testing.assert_allclose(g2.numpy(), (0.5 * (singles[0] + singles[1])).numpy(), rtol=1e-4, atol=1e-7)
 
 
+def test_generate_on_trained_weights_matches_reference(trained, tok):
+    """the host side of generate() (grammar masks, break rule, sampler, RNG consumption) on PEAKED distributions: the tiny model
+    trained by tests/gen_golden_trained.py, the reference's own seeded ids (midi_model.py:152-165, 195-248)"""
+    shp, sd, g = trained
+    with emu_ops.install():
+        from conftest import trained_config
+        model = mm.MIDIModel(trained_config())
+        model.load_state_dict(sd)
+        out = model.generate(None, batch_size=4, max_len=40, generator=torch.Generator().manual_seed(4321))
+        assert out.shape == g["sampled_b4"].shape and (out == g["sampled_b4"]).all()
+        out = model.generate(None, batch_size=4, max_len=40, top_k=1, generator=torch.Generator().manual_seed(0))
+        assert (out == g["greedy_b4"]).all()
+        out = model.generate(g["prompt"], batch_size=3, max_len=36, temp=0.9, top_p=0.9, top_k=8,
+                             generator=torch.Generator().manual_seed(99))
+        assert (out == g["prompt_sampled_b3"]).all()
+
+
 def test_generate_matches_reference(tiny, golden, tok):
     shp, sd, _ = tiny
     g = golden("tiny_generate.npz")
