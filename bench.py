@@ -142,7 +142,7 @@ def _free_port() -> int:
 def spawn(args) -> int:
     """`python bench.py --gpus N` without a launcher: re-exec this script under torch.distributed.run with N local ranks
     (one per GPU, rendezvous on 127.0.0.1) and pass its exit code on.  Refuses when the box has fewer than N GPUs."""
-    if not args.stub:
+    if not (args.stub or args.emu):
         have = torch.cuda.device_count() if torch.cuda.is_available() else 0
         if have < args.gpus:
             raise SystemExit(f"bench.py: --gpus {args.gpus} but this box exposes {have} GPU(s); refusing to report an "
@@ -166,7 +166,7 @@ def setup(args):
         raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: launch with matching values "
                          f"(or run `python bench.py --gpus {args.gpus}` alone and let it spawn its ranks)")
     import torch.distributed as dist
-    if args.stub:
+    if args.stub or args.emu:
         if world > 1:
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
             dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -199,11 +199,36 @@ def timed(fn_step, steps: int, dist, sync):
         dist.barrier()
     sync()
     dt = time.perf_counter() - t0
+    timed.per_rank = [dt]
     if dist is not None:
+        # every rank's own clock over the same barrier-bracketed region: the MAX is the job's time, the spread names a straggler
         t = torch.tensor([dt], dtype=torch.float64, device="cuda" if torch.cuda.is_available() and dist.get_backend() == "nccl" else "cpu")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+        every = [torch.zeros_like(t) for _ in range(dist.get_world_size())]
+        dist.all_gather(every, t)
+        timed.per_rank = [float(x.item()) for x in every]
+        dt = max(timed.per_rank)
     return dt, out
+
+
+timed.per_rank = []
+
+
+def multi_rank_fields(args, world: int, value: float, per_rank):
+    """what an N > 1 line carries beyond the contract: every rank's own time over the timed region (the job's time is their max)
+    and, given the 1-GPU number, the scaling efficiency (the driver computes its own from the per-N lines)"""
+    out = {}
+    if world > 1 and per_rank:
+        out["ranks"] = per_rank_report(per_rank, args.steps)
+    if world > 1 and args.baseline_1gpu:
+        out["baseline_1gpu"] = args.baseline_1gpu
+        out["scaling_efficiency"] = value / (world * args.baseline_1gpu)
+    return out
+
+
+def per_rank_report(per_rank, steps: int):
+    ms = [1e3 * x / steps for x in per_rank]
+    return {"ms_per_step_by_rank": ms, "ms_per_step_min": min(ms), "ms_per_step_max": max(ms),
+            "straggler_ratio": max(ms) / min(ms) if min(ms) > 0 else None}
 
 
 def comm_info(world, dist):
@@ -428,6 +453,10 @@ def measure_large(args, which: str, B: int, S: int, steps: int, warmup: int):
         model = TrainMIDIModel(cfg, lr=2e-4, weight_decay=0.01, warmup=1e3, max_step=1e6, accumulate_grad_batches=1)
         model = model.to(torch.device("cuda"), torch.bfloat16)
     model.configure_optimizers()
+    # the 2x-hidden shape at 16 x 4096 per GPU peaked at 305.9e9 of the card's 309.2e9 bytes with every activation kept (r04): no
+    # room for RCCL's channel buffers on a multi-GPU run.  Lean activation saving (SwiGLU outputs recomputed in the backward,
+    # identical bits) takes ~39 GB off that peak.
+    model.lean_activations = (which != "tv2o-large") or bool(os.environ.get("MH_LEAN_ACTIVATIONS"))
     t_build = time.perf_counter() - t_build
     n_params = sum(p.numel() for p in model.parameters())
     nc, tc = cfg.net_config, cfg.net_token_config
@@ -459,7 +488,9 @@ def measure_large(args, which: str, B: int, S: int, steps: int, warmup: int):
            "batch": B, "seq_len": S, "params": n_params, "loss": float(loss.item()),
            "train_flops_per_event": fl, "model_tflops": fl * B * S * steps / dt / 1e12,
            "model_flops_frac_of_peak": fl * B * S * steps / dt / 1e12 / PEAK_BF16_TFLOPS,
-           "hbm_peak_gb": torch.cuda.max_memory_allocated() / 1e9, "build_s": t_build}
+           "hbm_peak_gb": torch.cuda.max_memory_allocated() / 1e9,
+           "hbm_headroom_gb": (torch.cuda.get_device_properties(0).total_memory - torch.cuda.max_memory_allocated()) / 1e9,
+           "lean_activations": bool(model.lean_activations), "build_s": t_build}
     del model, batches
     gc.collect()
     torch.cuda.empty_cache()
@@ -483,9 +514,11 @@ def run_stub(args):
         step(i)
     dt, y = timed(step, args.steps, dist, lambda: None)
     if rank == 0:
-        print(json.dumps({"metric": "STUB: spawn/rendezvous self-test of bench.py, NOT a measurement", "value": 0.0, "unit": "none",
-                          "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps,
-                          "comm": comm_info(world, dist), "allreduce_sum_check": float(y[0])}))
+        out = {"metric": "STUB: spawn/rendezvous self-test of bench.py, NOT a measurement", "value": 0.0, "unit": "none",
+               "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps,
+               "comm": comm_info(world, dist), "allreduce_sum_check": float(y[0])}
+        out.update(multi_rank_fields(args, world, 1.0, timed.per_rank))
+        print(json.dumps(out))
     if dist is not None:
         dist.destroy_process_group()
 
@@ -515,10 +548,17 @@ def main():
     ap.add_argument("--block-seq", type=int, default=4096)
     ap.add_argument("--block-save", action="store_true",
                     help="block mode: the TRAINING forward (also stores gate|up for the backward) instead of the forward-only form")
-    ap.add_argument("--comm", default=os.environ.get("MH_COMM", "torch"), choices=["torch", "mh"],
+    ap.add_argument("--comm", default=os.environ.get("MH_COMM", "torch"), choices=["torch", "mh", "both"],
                     help="gradient exchange: torch = torch.distributed 'nccl' (RCCL, the default); mh = the library's own RCCL "
-                         "communicator (mh_comm_*: one pre-multiplied-sum collective per bucket)")
+                         "communicator (mh_comm_*: one pre-multiplied-sum collective per bucket); both (N > 1) = the headline on "
+                         "torch, then the same K steps on mh in the same allocation (`comm_ab` in the line)")
+    ap.add_argument("--baseline-1gpu", type=float, default=None,
+                    help="N > 1: the 1-GPU events/s of the same configuration; the line then carries scaling_efficiency = "
+                         "value / (N * this)")
     ap.add_argument("--stub", action="store_true", help=argparse.SUPPRESS)  # CPU/gloo self-test of the spawn path
+    # CPU/gloo self-test of the N > 1 TRAIN path itself (parameter broadcast, bucketed reducer, per-rank clocks, the rank-0 line):
+    # a tiny model on the tests' CPU stand-ins of the kernels (tests/emu_ops.py).  Never a measurement -- the metric says so.
+    ap.add_argument("--emu", action="store_true", help=argparse.SUPPRESS)
     args = ap.parse_args()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         raise SystemExit(spawn(args))
@@ -530,6 +570,13 @@ def main():
     sys.stdout = real_stdout
     if args.stub:
         return run_stub(args)
+    if args.emu:
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
+        import emu_ops
+        emu_ctx = emu_ops.install()
+        emu_ctx.__enter__()   # (held until the process exits)
+        args.mode, args.dtype = "train", "fp32"
+        args.no_gemm_events = args.no_extras = args.no_cpu_baseline = True
 
     world, rank, local, dist = setup(args)
     if args.mode == "generate":
@@ -582,16 +629,19 @@ def main():
 
     dtype = torch.bfloat16 if args.dtype == "bf16" else torch.float32
     torch.manual_seed(0)
-    cfg = mm.MIDIModelConfig.from_name(args.config)
-    model = TrainMIDIModel(cfg, lr=2e-4, weight_decay=0.01, warmup=1e3, max_step=1e6, accumulate_grad_batches=args.accumulate)
-    model = model.to(torch.device("cuda", local), dtype)
+    dev = torch.device("cpu") if args.emu else torch.device("cuda", local)
+    sync = (lambda: None) if args.emu else torch.cuda.synchronize
+    cfg = mm.MIDIModelConfig.get_config("v2", True, 4, 4, 256, 512) if args.emu else mm.MIDIModelConfig.from_name(args.config)
+    model = TrainMIDIModel(cfg, lr=2e-4, weight_decay=0.01, warmup=1e3, max_step=1e6, accumulate_grad_batches=args.accumulate,
+                           **({"bucket_mb": 4} if args.emu else {}))
+    model = model.to(dev, dtype)
     model.configure_optimizers()
     if args.comm == "mh" and world > 1:
         from midi_model_amd.comm import MHComm
-        model.use_comm(MHComm.from_process_group(local))
+        model.use_comm(MHComm.from_process_group(local))   # ("both": the headline runs on torch, the A/B leg follows below)
     model.broadcast_parameters(0)
     B, S = args.batch, args.seq
-    batches = [synthetic_events(model.tokenizer, B, S + 1, seed=1000 + 17 * rank + i, device="cuda") for i in range(2)]
+    batches = [synthetic_events(model.tokenizer, B, S + 1, seed=1000 + 17 * rank + i, device=dev) for i in range(2)]
 
     def step(i):
         return model.fit_step(batches[i % 2])  # (accumulate 1: training_step + optimizer_step every call)
@@ -603,7 +653,8 @@ def main():
     if model._reducer is not None:
         model._reducer.profile = True
         model._reducer.stats.clear()
-    dt, loss = timed(step, args.steps, dist, torch.cuda.synchronize)
+    dt, loss = timed(step, args.steps, dist, sync)
+    per_rank = list(timed.per_rank)
     ops.gemm_profile = None
     loss_v = float(loss.item())
     red = model._reducer
@@ -625,6 +676,36 @@ def main():
         lib().profile = launches
         fam_dt, _ = timed(step, fam_steps, dist, torch.cuda.synchronize)
         lib().profile = None
+
+    # --comm both (N > 1): the same K steps once more with the buckets going out through the library's own communicator, in the
+    # same allocation.  Every rank reports whether its communicator came up BEFORE any collective is issued on it: a rank
+    # that failed alone would otherwise leave the others waiting in their first bucket.
+    comm_ab = None
+    if world > 1 and args.comm == "both" and not args.emu:
+        ok, err = 1, None
+        try:
+            from midi_model_amd.comm import MHComm
+            mh = MHComm.from_process_group(local)
+        except Exception as e:
+            ok, err, mh = 0, repr(e), None
+        flag = torch.tensor([ok], dtype=torch.int32, device="cuda")
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        if int(flag.item()) == 1:
+            model.use_comm(mh)
+            for i in range(2):
+                step(i)
+            dt_mh, _ = timed(step, args.steps, dist, torch.cuda.synchronize)
+            comm_ab = {"torch_ms_per_step": 1e3 * (dt_plain if dt_plain else dt) / args.steps, "mh_ms_per_step": 1e3 * dt_mh / args.steps,
+                       "mh_ranks": per_rank_report(timed.per_rank, args.steps), "rccl_version_code": mh.rccl_version,
+                       "what": "same model, same batches, K steps each: torch.distributed 'nccl' (divide + all-reduce(SUM) per bucket) "
+                               "against mh_comm_allreduce (one pre-multiplied-sum all-reduce per bucket)"}
+            model.comm = None
+            model._reducer = None
+            mh.close()
+        else:
+            comm_ab = {"error": err or "another rank could not open the library communicator"}
+            if mh is not None:
+                mh.close()
 
     # One GPU cannot run a ring, but it can run the exchange's CALL SEQUENCE: the same step with every bucket of the flat
     # gradient buffer sent through the library's RCCL communicator at world size 1 (15 x 32 MB launches on the communication
@@ -666,7 +747,8 @@ def main():
         fl_event = train_flops_per_event(S, net_L=nc.num_hidden_layers, tok_L=tc.num_hidden_layers, D=nc.hidden_size,
                                          I=nc.intermediate_size, It=tc.intermediate_size, V=model.tokenizer.vocab_size)
         out = {
-            "metric": f"MIDI events/sec, training step (fwd+bwd+clip+AdamW), {args.config}, seq={S}",
+            "metric": (f"MIDI events/sec, training step (fwd+bwd+clip+AdamW), {args.config}, seq={S}" if not args.emu else
+                       "EMU: CPU self-test of bench.py's N > 1 train path on tests/emu_ops.py, NOT a measurement"),
             "value": value, "unit": "events/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": args.dtype, "data": "synthetic",
@@ -686,8 +768,11 @@ def main():
         if contention is not None:
             out["allreduce_contention"] = contention
             out["allreduce_contention_ms"] = contention.get("allreduce_contention_ms")
+        out.update(multi_rank_fields(args, world, value, per_rank))
+        if comm_ab is not None:
+            out["comm_ab"] = comm_ab
         if world > 1:
-            out["comm"]["exchange"] = args.comm
+            out["comm"]["exchange"] = "torch" if args.comm == "both" else args.comm
             st = red_stats
             exposed = [a.elapsed_time(b) for a, b, _, _ in st if a is not None]
             out.update(summarize_allreduce([(x[2], x[3]) for x in st], args.steps, exposed))
@@ -737,13 +822,14 @@ def main():
                                 "fwd_frac_of_peak": fwd_fl / (fwd_ms * 1e-3) / 1e12 / PEAK_BF16_TFLOPS if fwd_ms else None,
                                 "bwd_frac_of_peak": 2.5 * fwd_fl / (bwd_ms * 1e-3) / 1e12 / PEAK_BF16_TFLOPS if bwd_ms else None}
     del model, batches
-    torch.cuda.empty_cache()
+    if not args.emu:
+        torch.cuda.empty_cache()
     if world == 1 and not args.no_extras:
         # the other two measurements the judge asks for, in the same driver-run line (N=1 only: replicas add nothing)
         for key, fn in (("block", lambda: measure_block(args, args.block_batch, args.block_seq, 10, 3)),
-                        ("generate", lambda: measure_generate(args, 1, 0, None, 2, 1)),
-                        ("large", lambda: measure_large(args, "tv2o-large", 16, 4096, 3, 1)),
-                        ("large_2x_hidden", lambda: measure_large(args, "2x-hidden", 16, 4096, 2, 1))):
+                        ("generate", lambda: measure_generate(args, 1, 0, None, 5, 1)),
+                        ("large", lambda: measure_large(args, "tv2o-large", 16, 4096, 5, 1)),
+                        ("large_2x_hidden", lambda: measure_large(args, "2x-hidden", 16, 4096, 5, 1))):
             if key.startswith("large") and args.no_large:
                 continue
             try:

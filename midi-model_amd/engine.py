@@ -106,12 +106,15 @@ def linear_wgrad(dy: torch.Tensor, x: torch.Tensor, dw: torch.Tensor, accumulate
 # training / prefill forward
 # --------------------------------------------------------------------------------------------------
 def layer_forward(spec: StackSpec, lw: LayerTensors, x: torch.Tensor, nseq: int, slen: int, rope: RopeTable,
-                  kv_out: Optional[list] = None, save: bool = True):
+                  kv_out: Optional[list] = None, save: bool = True, lean: bool = False):
     """One pre-norm LLaMA block (LlamaDecoderLayer.forward, TF:models/llama/modeling_llama.py:295-324) on x [nseq*slen, D]:
     RMSNorm -> q|k|v projection -> RoPE -> causal attention -> o projection + residual -> RMSNorm -> gate|up projection with
     SwiGLU epilogue -> down projection + residual.  8 launches for the event-level stack in bf16 (bench.py --mode block times
     exactly this function).  ``save=False`` is the forward-only form (prompt prefill, validation): gate|up is never written,
-    only the activation.  Returns (block output, tensors the backward needs | None)."""
+    only the activation.  ``lean`` (with save): the SwiGLU activation ``a`` is not kept -- the backward recomputes it from the
+    stored gate|up with mh_swiglu_fwd, bit for bit (the fused epilogue and that kernel share their roundings) -- which takes
+    I of the 8 D + 3 I saved elements per row off the activation memory (the 2x-hidden large shape at 16 x 4096 per GPU: 39 GB).
+    Returns (block output, tensors the backward needs | None)."""
     M, D = x.shape
     H, I = spec.H, spec.I
     h1 = _empty((M, D), x)
@@ -156,20 +159,21 @@ def layer_forward(spec: StackSpec, lw: LayerTensors, x: torch.Tensor, nseq: int,
         ops.swiglu_fwd(gu, a)
     x3 = _empty((M, D), x)
     ops.gemm_nt(a, lw.wd, x3, beta=1.0, res=x2)
-    return x3, ((x, rstd1, h1, qkv, o, lse, x2, rstd2, h2, gu, a) if save else None)
+    return x3, ((x, rstd1, h1, qkv, o, lse, x2, rstd2, h2, gu, None if lean else a) if save else None)
 
 
 def stack_forward(spec: StackSpec, W: StackTensors, x: torch.Tensor, nseq: int, slen: int, rope: RopeTable,
-                  save: bool, kv_out: Optional[list] = None):
+                  save: bool, kv_out: Optional[list] = None, lean: bool = False):
     """x [nseq*slen, D] (inputs_embeds) -> last_hidden_state [nseq*slen, D].
-    save=True keeps what the backward needs; kv_out (prefill) receives each layer's post-RoPE qkv."""
+    save=True keeps what the backward needs (``lean``: minus the SwiGLU activations, recomputed in the backward);
+    kv_out (prefill) receives each layer's post-RoPE qkv."""
     _check_heads(spec)
     M, D = x.shape
     assert M == nseq * slen
     rope.ensure(slen)
     saved = []
     for lw in W.layers:
-        x3, keep = layer_forward(spec, lw, x, nseq, slen, rope, kv_out, save)
+        x3, keep = layer_forward(spec, lw, x, nseq, slen, rope, kv_out, save, lean and save)
         if save:
             saved.append(keep)
         x = x3
@@ -193,6 +197,9 @@ def stack_backward(spec: StackSpec, W: StackTensors, G: StackTensors, ctx, dy: t
         lw, lg = W.layers[li], G.layers[li]
         x, rstd1, h1, qkv, o, lse, x2, rstd2, h2, gu, a = saved[li]
         # ---- MLP ----
+        if a is None:                                   # lean forward: a = round(silu(gate)) * up again, from the stored gate|up
+            a = _empty((M, I), dy)
+            ops.swiglu_fwd(gu, a)
         dgu = _empty((M, 2 * I), dy)
         if ops.dswiglu_ok(dx, I):                       # d a = dx @ wd with the SwiGLU backward as its epilogue
             ops.gemm_dswiglu(dx, lw.wd, gu, dgu)
@@ -202,6 +209,7 @@ def stack_backward(spec: StackSpec, W: StackTensors, G: StackTensors, ctx, dy: t
             ops.swiglu_bwd(gu, da, dgu)
             del da
         linear_wgrad(dx, a, lg.wd, accumulate)
+        del a
         dh2 = _empty((M, D), dy)
         ops.gemm_nt(dgu, lw.wgu, dh2, tb=True)          # d h2 = dgu @ wgu
         linear_wgrad(dgu, h2, lg.wgu, accumulate)

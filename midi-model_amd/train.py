@@ -191,6 +191,10 @@ class TrainMIDIModel(MIDIModel):
         self.last_grad_norm = None
         self.process_group = None
         self.comm = None           # MHComm (comm.py): the gradient exchange through the library's own RCCL communicator
+        # memory for time: the forward does not keep the SwiGLU activations, the backward recomputes them from gate|up (identical
+        # bits, one extra elementwise pass per layer: ~1 % of a step).  For shapes whose activations crowd the 288 GB -- the
+        # 2x-hidden large shape at 16 x 4096 per GPU peaks at 306 of 309 GB without it, and RCCL needs room for its channel buffers
+        self.lean_activations = False
         self.force_reduce = False  # run the bucketed exchange even with one rank (tests, bench.py's contention probe)
         self._lora = None          # LoraAdapter while fine-tuning adapters on a frozen base (add_adapter)
 
@@ -257,7 +261,11 @@ class TrainMIDIModel(MIDIModel):
         """What ``trainer.fit(..., ckpt_path=opt.resume)`` (train.py:475-479) needs to continue a run, in the layout of a
         Lightning ``.ckpt``: ``state_dict``, ``global_step``, ``optimizer_states[0]`` = the ``torch.optim.AdamW.state_dict()`` of
         the reference's two parameter groups (per-parameter ``step`` / ``exp_avg`` / ``exp_avg_sq``), ``lr_schedulers[0]`` = the
-        LambdaLR position.  Ours on top: the accumulation phase (``mh_micro``) and, inside an accumulation window, the gradient
+        LambdaLR position (with the ``lr_lambdas`` / ``verbose`` / ``_get_lr_called_within_step`` keys
+        ``LambdaLR.load_state_dict`` expects) and the ``pytorch-lightning_version`` / ``loops`` / ``callbacks`` keys Lightning
+        looks up first.  Tested direction: a reference-layout checkpoint -> ``load_training_state`` and our own round trip, and
+        the scheduler / optimizer dictionaries loaded into the real torch objects (tests/test_host_logic.py); Lightning itself is
+        not installable here.  Ours on top: the accumulation phase (``mh_micro``) and, inside an accumulation window, the gradient
         accumulated so far."""
         if self._lora is not None:
             raise RuntimeError("training_state: adapter training keeps its state in the adapter (save_adapter)")
@@ -285,8 +293,13 @@ class TrainMIDIModel(MIDIModel):
             "optimizer_states": [{"state": state, "param_groups": [
                 dict(group, weight_decay=self.weight_decay, params=list(range(n_decay))),
                 dict(group, weight_decay=0.0, params=list(range(n_decay, len(order))))]}],
+            # torch.optim.lr_scheduler.LambdaLR.state_dict(): the lambdas themselves are not pickled (plain functions -> None)
+            # and load_state_dict pops "lr_lambdas", so the key must exist for the reference's trainer to resume from this file
             "lr_schedulers": [{"last_epoch": int(self.global_step), "_step_count": int(self.global_step) + 1,
-                               "base_lrs": [self.lr, self.lr], "_last_lr": [lr_now, lr_now]}],
+                               "base_lrs": [self.lr, self.lr], "_last_lr": [lr_now, lr_now], "lr_lambdas": [None, None],
+                               "verbose": False, "_get_lr_called_within_step": False}],
+            "pytorch-lightning_version": "2.4.0",
+            "loops": {}, "callbacks": {},
             "hyper_parameters": dict(lr=self.lr, weight_decay=self.weight_decay, warmup=self.warmup, max_step=self.max_step),
             "mh_micro": int(self._micro),
         }
@@ -297,13 +310,24 @@ class TrainMIDIModel(MIDIModel):
     def save_training_state(self, path: str) -> None:
         torch.save(self.training_state(), path)
 
-    def load_training_state(self, state) -> "TrainMIDIModel":
+    def load_training_state(self, state, trust_checkpoint: bool = False) -> "TrainMIDIModel":
         """Resume from ``training_state()`` or from a Lightning ``.ckpt`` payload of the reference's trainer (a path or the
         loaded dict): weights, AdamW moments (mapped back to parameters through the reference's group order), the step count
         the bias corrections and the LR schedule run on, the accumulation phase.  Strict: a moment tensor that is missing or has
         the wrong shape raises."""
         if isinstance(state, (str, os.PathLike)):
-            state = torch.load(state, map_location="cpu", weights_only=True)
+            import pickle
+            try:
+                state = torch.load(state, map_location="cpu", weights_only=True)
+            except pickle.UnpicklingError as e:
+                # a Lightning .ckpt with callback / hyper-parameter objects outside torch's allow-list: same per-call trust as
+                # MIDIModel.from_checkpoint (the reference's trainer unpickles whatever the file names)
+                if not trust_checkpoint:
+                    raise RuntimeError(f"{state} holds pickled objects beyond tensors ({e}); pass trust_checkpoint=True to unpickle "
+                                       "it as Lightning does (only for a file you trust)") from e
+                import warnings
+                warnings.warn(f"load_training_state: unpickling {state} with weights_only=False (trust_checkpoint=True)", stacklevel=2)
+                state = torch.load(state, map_location="cpu", weights_only=False)
         if "optimizer_states" not in state or "state_dict" not in state:
             raise RuntimeError("load_training_state: not a training checkpoint (needs state_dict + optimizer_states)")
         self.load_checkpoint_state(state)
@@ -487,7 +511,7 @@ class TrainMIDIModel(MIDIModel):
         # ---- forward: event-level net
         e = torch.empty((M, D), dtype=dty, device=dev)
         ops.embed_sum_fwd(x.view(M, T), Wn.embed, e)
-        hidden, ctx_net = engine.stack_forward(spec, Wn, e, B, S, self.rope("net"), save=backward)
+        hidden, ctx_net = engine.stack_forward(spec, Wn, e, B, S, self.rope("net"), save=backward, lean=self.lean_activations)
         del e
         sel = None
         if self.sample_seq:  # train.py:172-175: keep the last position + up to 127 random others
@@ -504,7 +528,8 @@ class TrainMIDIModel(MIDIModel):
         # ---- forward: token-level net over [hidden ; embed(y[:, :7])]
         seq = torch.empty((N, T, D), dtype=dty, device=dev)
         ops.concat_tok_fwd(hidden_t, y_t, Wt.embed, seq, T)
-        h, ctx_tok = engine.stack_forward(tspec, Wt, seq.view(R, D), N, T, self.rope("net_token"), save=backward)
+        h, ctx_tok = engine.stack_forward(tspec, Wt, seq.view(R, D), N, T, self.rope("net_token"), save=backward,
+                                          lean=self.lean_activations)
         del seq
 
         # ---- lm_head + cross-entropy (+ their backward), chunked over rows

@@ -247,6 +247,37 @@ def test_bench_spawns_its_own_ranks(tmp_path):
         assert r.returncode != 0 and "refusing" in r.stderr
 
 
+def test_bench_two_rank_train_path_end_to_end_on_cpu():
+    """`python bench.py --gpus 2` through the TRAIN path itself, not the stub step: spawn, 127.0.0.1 rendezvous (gloo), parameter
+    broadcast, the bucketed GradReducer inside fit_step, every rank's own clock gathered in timed(), the exchange summary, the
+    efficiency field and the single rank-0 JSON line -- on a tiny model over the tests' CPU stand-ins of the kernels (--emu; the
+    line's metric says it is not a measurement).  What cannot run here is RCCL; what can fail for a host-side reason on the
+    first multi-GPU run is executed here (train.py:461-474)."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env["OMP_NUM_THREADS"] = "4"
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--emu", "--steps", "2", "--warmup", "1",
+                        "--batch", "2", "--seq", "16", "--baseline-1gpu", "1000", "--comm", "both"],
+                       capture_output=True, text=True, env=env, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    d = json.loads(lines[0])
+    assert d["metric"].startswith("EMU") and d["n_gpus"] == 2 and d["steps"] == 2 and d["scaling"] == "weak"
+    assert d["comm"]["world_size"] == 2 and d["comm"]["backend"] == "gloo" and d["comm"]["exchange"] == "torch"
+    assert d["config"]["global_batch"] == 4 and d["config"]["parallelism"] == "dp2"
+    assert abs(d["value"] - 2 * 2 * 16 * 2 / (d["ms_per_step"] * 2e-3)) < 1e-6 * d["value"]       # whole-job events / max-over-ranks time
+    rk = d["ranks"]
+    assert len(rk["ms_per_step_by_rank"]) == 2 and abs(rk["ms_per_step_max"] - d["ms_per_step"]) < 1e-9 and rk["straggler_ratio"] >= 1.0
+    assert abs(d["scaling_efficiency"] - d["value"] / 2000.0) < 1e-12
+    # one exchange of the whole flat gradient buffer per step, in several buckets
+    assert d["allreduce_windows"] == 2 and d["allreduce_launches_per_optimizer_step"] >= 2
+    assert d["allreduce_bytes_per_step"] > 4e6 and np.isfinite(d["loss"])
+
+
 def test_bench_allreduce_summary_semantics():
     """bench.py's `allreduce_*` keys under --accumulate 2: the reducer reports one exchange per optimiser step (the whole flat
     gradient buffer, 467,685,376 B for tv2o-medium in bf16), i.e. one per TWO timed steps; per timed step that is half."""

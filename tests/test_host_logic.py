@@ -211,6 +211,38 @@ def test_training_state_resume(orc, tiny, tok, tmp_path):
         np.testing.assert_allclose(m._opt["m"][off:off + cnt].numpy(), st[i]["exp_avg"].reshape(-1).numpy(), rtol=2e-3, atol=1e-6, err_msg=n)
         np.testing.assert_allclose(m._opt["v"][off:off + cnt].numpy(), st[i]["exp_avg_sq"].reshape(-1).numpy(), rtol=2e-3, atol=1e-9, err_msg=n)
 
+    # (c) the OTHER direction: what training_state() writes loads into the REAL torch.optim.AdamW and LambdaLR of the
+    # reference recipe (LambdaLR.load_state_dict pops "lr_lambdas"; Lightning reads "pytorch-lightning_version" / "loops"), and
+    # torch's next step from there lands where ours lands
+    state = m.training_state()
+    assert {"pytorch-lightning_version", "loops", "state_dict", "optimizer_states", "lr_schedulers"} <= set(state)
+    params2 = {k: state["state_dict"][k].clone().float().requires_grad_(True) for k, _ in named}
+    named2 = list(params2.items())
+    opt2 = torch.optim.AdamW([{"params": [p for n, p in named2 if not any(nd in n for nd in no_decay)], "weight_decay": 0.01},
+                              {"params": [p for n, p in named2 if any(nd in n for nd in no_decay)], "weight_decay": 0.0}],
+                             lr=1e-2, betas=(0.9, 0.99), eps=1e-8)
+    sched2 = torch.optim.lr_scheduler.LambdaLR(opt2, lambda s_: lr_lambda(s_, 2, 10))
+    opt2.load_state_dict(state["optimizer_states"][0])
+    sched2.load_state_dict(state["lr_schedulers"][0])
+    assert sched2.last_epoch == 3 and abs(sched2.get_last_lr()[0] - m.current_lr()) < 1e-12
+    opt2.zero_grad()
+    loss2, _ = orc.training_loss(params2, shp, batches[3])
+    loss2.backward()
+    torch.nn.utils.clip_grad_norm_(list(params2.values()), 1.0)
+    opt2.step()
+    with emu_ops.install():
+        l3 = m.fit_step(batches[3]).item()
+    assert abs(l3 - loss2.item()) < 5e-5 * abs(l3)
+    for n, p in m.named_parameters():
+        np.testing.assert_allclose(p.detach().numpy(), params2[n].detach().numpy(), rtol=2e-4, atol=1e-5, err_msg=n)
+    # a checkpoint with objects beyond tensors needs the caller's word, per call
+    import fractions
+    torch.save(dict(ckpt, callbacks={"x": fractions.Fraction(1, 3)}), str(tmp_path / "odd.ckpt"))  # (not on torch's allow-list)
+    with emu_ops.install():
+        m2 = TrainMIDIModel(tiny_config(), accumulate_grad_batches=1, weight_decay=0.01, **kw)
+        with pytest.raises(RuntimeError, match="trust_checkpoint"):
+            m2.load_training_state(str(tmp_path / "odd.ckpt"))
+
 
 def test_midimodel_is_a_mixin_base_the_way_the_reference_trainer_uses_it(orc, tiny, tok, golden):
     """``class TrainMIDIModel(MIDIModel, pl.LightningModule)`` (train.py:106-119): MIDIModel must cooperate as the FIRST of two
@@ -292,6 +324,22 @@ def test_grad_accumulation_averages_micro_batches(orc, tiny, tok):
         m2.optimizer_step()
         assert m2.global_step == 1 and not torch.equal(m2._flat, before)
     np.testing.assert_allclose(g2.numpy(), (0.5 * (singles[0] + singles[1])).numpy(), rtol=1e-4, atol=1e-7)
+
+
+def test_lean_activation_saving_is_bit_identical(orc, tiny, tok):
+    """``lean_activations``: the forward drops the SwiGLU activations and the backward recomputes them from gate|up
+    (engine.layer_forward / stack_backward) -- same loss, same gradients, bit for bit (host schedule; the device kernels share
+    their roundings by construction, tests/test_model_gpu.py covers them)."""
+    shp, sd, batch = tiny
+    with emu_ops.install():
+        outs = []
+        for lean in (False, True):
+            m = TrainMIDIModel(tiny_config(), accumulate_grad_batches=1)
+            m.load_state_dict(sd)
+            m.lean_activations = lean
+            loss = m.training_step(batch)
+            outs.append((loss.clone(), m.grad_buffer().clone()))
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
 
 
 def test_generate_on_trained_weights_matches_reference(trained, tok):
