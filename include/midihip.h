@@ -92,6 +92,25 @@ int mh_gemm_rope(const void* A, int64_t lda, const void* W, int64_t ldw, void* C
  * neighbourhood.  bf16, production GEMM kernel only (option "gemm" != 0), I % 8 == 0; fails loudly otherwise.   */
 int mh_gemm_dswiglu(const void* A, int64_t lda, const void* B, int64_t ldb, const void* GU, int64_t ldgu, void* DGU,
                     int64_t lddgu, int64_t M, int64_t I, int64_t K, int dtype, void* stream);
+/* ---- RMSNorm folded around the projections of a FORWARD-ONLY block (r05; LlamaRMSNorm + nn.Linear,
+ * TF:models/llama/modeling_llama.py:62-67 with :254-256 / :174-176; the form mh_gemm_skinny's norm_eps runs for decode, at prefill
+ * sizes).  With W' = w (.) W folded by the caller, norm(x) W^T = rstd (.) (x W'^T): the normalised activation is never written.
+ *   mh_gemm_rowss        C = A B^T + R (R may be NULL) as mh_gemm_nt does, and rowss[(n / 64) * M + m] (fp32, N / 64 x M) = the sum
+ *                        of squares of the STORED bf16 values C[m, 64 (n/64) .. +64): the statistics of the norm that follows, from
+ *                        the registers the line is stored from.  N a multiple of 64; 16-byte aligned, ld multiples of 8.
+ *   mh_row_rstd          rstd[m] = rsqrt(mean_k(row m ^2) + eps), from `parts` (= rowss, nparts = N / 64) or from the rows `x`
+ *                        themselves (give exactly one of the two).
+ *   mh_gemm_rope_scaled / mh_gemm_swiglu_scaled   mh_gemm_rope / mh_gemm_swiglu with every row of the product multiplied by
+ *                        rowscale[m] (fp32 [M], 16-byte aligned, M a multiple of 4) before the epilogue's own arithmetic.   */
+int mh_gemm_rowss(const void* A, int64_t lda, const void* B, int64_t ldb, void* C, int64_t ldc, const void* R, int64_t ldr,
+                  float* rowss, int64_t M, int64_t N, int64_t K, int dtype, void* stream);
+int mh_row_rstd(const void* x, int64_t ldx, const float* parts, int nparts, int64_t M, int D, float eps, float* rstd, int dtype,
+                void* stream);
+int mh_gemm_rope_scaled(const void* A, int64_t lda, const void* W, int64_t ldw, void* C, int64_t ldc, const void* table,
+                        int64_t npos, int64_t S, int64_t pos0, int head_dim, const float* rowscale, int64_t M, int64_t N, int64_t K,
+                        int dtype, void* stream);
+int mh_gemm_swiglu_scaled(const void* A, int64_t lda, const void* W, int64_t ldw, void* GU, int64_t ldgu, void* ACT, int64_t ldact,
+                          const float* rowscale, int64_t M, int64_t I, int64_t K, int dtype, void* stream);
 int mh_gemm_splitk_reduce(const void* workspace, void* C, int64_t ldc, const void* R, int64_t ldr, int64_t M,
                           int64_t N, int splitk, float alpha, float beta, int dtype, void* stream);
 /* Skinny projection of the decode step (replaces the per-token nn.Linear calls of LlamaAttention / LlamaMLP /

@@ -498,6 +498,50 @@ extern "C" int mh_rmsnorm_fwd(const void* x, const void* w, void* y, float* rstd
   return MH_OK;
 }
 
+// rstd alone (r05: the statistics of an RMSNorm whose scaling rides on the following projection, mh_gemm_*_scaled):
+//   parts != NULL: rstd[m] = rsqrt(sum_p parts[p * M + m] / D + eps) -- the per-64-column sums of squares mh_gemm_rowss left
+//                  behind (a thread per row, nparts coalesced loads);
+//   x != NULL:     the same from the rows themselves (a wave per row; the first layer of a stack, whose input no GEMM of
+//                  ours produced).  LlamaRMSNorm.forward, TF:models/llama/modeling_llama.py:62-67: variance in fp32.
+__global__ __launch_bounds__(256) void rstd_from_parts_kernel(const float* __restrict__ parts, int nparts, int64_t M, float inv_d,
+                                                              float eps, float* __restrict__ rstd) {
+  const int64_t m = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (m >= M) return;
+  float ss = 0.f;
+  for (int p = 0; p < nparts; ++p) ss += parts[(int64_t)p * M + m];
+  rstd[m] = rsqrtf(ss * inv_d + eps);
+}
+template <typename T>
+__global__ __launch_bounds__(256) void row_rstd_kernel(const T* __restrict__ x, int64_t ldx, int64_t M, int D, float eps,
+                                                       float* __restrict__ rstd) {
+  constexpr int N = Pack<T>::N;
+  const int lane = threadIdx.x & 63;
+  for (int64_t m = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); m < M; m += (int64_t)gridDim.x * 4) {
+    const T* xr = x + m * ldx;
+    float ss = 0.f;
+    for (int c = lane * N; c < D; c += 64 * N) {
+      Pack<T> v = ld16(xr + c);
+#pragma unroll
+      for (int e = 0; e < N; ++e) ss += v.get(e) * v.get(e);
+    }
+    ss = wave_sum(ss);
+    if (lane == 0) rstd[m] = rsqrtf(ss / (float)D + eps);
+  }
+}
+extern "C" int mh_row_rstd(const void* x, int64_t ldx, const float* parts, int nparts, int64_t M, int D, float eps, float* rstd,
+                           int dtype, void* stream) {
+  MH_REQUIRE(M > 0 && D > 0 && rstd != nullptr && ((x != nullptr) != (parts != nullptr)), "row_rstd: give x OR parts (M=%ld D=%d)", (long)M, D);
+  if (parts != nullptr) {
+    MH_REQUIRE(nparts > 0, "row_rstd: nparts = %d", nparts);
+    rstd_from_parts_kernel<<<(unsigned)((M + 255) / 256), 256, 0, (hipStream_t)stream>>>(parts, nparts, M, 1.0f / (float)D, eps, rstd);
+  } else {
+    MH_REQUIRE(D % 8 == 0 && ldx % 8 == 0 && ldx >= D && ((uintptr_t)x & 15) == 0, "row_rstd: rows must be 16-byte aligned");
+    DISPATCH_T(dtype, (row_rstd_kernel<T><<<grid_for(M, 4, 65536), 256, 0, (hipStream_t)stream>>>((const T*)x, ldx, M, D, eps, rstd)));
+  }
+  MH_LAUNCH_CHECK();
+  return MH_OK;
+}
+
 // backward.  g = dy*w, xhat = x*rstd, dx = rstd*(g - xhat*mean(g*xhat)) (+dres); dw += dy*xhat per column.
 // Each wave walks rows with a fixed stride, so a lane always owns the same columns and keeps its dw
 // partial sums in LDS-free registers via a [D] LDS accumulator per wave (D <= 8192).

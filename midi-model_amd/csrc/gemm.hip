@@ -337,10 +337,23 @@ int mh_gemm_pp256_dswiglu_bf16(const void* A, int64_t lda, const void* B, int64_
                                void* DGU, int64_t lddgu, int64_t M, int64_t I, int64_t K, hipStream_t st);  // gemm_pp256.hip
 
 int mh_gemm_pp256_swiglu_bf16(const void* A, int64_t lda, const void* W, int64_t ldw, void* GU, int64_t ldgu, void* ACT,
-                              int64_t ldact, int64_t M, int64_t I, int64_t K, hipStream_t st);  // gemm_pp256.hip
+                              int64_t ldact, int64_t M, int64_t I, int64_t K, hipStream_t st, const float* rowscale);  // gemm_pp256.hip
+
+static int gemm_swiglu_any(const void* A, int64_t lda, const void* W, int64_t ldw, void* GU, int64_t ldgu, void* ACT,
+                           int64_t ldact, const float* rowscale, int64_t M, int64_t I, int64_t K, int dtype, void* stream);
 
 extern "C" int mh_gemm_swiglu(const void* A, int64_t lda, const void* W, int64_t ldw, void* GU, int64_t ldgu, void* ACT,
                               int64_t ldact, int64_t M, int64_t I, int64_t K, int dtype, void* stream) {
+  return gemm_swiglu_any(A, lda, W, ldw, GU, ldgu, ACT, ldact, nullptr, M, I, K, dtype, stream);
+}
+extern "C" int mh_gemm_swiglu_scaled(const void* A, int64_t lda, const void* W, int64_t ldw, void* GU, int64_t ldgu, void* ACT,
+                                     int64_t ldact, const float* rowscale, int64_t M, int64_t I, int64_t K, int dtype, void* stream) {
+  MH_REQUIRE(rowscale != nullptr && ((uintptr_t)rowscale & 15) == 0, "gemm_swiglu_scaled: rowscale must be a 16-byte aligned fp32 [M]");
+  return gemm_swiglu_any(A, lda, W, ldw, GU, ldgu, ACT, ldact, rowscale, M, I, K, dtype, stream);
+}
+
+static int gemm_swiglu_any(const void* A, int64_t lda, const void* W, int64_t ldw, void* GU, int64_t ldgu, void* ACT,
+                           int64_t ldact, const float* rowscale, int64_t M, int64_t I, int64_t K, int dtype, void* stream) {
   MH_REQUIRE(dtype == MH_BF16 && g_mh_gemm_variant != 0,
              "gemm_swiglu: served by the production bf16 kernel only (use mh_gemm + mh_swiglu_fwd otherwise)");
   MH_REQUIRE(M > 0 && I > 0 && K > 0 && I % 128 == 0, "gemm_swiglu: bad shape M=%ld I=%ld K=%ld (I must be a multiple of 128)",
@@ -350,15 +363,31 @@ extern "C" int mh_gemm_swiglu(const void* A, int64_t lda, const void* W, int64_t
                  (GU == nullptr || (ldgu % 8 == 0 && ldgu >= 2 * I)),
              "gemm_swiglu: leading dimensions must be multiples of 8 elements and cover the rows");
   MH_REQUIRE((((uintptr_t)A | (uintptr_t)W | (uintptr_t)GU | (uintptr_t)ACT) & 15) == 0, "gemm_swiglu: 16-byte alignment");
-  return mh_gemm_pp256_swiglu_bf16(A, lda, W, ldw, GU, ldgu, ACT, ldact, M, I, K, (hipStream_t)stream);
+  return mh_gemm_pp256_swiglu_bf16(A, lda, W, ldw, GU, ldgu, ACT, ldact, M, I, K, (hipStream_t)stream, rowscale);
 }
 
 int mh_gemm_pp256_rope_bf16(const void* A, int64_t lda, const void* W, int64_t ldw, void* C, int64_t ldc, const void* table,
-                            int64_t S, int64_t pos0, int64_t M, int64_t N, int64_t K, hipStream_t st);
+                            int64_t S, int64_t pos0, int64_t M, int64_t N, int64_t K, hipStream_t st, const float* rowscale);
+
+static int gemm_rope_any(const void* A, int64_t lda, const void* W, int64_t ldw, void* C, int64_t ldc, const void* table,
+                         int64_t npos, int64_t S, int64_t pos0, int head_dim, const float* rowscale, int64_t M, int64_t N, int64_t K,
+                         int dtype, void* stream);
 
 extern "C" int mh_gemm_rope(const void* A, int64_t lda, const void* W, int64_t ldw, void* C, int64_t ldc, const void* table,
                             int64_t npos, int64_t S, int64_t pos0, int head_dim, int64_t M, int64_t N, int64_t K, int dtype,
                             void* stream) {
+  return gemm_rope_any(A, lda, W, ldw, C, ldc, table, npos, S, pos0, head_dim, nullptr, M, N, K, dtype, stream);
+}
+extern "C" int mh_gemm_rope_scaled(const void* A, int64_t lda, const void* W, int64_t ldw, void* C, int64_t ldc, const void* table,
+                                   int64_t npos, int64_t S, int64_t pos0, int head_dim, const float* rowscale, int64_t M, int64_t N,
+                                   int64_t K, int dtype, void* stream) {
+  MH_REQUIRE(rowscale != nullptr && ((uintptr_t)rowscale & 15) == 0, "gemm_rope_scaled: rowscale must be a 16-byte aligned fp32 [M]");
+  return gemm_rope_any(A, lda, W, ldw, C, ldc, table, npos, S, pos0, head_dim, rowscale, M, N, K, dtype, stream);
+}
+
+static int gemm_rope_any(const void* A, int64_t lda, const void* W, int64_t ldw, void* C, int64_t ldc, const void* table,
+                         int64_t npos, int64_t S, int64_t pos0, int head_dim, const float* rowscale, int64_t M, int64_t N, int64_t K,
+                         int dtype, void* stream) {
   MH_REQUIRE(dtype == MH_BF16 && g_mh_gemm_variant != 0,
              "gemm_rope: served by the production bf16 kernel only (use mh_gemm + mh_rope otherwise)");
   MH_REQUIRE(M > 0 && K > 0 && N > 0 && N % 192 == 0 && head_dim == 64,
@@ -368,7 +397,22 @@ extern "C" int mh_gemm_rope(const void* A, int64_t lda, const void* W, int64_t l
   MH_REQUIRE(lda % 8 == 0 && ldw % 8 == 0 && ldc % 8 == 0 && lda >= K && ldw >= K && ldc >= N,
              "gemm_rope: leading dimensions must be multiples of 8 elements and cover the rows");
   MH_REQUIRE((((uintptr_t)A | (uintptr_t)W | (uintptr_t)C | (uintptr_t)table) & 15) == 0, "gemm_rope: 16-byte alignment");
-  return mh_gemm_pp256_rope_bf16(A, lda, W, ldw, C, ldc, table, S, pos0, M, N, K, (hipStream_t)stream);
+  return mh_gemm_pp256_rope_bf16(A, lda, W, ldw, C, ldc, table, S, pos0, M, N, K, (hipStream_t)stream, rowscale);
+}
+
+int mh_gemm_pp256_rowss_bf16(const void* A, int64_t lda, const void* B, int64_t ldb, void* C, int64_t ldc, const void* R,
+                             int64_t ldr, int64_t M, int64_t N, int64_t K, float* rowss, hipStream_t st);  // gemm_pp256.hip
+
+extern "C" int mh_gemm_rowss(const void* A, int64_t lda, const void* B, int64_t ldb, void* C, int64_t ldc, const void* R,
+                             int64_t ldr, float* rowss, int64_t M, int64_t N, int64_t K, int dtype, void* stream) {
+  MH_REQUIRE(dtype == MH_BF16 && g_mh_gemm_variant != 0, "gemm_rowss: served by the production bf16 kernel only");
+  MH_REQUIRE(M > 0 && N > 0 && K > 0 && N % 64 == 0 && rowss != nullptr, "gemm_rowss: bad shape M=%ld N=%ld K=%ld (N must be a multiple of 64)",
+             (long)M, (long)N, (long)K);
+  MH_REQUIRE(lda % 8 == 0 && ldb % 8 == 0 && ldc % 8 == 0 && lda >= K && ldb >= K && ldc >= N && (R == nullptr || (ldr % 8 == 0 && ldr >= N)),
+             "gemm_rowss: leading dimensions must be multiples of 8 elements and cover the rows");
+  MH_REQUIRE((((uintptr_t)A | (uintptr_t)B | (uintptr_t)C | (uintptr_t)R) & 15) == 0, "gemm_rowss: 16-byte alignment");
+  MH_REQUIRE(((M + 255) / 256) * ((N + 255) / 256) < (1ll << 30), "gemm_rowss: too many tiles");
+  return mh_gemm_pp256_rowss_bf16(A, lda, B, ldb, C, ldc, R, ldr, M, N, K, rowss, (hipStream_t)stream);
 }
 
 extern "C" int mh_gemm_dswiglu(const void* A, int64_t lda, const void* B, int64_t ldb, const void* GU, int64_t ldgu,

@@ -375,13 +375,26 @@ __device__ __forceinline__ void p8_main_loop(char* smem, const bf16* __restrict_
   }
 }
 
-template <bool TA, bool TB, int ABL, int EPI, int ML>
+// NRM (r05; the RMSNorm of a forward-only block folded around its projections, LlamaRMSNorm + nn.Linear of
+// TF:models/llama/modeling_llama.py:62-67, 254-256, 174-176 -- the form mh_gemm_skinny runs for decode, at prefill sizes):
+//   1 = PRODUCER (o / down projection + residual, plain epilogue): besides C = A B^T + R the kernel writes, for every row and
+//       every 64-column chunk, the sum of squares of the STORED bf16 values: aux[(n / 64) * M + m] (fp32).  Four dot2 + three DPP
+//       adds per 128-byte line, in the registers the line is stored from.  mh_row_rstd turns the N / 64 partials of a row into
+//       rstd[m] (one tiny launch) -- no pass over the residual stream at all;
+//   2 = CONSUMER (EPI 2 / EPI 3: gate|up + SwiGLU, q|k|v + RoPE; W carries the norm weight folded in by the caller): every row of
+//       the product is multiplied by aux[m] = rstd[m] before the epilogue's own arithmetic.  Wave 0 brings the tile's 256 values
+//       into LDS with ONE LDS-DMA request ahead of the main loop's (the oldest request: the first counted wait covers it), so
+//       the epilogue reads them with eight ds_read_b32 and no global latency.
+template <bool TA, bool TB, int ABL, int EPI, int ML, int NRM>
 __global__ __launch_bounds__(512, 2) void gemm_pp256_kernel(const bf16* __restrict__ A, int64_t lda,
                                                             const bf16* __restrict__ B, int64_t ldb, bf16* C, int64_t ldc,
                                                             const bf16* R, int64_t ldr, int64_t M, int64_t N, int64_t K,
                                                             float alpha, float beta, int tiles_n, int nwg,
                                                             int64_t k_per_split, float* __restrict__ ws,
-                                                            const void* __restrict__ zero16) {
+                                                            const void* __restrict__ zero16, float* aux) {
+  static_assert(NRM == 0 || (ML == 1 && ABL == 0 && !TA && !TB), "the norm forms ride on the K-step-64 row-major loop only");
+  static_assert(NRM != 1 || EPI == 0, "sum-of-squares partials come out of the plain epilogue");
+  static_assert(NRM != 2 || EPI == 2 || EPI == 3, "the row scale is applied by the SwiGLU / RoPE epilogues");
   extern __shared__ __attribute__((aligned(16))) char smem[];
   // ABL != 0 builds are micro-benchmarks with wrong results (tools/bench_gemm.py): 1 = no LDS-DMA after the pipeline
   // fill, 2 = no fragment reads, 4 = no MFMA, 8 = row-major pieces fetch whole 128-byte lines (8 rows x 128 B),
@@ -424,6 +437,12 @@ __global__ __launch_bounds__(512, 2) void gemm_pp256_kernel(const bf16* __restri
   };
 
   if constexpr (ML >= 1) {
+    if constexpr (NRM == 2) {  // rstd[m0 .. m0 + 255] -> smem + LDS_BYTES (1 KiB behind the two K-tile buffers); M % 4 == 0 (launcher)
+      if (wave == 0) {
+        const int64_t r = m0 + lane * 4;
+        glds16((r + 4 <= M) ? (const void*)(aux + r) : zero16, smem + LDS_BYTES);
+      }
+    }
     p8_main_loop<EPI, ABL, TB>(smem, A, lda, B, ldb, M, N, m0, n0, kbeg, kend, wave, lane, zero16, acc);
     if constexpr ((ABL & 128) != 0) {  // timeline build: workgroup 0 hands its stamps to the caller (ws), then the normal epilogue
       __syncthreads();
@@ -530,6 +549,12 @@ __global__ __launch_bounds__(512, 2) void gemm_pp256_kernel(const bf16* __restri
   }  // ML == 0
 
   // epilogue: lane (fi, fg) of fragment (fn, fm) holds C[m][n..n+3], m = m0 + grp*128 + fm*16 + fi
+  float rs[8];  // NRM 2: rstd of the lane's eight rows
+  if constexpr (NRM == 2) {
+    const float* rl = reinterpret_cast<const float*>(smem + LDS_BYTES);
+#pragma unroll
+    for (int fm = 0; fm < 8; ++fm) rs[fm] = rl[grp * 128 + fm * 16 + fi];
+  }
   const bool partial = (gridDim.z > 1);
   float* wsz = partial ? ws + (int64_t)zslice * M * N : nullptr;
   if constexpr ((ABL & 32) != 0) {  // micro-benchmark: no output
@@ -623,7 +648,9 @@ __global__ __launch_bounds__(512, 2) void gemm_pp256_kernel(const bf16* __restri
 #pragma unroll
         for (int fn = 0; fn < 4; ++fn) {
           const int row = fmh * 16 + fi, ch = fn * 4 + fg;
-          *reinterpret_cast<f32x4*>(wreg + row * 256 + ((ch ^ (row & 15)) << 4)) = acc[fn][half * 4 + fmh];
+          f32x4 t4 = acc[fn][half * 4 + fmh];
+          if constexpr (NRM == 2) t4 *= rs[half * 4 + fmh];
+          *reinterpret_cast<f32x4*>(wreg + row * 256 + ((ch ^ (row & 15)) << 4)) = t4;
         }
 #pragma unroll
       for (int i = 0; i < 4; ++i) {  // 16 rows x (64 B gate, 64 B up) per pass
@@ -694,7 +721,8 @@ __global__ __launch_bounds__(512, 2) void gemm_pp256_kernel(const bf16* __restri
 #pragma unroll
         for (int fn = 0; fn < 4; ++fn) {
           const int row = fmh * 16 + fi, ch = fn * 4 + fg;
-          const f32x4 a4 = acc[fn][half * 4 + fmh];
+          f32x4 a4 = acc[fn][half * 4 + fmh];
+          if constexpr (NRM == 2) a4 *= rs[half * 4 + fmh];
           // rounded to bf16 here, once per element (both the owner and the partner lane read it back)
           const bf16x2 lo = __builtin_convertvector(f32x2{a4[0], a4[1]}, bf16x2), hi2 = __builtin_convertvector(f32x2{a4[2], a4[3]}, bf16x2);
           f32x4 r4;
@@ -784,6 +812,20 @@ __global__ __launch_bounds__(512, 2) void gemm_pp256_kernel(const bf16* __restri
 #pragma unroll
         for (int e = 0; e < 8; ++e) o[e] = (bf16)v[e];
         __builtin_nontemporal_store(o, reinterpret_cast<bf16x8*>(C + m * ldc + n));
+        if constexpr (NRM == 1) {  // sum of squares of the line as it is stored: 4 x v_dot2c_f32_bf16, then the 8 lanes of the row
+          union {
+            bf16x8 v8;
+            bf16x2 h[4];
+          } u;
+          u.v8 = o;
+          float ss = 0.f;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) ss = __builtin_amdgcn_fdot2_f32_bf16(u.h[e], u.h[e], ss, false);
+          ss += dpp_move<0xB1>(ss);   // quad_perm(1,0,3,2)
+          ss += dpp_move<0x4E>(ss);   // quad_perm(2,3,0,1)
+          ss += dpp_move<0x141>(ss);  // row_half_mirror: the other quad of the 8-lane line
+          if (c == 0) aux[((n0 + wn * 64) >> 6) * M + m] = ss;
+        }
       }
     }
     return;
@@ -834,10 +876,11 @@ __global__ __launch_bounds__(512, 2) void gemm_pp256_kernel(const bf16* __restri
   }
 }
 
-template <bool TA, bool TB, int ABL, int EPI = 0, int ML = 0>
+template <bool TA, bool TB, int ABL, int EPI = 0, int ML = 0, int NRM = 0>
 int launch_one(const void* A, int64_t lda, const void* B, int64_t ldb, void* C, int64_t ldc, const void* R, int64_t ldr,
-               int64_t M, int64_t N, int64_t K, float alpha, float beta, int splitk, void* workspace, hipStream_t st) {
-  constexpr int LDSB = LDS_BYTES + ((ABL & 128) ? P8_DBG_BYTES : 0);
+               int64_t M, int64_t N, int64_t K, float alpha, float beta, int splitk, void* workspace, hipStream_t st,
+               float* aux = nullptr) {
+  constexpr int LDSB = LDS_BYTES + ((ABL & 128) ? P8_DBG_BYTES : 0) + (NRM == 2 ? 1024 : 0);
   // Both caches are PER DEVICE (a symbol's address and a function attribute belong to the device that is current when they
   // are asked for): a host that drives several GPUs from one process gets each device's own, keyed by the calling thread's
   // current device -- which is the device of `st`, as for every entry point (include/midihip.h).  Racing first calls write
@@ -859,7 +902,7 @@ int launch_one(const void* A, int64_t lda, const void* B, int64_t ldb, void* C, 
     __atomic_store_n(&zero16_of[dev], zero16, __ATOMIC_RELEASE);
   }
   if (!__atomic_load_n(&attr_set_of[dev], __ATOMIC_ACQUIRE)) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_pp256_kernel<TA, TB, ABL, EPI, ML>),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_pp256_kernel<TA, TB, ABL, EPI, ML, NRM>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, LDSB);
     if (e != hipSuccess) {
       mh_set_error("gemm_pp256: cannot raise dynamic LDS to %d bytes: %s", LDSB, hipGetErrorString(e));
@@ -872,9 +915,9 @@ int launch_one(const void* A, int64_t lda, const void* B, int64_t ldb, void* C, 
   constexpr int KSTEP = (ML == 1) ? 64 : QBK;
   const int64_t kps = ((K + splitk - 1) / splitk + KSTEP - 1) / KSTEP * KSTEP;
   dim3 grid(nwg, 1, splitk);
-  gemm_pp256_kernel<TA, TB, ABL, EPI, ML><<<grid, 512, LDSB, st>>>((const bf16*)A, lda, (const bf16*)B, ldb, (bf16*)C, ldc,
+  gemm_pp256_kernel<TA, TB, ABL, EPI, ML, NRM><<<grid, 512, LDSB, st>>>((const bf16*)A, lda, (const bf16*)B, ldb, (bf16*)C, ldc,
                                                           (const bf16*)R, ldr, M, N, K, alpha, beta, (int)tiles_n, nwg, kps,
-                                                          (float*)workspace, zero16);
+                                                          (float*)workspace, zero16, aux);
   MH_LAUNCH_CHECK();
   return MH_OK;
 }
@@ -939,15 +982,26 @@ int mh_gemm_pp256_bf16(const void* A, int64_t lda, int ta, const void* B, int64_
 }
 
 // gate|up = A * [Wgate; Wup]^T and a = round(silu(gate)) * up in one launch (both operands row-major); gemm.hip validates
+// (rowscale != NULL: every row of the product times rowscale[m] first -- the folded RMSNorm, NRM 2 above)
 int mh_gemm_pp256_swiglu_bf16(const void* A, int64_t lda, const void* W, int64_t ldw, void* GU, int64_t ldgu, void* ACT,
-                              int64_t ldact, int64_t M, int64_t I, int64_t K, hipStream_t st) {
+                              int64_t ldact, int64_t M, int64_t I, int64_t K, hipStream_t st, const float* rowscale) {
+  if (rowscale != nullptr) {
+    MH_REQUIRE(g_mh_gemm_k64 != 0 && M % 4 == 0, "gemm_swiglu: the row-scaled form needs the K-step-64 main loop and M %% 4 == 0");
+    return launch_one<false, false, 0, 2, 1, 2>(A, lda, W, ldw, GU, ldgu, ACT, ldact, M, 2 * I, K, 1.f, 0.f, 1, nullptr, st,
+                                                const_cast<float*>(rowscale));
+  }
   if (g_mh_gemm_k64) return launch_one<false, false, 0, 2, 1>(A, lda, W, ldw, GU, ldgu, ACT, ldact, M, 2 * I, K, 1.f, 0.f, 1, nullptr, st);
   return launch_one<false, false, 0, 2>(A, lda, W, ldw, GU, ldgu, ACT, ldact, M, 2 * I, K, 1.f, 0.f, 1, nullptr, st);
 }
 
 // [q | k | v] = A * W^T with the rotary embedding applied to the q and k heads in the epilogue; gemm.hip validates
 int mh_gemm_pp256_rope_bf16(const void* A, int64_t lda, const void* W, int64_t ldw, void* C, int64_t ldc, const void* table,
-                            int64_t S, int64_t pos0, int64_t M, int64_t N, int64_t K, hipStream_t st) {
+                            int64_t S, int64_t pos0, int64_t M, int64_t N, int64_t K, hipStream_t st, const float* rowscale) {
+  if (rowscale != nullptr) {
+    MH_REQUIRE(g_mh_gemm_k64 != 0 && M % 4 == 0, "gemm_rope: the row-scaled form needs the K-step-64 main loop and M %% 4 == 0");
+    return launch_one<false, false, 0, 3, 1, 2>(A, lda, W, ldw, C, ldc, table, S | (pos0 << 32), M, N, K, 1.f, 0.f, 1, nullptr, st,
+                                                const_cast<float*>(rowscale));
+  }
   if (g_mh_gemm_k64) return launch_one<false, false, 0, 3, 1>(A, lda, W, ldw, C, ldc, table, S | (pos0 << 32), M, N, K, 1.f, 0.f, 1, nullptr, st);
   return launch_one<false, false, 0, 3>(A, lda, W, ldw, C, ldc, table, S | (pos0 << 32), M, N, K, 1.f, 0.f, 1, nullptr, st);
 }
@@ -957,4 +1011,12 @@ int mh_gemm_pp256_dswiglu_bf16(const void* A, int64_t lda, const void* B, int64_
                                void* DGU, int64_t lddgu, int64_t M, int64_t I, int64_t K, hipStream_t st) {
   if (g_mh_gemm_k64 == 1) return launch_one<false, true, 0, 1, 1>(A, lda, B, ldb, DGU, lddgu, GU, ldgu, M, I, K, 1.f, 0.f, 1, nullptr, st);
   return launch_one<false, true, 0, 1>(A, lda, B, ldb, DGU, lddgu, GU, ldgu, M, I, K, 1.f, 0.f, 1, nullptr, st);
+}
+
+// C = A * B^T + R (both operands row-major, whole-line epilogue) and rowss[(n / 64) * M + m] = sum of squares of the stored row
+// chunk C[m, 64 (n / 64) .. + 64) -- the statistics of the RMSNorm that follows (NRM 1 above); gemm.hip validates
+int mh_gemm_pp256_rowss_bf16(const void* A, int64_t lda, const void* B, int64_t ldb, void* C, int64_t ldc, const void* R,
+                             int64_t ldr, int64_t M, int64_t N, int64_t K, float* rowss, hipStream_t st) {
+  MH_REQUIRE(g_mh_gemm_k64 != 0, "gemm_rowss: needs the K-step-64 main loop (option gemm_k64)");
+  return launch_one<false, false, 0, 0, 1, 1>(A, lda, B, ldb, C, ldc, R, ldr, M, N, K, 1.f, R ? 1.f : 0.f, 1, nullptr, st, rowss);
 }
