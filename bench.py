@@ -314,7 +314,7 @@ def pmc_traffic(kind: str = "gemm"):
 # mode: block (the north_star target)
 # ------------------------------------------------------------------------------------------------------------------
 def measure_block(args, B: int, S: int, steps: int, warmup: int, dist=None):
-    """ONE event-level block forward (engine.layer_forward: 8 launches) on a resident [B*S, 1024] bf16 input; FLOPs
+    """ONE event-level block forward (engine.layer_forward_folded: 7 launches; engine.layer_forward: 8) on a resident [B*S, 1024] bf16 input; FLOPs
     41,945,088 per event at S=4096 against the 2.5 PFLOP/s bf16 MFMA peak."""
     import midi_model_amd as mm
     from midi_model_amd import engine, ops
@@ -332,8 +332,20 @@ def measure_block(args, B: int, S: int, steps: int, warmup: int, dist=None):
         ops.embed_sum_fwd(ev.view(B * S, -1), W.embed, x)
         x, _ = engine.layer_forward(spec, W.layers[0], x, B, S, rope)   # input of block 1: a real residual stream
         lw = W.layers[1]
+        # r05: the forward-only block as a prefill of this size runs it (engine.stack_forward, save=False): both RMSNorms folded
+        # around the projections.  The folded weight copies are derived data of static inference weights (made once, outside the
+        # timed loop, as a decode session keeps them); the row statistics of the block's input are those the previous block's down
+        # projection leaves behind.
+        folded_form = (not args.block_save) and not args.block_unfolded and ops.norm_fold_ok(x, spec.D, spec.hd, spec.I)
+        parts_in = None
+        if folded_form:
+            fold = engine.fold_norm_weights(W)[1]
+            # (the statistics of x in the layout the previous block's down projection leaves them: [D / 64, M] partial sums of squares)
+            parts_in = x.float().pow(2).view(B * S, spec.D // 64, 64).sum(-1).t().contiguous()
 
         def step(i):  # (save=False: the forward-only form a prompt prefill runs -- gate|up is not written for a backward)
+            if folded_form:
+                return engine.layer_forward_folded(spec, lw, fold, x, B, S, rope, parts_in)[0]
             return engine.layer_forward(spec, lw, x, B, S, rope, save=args.block_save)[0]
 
         for i in range(warmup):
@@ -357,7 +369,9 @@ def measure_block(args, B: int, S: int, steps: int, warmup: int, dist=None):
     return {
         "what": "one net block forward (LlamaDecoderLayer.forward, TF modeling_llama.py:295-324): RMSNorm, q|k|v + RoPE (projection "
                 "epilogue), causal flash attention, o + residual, RMSNorm, gate|up + SwiGLU (projection epilogue), down + residual",
-        "form": "training forward (activations kept for the backward)" if args.block_save else "forward only (prefill / validation: gate|up not stored)",
+        "form": ("training forward (activations kept for the backward)" if args.block_save else
+                 "forward only (prefill / validation: gate|up not stored)" + ("; both RMSNorms folded around the projections" if folded_form else "")),
+        "norms_folded": bool(folded_form),
         "batch": B, "seq_len": S, "dtype": args.dtype, "ms_per_block": 1e3 * dt / steps, "events_per_s": B * S * steps / dt,
         "flops_per_event": block_flops_per_event(S, spec.D, spec.I),
         "roofline": {"bound": "mfma", "achieved": ach, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": ach / PEAK_BF16_TFLOPS,
@@ -546,6 +560,8 @@ def main():
     ap.add_argument("--gen-events", type=int, default=1024, help="new events per sequence per generate() call")
     ap.add_argument("--block-batch", type=int, default=16)
     ap.add_argument("--block-seq", type=int, default=4096)
+    ap.add_argument("--block-unfolded", action="store_true",
+                    help="block mode: the forward-only block with its two RMSNorm passes (the r04 form) instead of the folded norms")
     ap.add_argument("--block-save", action="store_true",
                     help="block mode: the TRAINING forward (also stores gate|up for the backward) instead of the forward-only form")
     ap.add_argument("--comm", default=os.environ.get("MH_COMM", "torch"), choices=["torch", "mh", "both"],

@@ -503,13 +503,22 @@ extern "C" int mh_rmsnorm_fwd(const void* x, const void* w, void* y, float* rstd
 //                  behind (a thread per row, nparts coalesced loads);
 //   x != NULL:     the same from the rows themselves (a wave per row; the first layer of a stack, whose input no GEMM of
 //                  ours produced).  LlamaRMSNorm.forward, TF:models/llama/modeling_llama.py:62-67: variance in fp32.
+// 64 rows per workgroup, the parts of a row spread over the four waves (wave q takes parts q, q + 4, ...: at most a handful of
+// independent loads per thread, 1024 workgroups for 65536 rows) and folded through LDS: the first form -- a thread per row walking
+// all 16 parts, 256 workgroups -- took 10 us per launch at 65536 rows, a third of what the fold saves (profiles/r05b_block_ab.txt).
 __global__ __launch_bounds__(256) void rstd_from_parts_kernel(const float* __restrict__ parts, int nparts, int64_t M, float inv_d,
                                                               float eps, float* __restrict__ rstd) {
-  const int64_t m = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  if (m >= M) return;
+  __shared__ float acc[4][64];
+  const int r = threadIdx.x & 63, q = threadIdx.x >> 6;
+  const int64_t m = (int64_t)blockIdx.x * 64 + r;
   float ss = 0.f;
-  for (int p = 0; p < nparts; ++p) ss += parts[(int64_t)p * M + m];
-  rstd[m] = rsqrtf(ss * inv_d + eps);
+  if (m < M) {
+#pragma unroll 4
+    for (int p = q; p < nparts; p += 4) ss += parts[(int64_t)p * M + m];
+  }
+  acc[q][r] = ss;
+  __syncthreads();
+  if (q == 0 && m < M) rstd[m] = rsqrtf((acc[0][r] + acc[1][r] + acc[2][r] + acc[3][r]) * inv_d + eps);
 }
 template <typename T>
 __global__ __launch_bounds__(256) void row_rstd_kernel(const T* __restrict__ x, int64_t ldx, int64_t M, int D, float eps,
@@ -533,7 +542,7 @@ extern "C" int mh_row_rstd(const void* x, int64_t ldx, const float* parts, int n
   MH_REQUIRE(M > 0 && D > 0 && rstd != nullptr && ((x != nullptr) != (parts != nullptr)), "row_rstd: give x OR parts (M=%ld D=%d)", (long)M, D);
   if (parts != nullptr) {
     MH_REQUIRE(nparts > 0, "row_rstd: nparts = %d", nparts);
-    rstd_from_parts_kernel<<<(unsigned)((M + 255) / 256), 256, 0, (hipStream_t)stream>>>(parts, nparts, M, 1.0f / (float)D, eps, rstd);
+    rstd_from_parts_kernel<<<(unsigned)((M + 63) / 64), 256, 0, (hipStream_t)stream>>>(parts, nparts, M, 1.0f / (float)D, eps, rstd);
   } else {
     MH_REQUIRE(D % 8 == 0 && ldx % 8 == 0 && ldx >= D && ((uintptr_t)x & 15) == 0, "row_rstd: rows must be 16-byte aligned");
     DISPATCH_T(dtype, (row_rstd_kernel<T><<<grid_for(M, 4, 65536), 256, 0, (hipStream_t)stream>>>((const T*)x, ldx, M, D, eps, rstd)));

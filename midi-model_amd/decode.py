@@ -256,7 +256,7 @@ class DecodeSession:
         e = torch.empty((B * S, spec.D), dtype=m.dtype, device=m.device)
         ops.embed_sum_fwd(tokens.contiguous().view(B * S, T), m._W["net"].embed, e)
         self.kv1.len = 0
-        y = engine.stack_prefill(spec, m._W["net"], e, B, S, self.rope1, self.kv1)
+        y = engine.stack_prefill(spec, m._W["net"], e, B, S, self.rope1, self.kv1, folded=self.fold1)
         self.hidden.copy_(y.view(B, S, spec.D)[:, -1])
         self.pos.fill_(S)
 

@@ -162,15 +162,70 @@ def layer_forward(spec: StackSpec, lw: LayerTensors, x: torch.Tensor, nseq: int,
     return x3, ((x, rstd1, h1, qkv, o, lse, x2, rstd2, h2, gu, None if lean else a) if save else None)
 
 
+# The forward-only event-level block with both RMSNorms folded around its projections (r05): below these row counts the two
+# extra ~3 us statistics launches (and, without pre-folded weights, the fold itself: ~20 us per layer of elementwise work) cost more
+# than the two norm passes they replace (2 x 44 us at 65536 rows, proportional to the rows).
+FOLD_MIN_ROWS_PREFOLDED = 8192
+FOLD_MIN_ROWS_ON_THE_FLY = 32768
+
+
+def layer_forward_folded(spec: StackSpec, lw: LayerTensors, fold, x: torch.Tensor, nseq: int, slen: int, rope: RopeTable,
+                         parts_in: Optional[torch.Tensor], kv_out: Optional[list] = None):
+    """layer_forward(save=False) without its two RMSNorm passes (LlamaDecoderLayer.forward, TF:models/llama/modeling_llama.py:295-324;
+    LlamaRMSNorm :62-67): ``fold`` = (wqkv * n1, wgu * n2) from fold_norm_weights, so norm(x) W^T = rstd (.) (x W'^T) and the
+    normalised activations h1 / h2 are never written or read.  The row statistics come out of the PRODUCING projections: the
+    o and down projections (mh_gemm_rowss) leave per-64-column sums of squares of the rows they store (``parts`` [D/64, M]),
+    mh_row_rstd turns them into rstd (one tiny launch), the q|k|v + RoPE and gate|up + SwiGLU projections apply it to their
+    fp32 accumulators before their own epilogue arithmetic.  7 launches, none of them a pass over the residual stream.
+    ``parts_in``: the statistics of ``x`` left by the previous block's down projection (None: computed from x itself).
+    Returns (block output, its parts)."""
+    M, D = x.shape
+    H, I = spec.H, spec.I
+    wq_n, wgu_n = fold
+    rstd = _empty((M,), x, torch.float32)
+    if parts_in is not None:
+        ops.row_rstd(rstd, D, spec.eps, parts=parts_in)
+    else:
+        ops.row_rstd(rstd, D, spec.eps, x=x)
+    qkv = _empty((M, 3 * D), x)
+    ops.gemm_rope(x, wq_n, qkv, rope.fused(), slen, 0, spec.hd, rowscale=rstd)
+    o = _empty((M, D), x)
+    lse = _empty((nseq * H * ops.round_up(slen, 64),), x, torch.float32)
+    ops.attn_fwd(qkv, o, lse, nseq, slen, H, spec.scale)
+    if kv_out is not None:
+        kv_out.append(qkv)
+    parts = _empty((D // 64, M), x, torch.float32)
+    x2 = _empty((M, D), x)
+    ops.gemm_rowss(o, lw.wo, x2, parts, res=x)
+    ops.row_rstd(rstd, D, spec.eps, parts=parts)
+    a = _empty((M, I), x)
+    ops.gemm_swiglu(x2, wgu_n, None, a, rowscale=rstd)
+    x3 = _empty((M, D), x)
+    ops.gemm_rowss(a, lw.wd, x3, parts, res=x2)
+    return x3, parts
+
+
 def stack_forward(spec: StackSpec, W: StackTensors, x: torch.Tensor, nseq: int, slen: int, rope: RopeTable,
-                  save: bool, kv_out: Optional[list] = None, lean: bool = False):
+                  save: bool, kv_out: Optional[list] = None, lean: bool = False, folded=None):
     """x [nseq*slen, D] (inputs_embeds) -> last_hidden_state [nseq*slen, D].
     save=True keeps what the backward needs (``lean``: minus the SwiGLU activations, recomputed in the backward);
-    kv_out (prefill) receives each layer's post-RoPE qkv."""
+    kv_out (prefill) receives each layer's post-RoPE qkv.  Forward-only passes of the event-level stack over enough rows run
+    the folded-norm blocks (layer_forward_folded); ``folded`` = fold_norm_weights(W) kept current by the caller (a decode
+    session's), otherwise the fold is made here, from the live weights, per call."""
     _check_heads(spec)
     M, D = x.shape
     assert M == nseq * slen
     rope.ensure(slen)
+    if (not save and spec.kind == "event" and M >= (FOLD_MIN_ROWS_PREFOLDED if folded is not None else FOLD_MIN_ROWS_ON_THE_FLY)
+            and ops.norm_fold_ok(x, D, spec.hd, spec.I)):
+        if folded is None:
+            folded = fold_norm_weights(W)
+        parts = None
+        for lw, fold in zip(W.layers, folded):
+            x, parts = layer_forward_folded(spec, lw, fold, x, nseq, slen, rope, parts, kv_out)
+        y = _empty((M, D), x)
+        ops.rmsnorm_fwd(x, W.norm, y, None, spec.eps)
+        return y, None
     saved = []
     for lw in W.layers:
         x3, keep = layer_forward(spec, lw, x, nseq, slen, rope, kv_out, save, lean and save)
@@ -262,12 +317,13 @@ class KVState:
         self.cap = cap
 
 
-def stack_prefill(spec: StackSpec, W: StackTensors, x: torch.Tensor, nseq: int, slen: int, rope: RopeTable, kv: KVState):
+def stack_prefill(spec: StackSpec, W: StackTensors, x: torch.Tensor, nseq: int, slen: int, rope: RopeTable, kv: KVState,
+                  folded=None):
     """Causal forward over a whole prompt from an EMPTY cache, storing K/V rows [0, slen)."""
     assert kv.len == 0
     kv.reserve(slen)
     qkvs: list = []
-    y, _ = stack_forward(spec, W, x, nseq, slen, rope, save=False, kv_out=qkvs)
+    y, _ = stack_forward(spec, W, x, nseq, slen, rope, save=False, kv_out=qkvs, folded=folded)
     for li, qkv in enumerate(qkvs):
         ops.kv_store_prefill(qkv, kv.k[li], kv.v[li], nseq, slen, spec.H, spec.hd, kv.cap)
     kv.len = slen

@@ -310,6 +310,15 @@ class MIDIModel(nn.Module):
         self._check_ids(x)
         x = x.to(device=self.device, dtype=torch.long).contiguous()
         if cache is None:
+            if not torch.is_grad_enabled():
+                # nothing will backpropagate (validation, app.py's no_grad calls): the forward-only schedule -- no activations kept,
+                # gate|up never written, and for enough rows the folded-norm blocks.  (Inside an autograd.Function the grad mode is
+                # always off and needs_input_grad still reports the parameters' flags, so the decision is taken here.)
+                spec = self._specs["net"]
+                e = torch.empty((B * S, spec.D), dtype=self.dtype, device=self.device)
+                ops.embed_sum_fwd(x.view(B * S, T), self._W["net"].embed, e)
+                y, _ = engine.stack_forward(spec, self._W["net"], e, B, S, self.rope("net"), save=False)
+                return y.view(B, S, spec.D)
             from .autograd import NetFn
             params = self._stack_params("net")
             return NetFn.apply(self, x, *params)

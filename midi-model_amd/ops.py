@@ -165,8 +165,49 @@ def rope_fused_ok(x: torch.Tensor, hd: int) -> bool:
     return x.dtype == torch.bfloat16 and hd == 64 and get_option("gemm") != 0 and (_FUSE & 4) != 0
 
 
-def gemm_rope(x: torch.Tensor, wqkv: torch.Tensor, qkv: torch.Tensor, table: torch.Tensor, S: int, pos0: int, hd: int):
-    """qkv = x @ wqkv^T with q and k rotated in the projection's epilogue (table: RopeTable.fused())"""
+def norm_fold_ok(x: torch.Tensor, D: int, hd: int, I: int) -> bool:
+    """whether the forward-only block can fold its two RMSNorms around the projections (mh_gemm_rowss producers, mh_row_rstd,
+    mh_gemm_rope_scaled / mh_gemm_swiglu_scaled consumers): bf16, event-level heads of 64, the fused epilogues available,
+    whole 64-column chunks and 4-row groups"""
+    return (rope_fused_ok(x, hd) and swiglu_fused_ok(x, I) and D % 64 == 0 and x.shape[0] % 4 == 0 and get_option("gemm_k64") != 0
+            and os.environ.get("MH_NORM_FOLD", "1") != "0")
+
+
+def gemm_rowss(a: torch.Tensor, b: torch.Tensor, out: torch.Tensor, rowss: torch.Tensor, res: Optional[torch.Tensor] = None):
+    """out = a @ b^T (+ res) and rowss[N // 64, M] (fp32) = per-64-column sums of squares of the stored rows of `out`"""
+    M, N = out.shape
+    K = a.shape[1]
+    assert b.shape == (N, K) and a.shape[0] == M and N % 64 == 0 and rowss.shape == (N // 64, M) and rowss.dtype == torch.float32
+    assert rowss.is_contiguous() and (res is None or res.shape == out.shape)
+    prof = gemm_profile
+    if prof is not None:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+    lib().call("mh_gemm_rowss", _p(a), _rowmajor(a), _p(b), _rowmajor(b), _p(out), _rowmajor(out), _p(res),
+               _rowmajor(res) if res is not None else 0, _p(rowss), M, N, K, dt(out), _stream())
+    if prof is not None:
+        e1.record()
+        prof.append((e0, e1, 2.0 * M * N * K, (M, N, K, 1, 0, 0, "+rowss")))
+    return out
+
+
+def row_rstd(rstd: torch.Tensor, D: int, eps: float, x: Optional[torch.Tensor] = None, parts: Optional[torch.Tensor] = None):
+    """rstd[M] (fp32) = rsqrt(mean(row^2) + eps) from the rows ``x`` [M, D] or from ``parts`` = gemm_rowss's [D // 64, M] sums"""
+    M = rstd.shape[0]
+    assert (x is None) != (parts is None) and rstd.dtype == torch.float32 and rstd.is_contiguous()
+    if parts is not None:
+        assert parts.shape[1] == M and parts.dtype == torch.float32 and parts.is_contiguous()
+        lib().call("mh_row_rstd", None, 0, _p(parts), parts.shape[0], M, D, eps, _p(rstd), MH_BF16, _stream())
+    else:
+        assert x.shape == (M, D)
+        lib().call("mh_row_rstd", _p(x), _rowmajor(x), None, 0, M, D, eps, _p(rstd), dt(x), _stream())
+    return rstd
+
+
+def gemm_rope(x: torch.Tensor, wqkv: torch.Tensor, qkv: torch.Tensor, table: torch.Tensor, S: int, pos0: int, hd: int,
+              rowscale: Optional[torch.Tensor] = None):
+    """qkv = x @ wqkv^T with q and k rotated in the projection's epilogue (table: RopeTable.fused()); ``rowscale`` (fp32 [M]):
+    every row of the product times rowscale[m] first -- RMSNorm with its weight folded into wqkv by the caller"""
     M, K = x.shape
     N = wqkv.shape[0]
     assert qkv.shape == (M, N) and wqkv.shape[1] == K and table.dtype == torch.bfloat16 and table.shape[1] == 96
@@ -174,8 +215,13 @@ def gemm_rope(x: torch.Tensor, wqkv: torch.Tensor, qkv: torch.Tensor, table: tor
     if prof is not None:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-    lib().call("mh_gemm_rope", _p(x), _rowmajor(x), _p(wqkv), _rowmajor(wqkv), _p(qkv), _rowmajor(qkv), _p(table),
-               table.shape[0], S, pos0, hd, M, N, K, dt(x), _stream())
+    if rowscale is not None:
+        assert rowscale.shape == (M,) and rowscale.dtype == torch.float32 and rowscale.is_contiguous()
+        lib().call("mh_gemm_rope_scaled", _p(x), _rowmajor(x), _p(wqkv), _rowmajor(wqkv), _p(qkv), _rowmajor(qkv), _p(table),
+                   table.shape[0], S, pos0, hd, _p(rowscale), M, N, K, dt(x), _stream())
+    else:
+        lib().call("mh_gemm_rope", _p(x), _rowmajor(x), _p(wqkv), _rowmajor(wqkv), _p(qkv), _rowmajor(qkv), _p(table),
+                   table.shape[0], S, pos0, hd, M, N, K, dt(x), _stream())
     if prof is not None:
         e1.record()
         prof.append((e0, e1, 2.0 * M * N * K, (M, N, K, 1, 0, 0, "+rope")))
@@ -187,9 +233,10 @@ def swiglu_fused_ok(x: torch.Tensor, I: int) -> bool:
     return x.dtype == torch.bfloat16 and I % 128 == 0 and get_option("gemm") != 0 and (_FUSE & 1) != 0
 
 
-def gemm_swiglu(x: torch.Tensor, wgu: torch.Tensor, gu: Optional[torch.Tensor], a: torch.Tensor) -> torch.Tensor:
+def gemm_swiglu(x: torch.Tensor, wgu: torch.Tensor, gu: Optional[torch.Tensor], a: torch.Tensor,
+                rowscale: Optional[torch.Tensor] = None) -> torch.Tensor:
     """gu [M, 2I] = x @ wgu^T (wgu = [gate; up], [2I, K]) and a [M, I] = silu(gate) * up; gu=None: forward only, gate|up is
-    not written (nothing will backpropagate)"""
+    not written (nothing will backpropagate); ``rowscale`` (fp32 [M]): rows of the product scaled first (folded RMSNorm)"""
     M, K = x.shape
     I = a.shape[1]
     assert wgu.shape == (2 * I, K) and a.shape[0] == M and x.dtype == wgu.dtype == a.dtype
@@ -198,8 +245,13 @@ def gemm_swiglu(x: torch.Tensor, wgu: torch.Tensor, gu: Optional[torch.Tensor], 
     if prof is not None:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-    lib().call("mh_gemm_swiglu", _p(x), _rowmajor(x), _p(wgu), _rowmajor(wgu), _p(gu), _rowmajor(gu) if gu is not None else 0,
-               _p(a), _rowmajor(a), M, I, K, dt(x), _stream())
+    if rowscale is not None:
+        assert rowscale.shape == (M,) and rowscale.dtype == torch.float32 and rowscale.is_contiguous()
+        lib().call("mh_gemm_swiglu_scaled", _p(x), _rowmajor(x), _p(wgu), _rowmajor(wgu), _p(gu), _rowmajor(gu) if gu is not None else 0,
+                   _p(a), _rowmajor(a), _p(rowscale), M, I, K, dt(x), _stream())
+    else:
+        lib().call("mh_gemm_swiglu", _p(x), _rowmajor(x), _p(wgu), _rowmajor(wgu), _p(gu), _rowmajor(gu) if gu is not None else 0,
+                   _p(a), _rowmajor(a), M, I, K, dt(x), _stream())
     if prof is not None:
         e1.record()
         prof.append((e0, e1, 2.0 * M * 2 * I * K, (M, 2 * I, K, 1, 0, 0, "+swiglu")))

@@ -48,20 +48,49 @@ def swiglu_fused_ok(x, I):
     return x.dtype == torch.bfloat16 and I % 128 == 0
 
 
-def gemm_swiglu(x, wgu, gu, a):
+def _scaled_product(x, w, out, rowscale):
+    """out = round(rowscale[:, None] * (x @ w^T)): the fp32 product scaled BEFORE it is rounded (mh_gemm_*_scaled)"""
+    out.copy_((rowscale.float()[:, None] * (x.float() @ w.float().T)).to(out.dtype))
+    return out
+
+
+def gemm_swiglu(x, wgu, gu, a, rowscale=None):
     if gu is None:  # forward-only form: gate|up is not kept
         gu = torch.empty((x.shape[0], wgu.shape[0]), dtype=x.dtype)
-    gemm_nt(x, wgu, gu)
+    if rowscale is not None:
+        _scaled_product(x, wgu, gu, rowscale)
+    else:
+        gemm_nt(x, wgu, gu)
     return swiglu_fwd(gu, a)
+
+
+def norm_fold_ok(x, D, hd, I):
+    return rope_fused_ok(x, hd) and swiglu_fused_ok(x, I) and D % 64 == 0 and x.shape[0] % 4 == 0
+
+
+def gemm_rowss(a, b, out, rowss, res=None):
+    gemm_nt(a, b, out, beta=0.0 if res is None else 1.0, res=res)
+    M, N = out.shape
+    rowss.copy_(out.float().pow(2).view(M, N // 64, 64).sum(-1).T)
+    return out
+
+
+def row_rstd(rstd, D, eps, x=None, parts=None):
+    ss = parts.sum(0) if parts is not None else x.float().pow(2).sum(-1)
+    rstd.copy_(torch.rsqrt(ss / D + eps))
+    return rstd
 
 
 def rope_fused_ok(x, hd):
     return x.dtype == torch.bfloat16 and hd == 64
 
 
-def gemm_rope(x, wqkv, qkv, table, S, pos0, hd):
+def gemm_rope(x, wqkv, qkv, table, S, pos0, hd, rowscale=None):
     """table: bf16 [npos, 96] = cos | -sin | +sin (RopeTable.fused)"""
-    gemm_nt(x, wqkv, qkv)
+    if rowscale is not None:
+        _scaled_product(x, wqkv, qkv, rowscale)
+    else:
+        gemm_nt(x, wqkv, qkv)
     H = wqkv.shape[0] // (3 * hd)
     return rope_(qkv, table[:, :32].float(), table[:, 64:96].float(), S, pos0, H, hd, +1)
 

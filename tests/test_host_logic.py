@@ -326,6 +326,41 @@ def test_grad_accumulation_averages_micro_batches(orc, tiny, tok):
     np.testing.assert_allclose(g2.numpy(), (0.5 * (singles[0] + singles[1])).numpy(), rtol=1e-4, atol=1e-7)
 
 
+def test_folded_norm_forward_only_stack(orc, tiny, tok, monkeypatch):
+    """engine.stack_forward(save=False) with the RMSNorms folded around the projections (layer_forward_folded: statistics out of the
+    o / down projections, rstd applied by the q|k|v and gate|up projections) against the plain blocks: the same hidden states
+    within bf16 rounding (the fold moves two roundings: W' = round(w W) instead of round(w round(x rstd))), through the model's
+    own no-grad forward, a cached prefill, and with a session-style pre-folded weight list.  Host schedule on the CPU stand-ins;
+    the kernels are compared on the device (tests/test_kernels_gpu.py, test_parity_long_gpu.py)."""
+    from midi_model_amd import engine
+    shp, sd, batch = tiny
+    x = orc.synthetic_events(tok, 2, 24, seed=8)
+    with emu_ops.install():
+        m = mm.MIDIModel(tiny_config())
+        m.load_state_dict(sd)
+        m = m.to(torch.bfloat16)
+        with torch.no_grad():
+            plain = m.forward(x).float()
+        calls = []
+        real = engine.layer_forward_folded
+        monkeypatch.setattr(engine, "layer_forward_folded", lambda *a, **k: (calls.append(a[7] is not None), real(*a, **k))[1])
+        monkeypatch.setattr(engine, "FOLD_MIN_ROWS_ON_THE_FLY", 0)
+        monkeypatch.setattr(engine, "FOLD_MIN_ROWS_PREFOLDED", 0)
+        with torch.no_grad():
+            folded = m.forward(x).float()
+
+            class AnyCache:
+                pass
+            cached = m.forward(x, cache=AnyCache()).float()
+        # 4 layers x 2 calls; only the first block of a stack computes its statistics from the rows themselves
+        assert calls == [False, True, True, True] * 2
+    err = (folded - plain).abs().max().item()
+    assert err < 0.06 * plain.abs().max().item(), err      # bf16 rounding noise through 4 layers, not a wiring error
+    assert torch.equal(cached, folded)
+    hid_o = orc.midi_forward(sd, shp, x)
+    assert (folded - hid_o).abs().max() < 1.5 * (plain - hid_o).abs().max() + 0.02
+
+
 def test_lean_activation_saving_is_bit_identical(orc, tiny, tok):
     """``lean_activations``: the forward drops the SwiGLU activations and the backward recomputes them from gate|up
     (engine.layer_forward / stack_backward) -- same loss, same gradients, bit for bit (host schedule; the device kernels share

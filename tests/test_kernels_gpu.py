@@ -256,6 +256,67 @@ def test_gemm_rope(ops, main_loop, B, S, H, K):
     ref = emu.rope_(plain.cpu().clone(), tab.cos.cpu(), tab.sin.cpu(), S, 0, H, 64, +1)
     cmp(fused, ref, dt, what="gemm_rope vs emulation")
 
+@pytest.mark.parametrize("M,N,K,res", [(512, 1024, 1024, True), (1000, 256, 4096, True), (260, 1024, 512, False)])
+def test_gemm_rowss(ops, M, N, K, res):
+    """mh_gemm_rowss (the producer side of the folded RMSNorm): C is bit-identical to mh_gemm_nt's, and rowss[n / 64, m] is the
+    sum of squares of the STORED bf16 chunk C[m, 64 (n/64) .. + 64) (fp32 accumulation: rtol 1e-5 against torch's)."""
+    a, b = rnd((M, K), torch.bfloat16, 1), rnd((N, K), torch.bfloat16, 2, 0.05)
+    r = rnd((M, N), torch.bfloat16, 3) if res else None
+    want = torch.empty((M, N), dtype=torch.bfloat16, device="cuda")
+    ops.gemm_nt(a.cuda(), b.cuda(), want, beta=1.0 if res else 0.0, res=r.cuda() if res else None, splitk=1)  # (the same single-slice sum)
+    got = torch.empty_like(want)
+    parts = torch.full((N // 64, M), float("nan"), device="cuda")
+    ops.gemm_rowss(a.cuda(), b.cuda(), got, parts, res=r.cuda() if res else None)
+    assert torch.equal(got, want)
+    ss = want.float().pow(2).view(M, N // 64, 64).sum(-1).t()
+    assert torch.isfinite(parts).all()
+    torch.testing.assert_close(parts, ss, rtol=2e-5, atol=1e-6)
+    rs = torch.empty((M,), device="cuda")
+    ops.row_rstd(rs, N, 1e-6, parts=parts)
+    torch.testing.assert_close(rs, torch.rsqrt(want.float().pow(2).mean(-1) + 1e-6), rtol=2e-5, atol=0)
+    rs2 = torch.empty((M,), device="cuda")
+    ops.row_rstd(rs2, N, 1e-6, x=want)
+    torch.testing.assert_close(rs2, rs, rtol=2e-5, atol=0)
+
+
+@pytest.mark.parametrize("M", [512, 1028])
+def test_gemm_scaled_epilogues(ops, M):
+    """mh_gemm_rope_scaled / mh_gemm_swiglu_scaled (the consumer side): every row of the fp32 product is multiplied by rowscale[m]
+    BEFORE the epilogue rounds and rotates / applies SwiGLU -- against the same arithmetic spelled out in torch (fp32 product of
+    the bf16 operands, scale, round, then mh_rope / mh_swiglu_fwd, which the unscaled fused epilogues equal bit for bit).  A bf16
+    rounding of the scaled product can differ from the kernel's by one step where fp32 summation order moves a value across a
+    rounding boundary: compared within two bf16 ulps of the value's magnitude, and exactly on > 99 % of the elements."""
+    import midi_model_amd as mm
+    from midi_model_amd.engine import RopeTable
+    K, H, hd, I, S = 1024, 4, 64, 1024, 128
+    x = rnd((M, K), torch.bfloat16, 11).cuda()
+    sc = (0.5 + torch.rand((M,), generator=torch.Generator().manual_seed(5))).cuda()
+    # q|k|v + RoPE
+    wq = rnd((3 * H * hd, K), torch.bfloat16, 12, 0.05).cuda()
+    rope = RopeTable(hd, 10000.0, torch.device("cuda"), S)
+    got = torch.empty((M, 3 * H * hd), dtype=torch.bfloat16, device="cuda")
+    ops.gemm_rope(x, wq, got, rope.fused(), S, 0, hd, rowscale=sc)
+    want = (sc[:, None] * (x.float() @ wq.float().t())).to(torch.bfloat16)
+    ops.rope_(want, rope.cos, rope.sin, S, 0, H, hd, +1)
+    tol = 2.0 ** -7 * want.float().abs() + 2.0 ** -8 * want.float().abs().amax(-1, keepdim=True)
+    assert ((got.float() - want.float()).abs() <= tol).all() and (got == want).float().mean() > 0.99
+    # gate|up + SwiGLU, forward-only form (gate|up not written)
+    wg = rnd((2 * I, K), torch.bfloat16, 13, 0.05).cuda()
+    act = torch.empty((M, I), dtype=torch.bfloat16, device="cuda")
+    ops.gemm_swiglu(x, wg, None, act, rowscale=sc)
+    gu = (sc[:, None] * (x.float() @ wg.float().t())).to(torch.bfloat16)
+    want = torch.empty_like(act)
+    ops.swiglu_fwd(gu, want)
+    tol = 2.0 ** -6 * want.float().abs() + 2.0 ** -8 * want.float().abs().amax(-1, keepdim=True)
+    assert ((act.float() - want.float()).abs() <= tol).all() and (act == want).float().mean() > 0.98
+    # rowscale = 1: the scaled forms ARE the unscaled ones
+    one = torch.ones((M,), device="cuda")
+    a1, a0 = torch.empty_like(act), torch.empty_like(act)
+    ops.gemm_swiglu(x, wg, None, a1, rowscale=one)
+    ops.gemm_swiglu(x, wg, None, a0)
+    assert torch.equal(a1, a0)
+
+
 
 @pytest.mark.parametrize("M,I,K", [(256, 256, 64), (300, 520, 1024), (1000, 4096, 1024), (77, 1024, 264)])
 def test_gemm_dswiglu(ops, main_loop, M, I, K):

@@ -124,6 +124,21 @@ def test_forward_at_benchmarked_length(orc, medium, tok, golden, S, dtype):
     assert safe.any() and (amax == g["logits_argmax"])[safe].all()
 
 
+def test_forward_with_folded_norms_at_S4096(orc, medium, tok, golden, monkeypatch):
+    """The forward-only stack with both RMSNorms of every block folded around the projections (engine.layer_forward_folded: the
+    form bench.py --mode block times and a large prefill runs; mh_gemm_rowss / mh_row_rstd / mh_gemm_rope_scaled /
+    mh_gemm_swiglu_scaled) at S = 4096 against the reference's outputs (medium_long_S4096.npz): the same bounds as the unfolded
+    bf16 forward above -- inside 1.5x the reference's own bf16 drift, arg-max equal wherever the margin clears it.  The row
+    threshold that keeps small prompts on the plain path is lowered so that these 4096 rows take the folded one."""
+    from midi_model_amd import engine, ops
+    monkeypatch.setattr(engine, "FOLD_MIN_ROWS_ON_THE_FLY", 0)
+    calls = []
+    real = engine.layer_forward_folded
+    monkeypatch.setattr(engine, "layer_forward_folded", lambda *a, **k: (calls.append(1), real(*a, **k))[1])
+    test_forward_at_benchmarked_length(orc, medium, tok, golden, 4096, torch.bfloat16)
+    assert len(calls) >= 12, "the forward did not take the folded blocks"
+
+
 # ------------------------------------------------------------------------------ training step at S = 2048
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16], ids=["fp32", "bf16"])
 def test_training_step_gradients_at_S2048(orc, medium, tok, golden, dtype):
