@@ -7,7 +7,7 @@ for v in 0 3; do
     tag=$(echo $grp | cut -c1-12 | tr ' ' '_')
     rm -rf /tmp/p4_$v_$tag
     (cd /tmp && timeout 300 rocprofv3 --pmc $grp --kernel-trace --output-format csv -d /tmp/p4_${v}_$tag -o p -- $R/tools/bin/gemm4w_probe 32768 1024 16384 $v > /dev/null 2>&1)
-    python3 - /tmp/p4_${v}_$tag $v >> $O/r05d_pmc.txt <<'PY'
+    python3 - /tmp/p4_${v}_$tag $v >> $O/r05_probe_pmc.txt <<'PY'
 import csv, sys, glob, collections
 f = glob.glob(sys.argv[1] + "/**/*counter_collection.csv", recursive=True)
 agg = collections.defaultdict(lambda: collections.defaultdict(float)); n = collections.Counter()
@@ -19,4 +19,4 @@ for k, d in agg.items():
 PY
   done
 done
-cat $O/r05d_pmc.txt
+cat $O/r05_probe_pmc.txt
