@@ -23,6 +23,12 @@ INCLUDE = os.path.join(os.path.dirname(HERE), "include")
 
 SOURCES = ["api.cpp", "comm.cpp", "gemm.hip", "gemm_pp256.hip", "gemm_skinny.hip", "elementwise.hip", "loss_optim.hip", "attention_small.hip", "attention_mfma.hip", "attention_mfma3.hip", "augment.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-munsafe-fp-atomics", "-Wno-unused-result"]
+# per-file additions.  attention_mfma3.hip: no SLP vectorisation -- hipcc otherwise packs adjacent fp32 multiplies of the dS / rescale
+# arithmetic into v_pk_mul_f32, and a packed fp32 VALU instruction beside MFMAs costs the matrix pipe more than the issue slot it
+# saves (MI355X_MICROARCH.md, "price of one filler beside MFMAs").  Same bits (IEEE multiplies either way); same-box A/B, interleaved
+# (profiles/r05_attn_noslp_ab.txt): backward 689 -> 672 us at 16 x 2048, 1988 -> 1936 us at 16 x 4096, forward +-0 (its main loop
+# had no packed instruction).
+FILE_FLAGS = {"attention_mfma3.hip": ["-fno-slp-vectorize"]}
 
 
 def _hipcc() -> str:
@@ -57,7 +63,7 @@ def build(force: bool = False, verbose: bool = False, ab: bool = True) -> str:
 
     def run(job):
         s, o, extra = job
-        cmd = [hipcc, *FLAGS, *extra, "-x", "hip", "-c", s, "-o", o]
+        cmd = [hipcc, *FLAGS, *FILE_FLAGS.get(os.path.basename(s), []), *extra, "-x", "hip", "-c", s, "-o", o]
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError(f"hipcc failed on {s}:\n{r.stderr}")
