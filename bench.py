@@ -19,7 +19,11 @@ A step = forward + backward + gradient all-reduce (N>1) + global-norm clip + Ada
                    on a bounded sample of the same workload (N=1, rank 0 only)
   block            N=1: the `north_star` target -- ONE net block forward (RMSNorm -> q|k|v -> RoPE -> flash attention ->
                    o + residual -> RMSNorm -> gate|up + SwiGLU -> down + residual) at batch 16 x 4096 events, fraction
-                   of the bf16 MFMA peak against 41,945,088 FLOP per event
+                   of the bf16 MFMA peak against 41,945,088 FLOP per event; the forward-only form a
+                   prefill of this size runs: the two RMSNorms folded around the projections (`norms_folded`;
+                   `--mode block --block-unfolded` times the form with the two norm passes)
+  large, large_2x_hidden   N=1: BASELINE.json configs[4] at its per-GPU batch (16 x 4096), with hbm_peak_gb / hbm_headroom_gb
+  ranks, scaling_efficiency, comm_ab   N>1: every rank's own time, efficiency against --baseline-1gpu, --comm both
   generate         N=1: BASELINE.json configs[3] (KV-cached generate(), batch 64 x 1024 new events), fraction of the HBM
                    roofline of the decode step
 `--mode block` / `--mode generate` print those measurements as the top-level line instead.
