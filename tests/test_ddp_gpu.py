@@ -153,3 +153,38 @@ def test_rccl_world1_bucketed_exchange_inside_the_benchmarked_step(tmp_path, bac
     assert float(r["loss_plain"]) == float(r["loss_x"])
     assert bool(r["same"]), float(r["maxdiff"])
     assert float(r["exposed_ms"]) >= 0.0
+
+
+def test_bench_multi_gpu_code_path_rehearsal_on_the_real_backend():
+    """The N > 1 lines of bench.py on the backend the 8-GPU run will use, with ONE rank (`--force-dist`, launched exactly as the
+    driver launches N ranks: `python -m torch.distributed.run --nproc-per-node 1 ... bench.py --gpus 1 ...`): env:// rendezvous on
+    127.0.0.1, init_process_group("nccl", device_id), the barrier + synchronize bracket, the all-gather of the ranks' clocks on
+    the device, the parameter broadcast, fit_step with the bucketed all-reduce through torch.distributed's RCCL (15 x 32 MB on the
+    communication stream), `--comm both` (the library's communicator built from the process group, then the same steps through
+    mh_comm_allreduce), the all-reduce summary and the rank-0 JSON line.  What one rank cannot show is a ring; everything that
+    can fail before the first ring starts runs here (train.py:461-474)."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(root, "bench.py"), "--gpus", "1", "--force-dist", "--comm", "both",
+           "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--baseline-1gpu", "300000"]
+    r = subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["metric"].startswith("REHEARSAL") and d["n_gpus"] == 1 and d["steps"] == 2
+    assert d["comm"]["backend"] == "nccl" and d["comm"]["world_size"] == 1 and d["comm"]["exchange"] == "torch"
+    assert len(d["ranks"]["ms_per_step_by_rank"]) == 1 and abs(d["ranks"]["ms_per_step_max"] - d["ms_per_step"]) < 1e-6
+    assert abs(d["scaling_efficiency"] - d["value"] / 300000.0) < 1e-9
+    # one exchange of the whole bf16 gradient buffer per step, ~15 buckets, through torch's RCCL
+    assert d["allreduce_windows"] == 2 and d["allreduce_bytes_per_optimizer_step"] == 467_685_376
+    assert 14 <= d["allreduce_launches_per_optimizer_step"] <= 20
+    ab = d["comm_ab"]
+    assert "error" not in ab, ab
+    assert ab["mh_ms_per_step"] > 0 and ab["torch_ms_per_step"] > 0 and abs(ab["mh_ms_per_step"] / ab["torch_ms_per_step"] - 1) < 0.1
+    assert "roofline" in d and 0.2 < d["roofline"]["frac"] < 0.7 and "block" not in d and "cpu_baseline" not in d
