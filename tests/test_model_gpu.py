@@ -278,6 +278,31 @@ def test_bf16_gradients_track_fp32(orc, tok):
     assert cos > 0.98
 
 
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16], ids=["fp32", "bf16"])
+def test_lean_activation_saving_is_bit_identical_on_the_device(orc, tok, dtype):
+    """``TrainMIDIModel.lean_activations`` (the forward drops the SwiGLU activations, the backward recomputes them from gate|up
+    with mh_swiglu_fwd): loss and every gradient element equal the full-activation step's, bit for bit -- the fused gate|up
+    epilogue and mh_swiglu_fwd share their roundings.  Shape with a fused-epilogue MLP (inner 1024 / 256), 4 x 128 events."""
+    cfg = mm.MIDIModelConfig.get_config("v2", True, 4, 4, 256, 1024)
+    shp = orc.Shape(n_layer=4, n_head=4, n_embd=256, n_inner=1024, vocab=tok.vocab_size)
+    sd = orc.make_state_dict(shp, seed=21)
+    batch = orc.synthetic_events(tok, 4, 129, seed=22)
+    outs = []
+    for lean in (False, True):
+        m = build(TrainMIDIModel, cfg, sd, dtype, accumulate_grad_batches=1)
+        m.lean_activations = lean
+        loss = m.training_step(batch)
+        outs.append((loss.float().cpu().clone(), m.grad_buffer().float().cpu().clone()))
+    assert torch.equal(outs[0][0], outs[1][0])
+    if dtype == torch.bfloat16:
+        assert torch.equal(outs[0][1], outs[1][1])
+    else:  # fp32: the embedding gradients are summed with fp32 atomics per run of equal ids (order varies launch to launch: the
+        #       last bits of those rows differ between ANY two runs of the same step); everything else is exact
+        torch.testing.assert_close(outs[0][1], outs[1][1], rtol=1e-5, atol=1e-8)
+        assert (outs[0][1] == outs[1][1]).float().mean() > 0.9
+    assert torch.isfinite(outs[0][1]).all() and outs[0][1].abs().max() > 0
+
+
 def test_device_corpus_feeds_training_step(tiny, tok):
     """the step before the path (data.TokenCorpus / WindowSampler, one-kernel batch assembly on the device) feeding the
     training step: ragged pieces -> padded (B, L, 8) int64 batch -> finite loss, pad targets ignored"""
