@@ -166,7 +166,7 @@ def layer_forward(spec: StackSpec, lw: LayerTensors, x: torch.Tensor, nseq: int,
 # extra ~3 us statistics launches (and, without pre-folded weights, the fold itself: ~20 us per layer of elementwise work) cost more
 # than the two norm passes they replace (2 x 44 us at 65536 rows, proportional to the rows).
 FOLD_MIN_ROWS_PREFOLDED = 8192
-FOLD_MIN_ROWS_ON_THE_FLY = 32768
+FOLD_MIN_ROWS_ON_THE_FLY = 131072   # (12 layers: the fold ~0.7 ms of elementwise launches against ~14 us saved per layer and 8192 rows)
 
 
 def layer_forward_folded(spec: StackSpec, lw: LayerTensors, fold, x: torch.Tensor, nseq: int, slen: int, rope: RopeTable,
