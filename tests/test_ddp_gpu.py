@@ -188,3 +188,30 @@ def test_bench_multi_gpu_code_path_rehearsal_on_the_real_backend():
     assert "error" not in ab, ab
     assert ab["mh_ms_per_step"] > 0 and ab["torch_ms_per_step"] > 0 and abs(ab["mh_ms_per_step"] / ab["torch_ms_per_step"] - 1) < 0.1
     assert "roofline" in d and 0.2 < d["roofline"]["frac"] < 0.7 and "block" not in d and "cpu_baseline" not in d
+
+
+@pytest.mark.parametrize("mode,extra", [("block", ["--block-batch", "2", "--block-seq", "512"]),
+                                        ("block", ["--block-batch", "2", "--block-seq", "512", "--block-unfolded"]),
+                                        ("generate", ["--gen-batch", "4", "--gen-events", "12"])],
+                         ids=["block_folded", "block_unfolded", "generate"])
+def test_bench_modes_print_one_valid_line(mode, extra):
+    """the other modes of bench.py (the `block` and `generate` objects of the driver's line come from the same functions) at toy
+    sizes: one JSON line on stdout with the contract's keys and a roofline object; the folded and unfolded block forms both run"""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--mode", mode, "--steps", "2", "--warmup", "1", "--no-cpu-baseline", *extra],
+                       capture_output=True, text=True, env=env, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-1000:]
+    d = json.loads(lines[0])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "dtype", "data", "config", "roofline"):
+        assert k in d, k
+    assert d["value"] > 0 and d["n_gpus"] == 1 and d["roofline"]["frac"] > 0
+    if mode == "block":
+        assert d["block"]["norms_folded"] == ("--block-unfolded" not in extra)
+        names = set(d["block"]["kernels"])
+        assert ("mh_gemm_rowss" in names) == d["block"]["norms_folded"] and ("mh_rmsnorm_fwd" in names) != d["block"]["norms_folded"]
