@@ -605,7 +605,10 @@ __global__ __launch_bounds__(256) void rmsnorm_bwd_kernel(const T* __restrict__ 
 
 // Register-resident variant (D = NCH * 64 * 16 bytes): every operand is read once, and the weight gradient of the columns a
 // lane owns accumulates in registers over all the rows its wave walks; LDS only for the final 4-wave reduction.
-template <typename T, int NCH>
+// NT (r05): non-temporal loads and stores when an operand is larger than the Infinity Cache can keep between kernels (the token-level
+// stack: 262144 rows x 1024 = 537 MB per operand: 430-450 -> 404-419 us per launch); at the event-level size (67 MB per operand, which the
+// preceding kernel has just left in the 256 MiB cache) the same hints are 6 % SLOWER, so the launcher picks by size.  Same bits.
+template <typename T, int NCH, bool NT>
 __global__ __launch_bounds__(256) void rmsnorm_bwd_reg_kernel(const T* __restrict__ x, const T* __restrict__ w,
                                                               const float* __restrict__ rstd, const T* __restrict__ dy,
                                                               const T* dres, T* dx, float* __restrict__ dw_partial,
@@ -627,9 +630,15 @@ __global__ __launch_bounds__(256) void rmsnorm_bwd_reg_kernel(const T* __restric
 #pragma unroll
     for (int k = 0; k < NCH; ++k) {
       const int64_t c = m * D + (k * 64 + lane) * N;
-      xv[k] = ld16(x + c);
-      gv[k] = ld16(dy + c);
-      if (dres != nullptr) rv[k] = ld16(dres + c);
+      if constexpr (NT) {
+        xv[k].v = __builtin_nontemporal_load(reinterpret_cast<const decltype(xv[k].v)*>(x + c));
+        gv[k].v = __builtin_nontemporal_load(reinterpret_cast<const decltype(gv[k].v)*>(dy + c));
+        if (dres != nullptr) rv[k].v = __builtin_nontemporal_load(reinterpret_cast<const decltype(rv[k].v)*>(dres + c));
+      } else {
+        xv[k] = ld16(x + c);
+        gv[k] = ld16(dy + c);
+        if (dres != nullptr) rv[k] = ld16(dres + c);
+      }
     }
     float dot = 0.f;
 #pragma unroll
@@ -648,7 +657,8 @@ __global__ __launch_bounds__(256) void rmsnorm_bwd_reg_kernel(const T* __restric
         o.set(e, d);
         dwr[k][e] += gv[k].get(e) * rnd<T>(xh);
       }
-      st16(dx + m * D + (k * 64 + lane) * N, o);
+      if constexpr (NT) __builtin_nontemporal_store(o.v, reinterpret_cast<decltype(o.v)*>(dx + m * D + (k * 64 + lane) * N));
+      else st16(dx + m * D + (k * 64 + lane) * N, o);
     }
   }
 #pragma unroll
@@ -667,9 +677,16 @@ extern "C" int mh_rmsnorm_bwd(const void* x, const void* w, const float* rstd, c
   const size_t shm = (size_t)4 * D * sizeof(float);
   const int nch = D / (dtype == MH_BF16 ? 512 : 256);  // 16-byte chunks per lane
   const bool reg = nch * (dtype == MH_BF16 ? 512 : 256) == D && (nch == 1 || nch == 2 || nch == 4);
+  const bool nt = M * (int64_t)D * (dtype == MH_BF16 ? 2 : 4) > (int64_t(192) << 20);  // one operand against the 256 MiB Infinity Cache
 #define MH_RMSB(NCH_)                                                                                        \
-  DISPATCH_T(dtype, (rmsnorm_bwd_reg_kernel<T, NCH_><<<blocks, 256, shm, (hipStream_t)stream>>>(              \
-                        (const T*)x, (const T*)w, rstd, (const T*)dy, (const T*)dres, (T*)dx, dw_partial, M, D)))
+  do {                                                                                                      \
+    if (nt)                                                                                                 \
+      DISPATCH_T(dtype, (rmsnorm_bwd_reg_kernel<T, NCH_, true><<<blocks, 256, shm, (hipStream_t)stream>>>(    \
+                            (const T*)x, (const T*)w, rstd, (const T*)dy, (const T*)dres, (T*)dx, dw_partial, M, D))); \
+    else                                                                                                    \
+      DISPATCH_T(dtype, (rmsnorm_bwd_reg_kernel<T, NCH_, false><<<blocks, 256, shm, (hipStream_t)stream>>>(   \
+                            (const T*)x, (const T*)w, rstd, (const T*)dy, (const T*)dres, (T*)dx, dw_partial, M, D))); \
+  } while (0)
   if (reg && nch == 1) MH_RMSB(1);
   else if (reg && nch == 2) MH_RMSB(2);
   else if (reg && nch == 4) MH_RMSB(4);
