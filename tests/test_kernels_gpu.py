@@ -447,6 +447,29 @@ def test_rmsnorm(ops, dtype, M, D):
     cmp(dwg, dw, dtype, k=max(3.0, math.sqrt(M) / 3), what="rmsnorm dw (acc)")
 
 
+def test_rmsnorm_bwd_forms_agree_bit_for_bit(ops):
+    """mh_rmsnorm_bwd picks non-temporal loads / stores when an operand is larger than the Infinity Cache keeps between kernels
+    (> 192 MiB: the token-level stack's 262144 x 1024 rows).  Cache hints only: a 131072-row call (256 MiB per operand: the hinted
+    kernel) gives, on every 32768-row quarter, the bits the plain kernel gives for that quarter alone (dx is row-local)."""
+    M, D = 131072, 1024
+    g = torch.Generator(device="cuda").manual_seed(3)
+    x = torch.randn((M, D), device="cuda", generator=g).to(torch.bfloat16)
+    dy = torch.randn((M, D), device="cuda", generator=g).to(torch.bfloat16)
+    dres = torch.randn((M, D), device="cuda", generator=g).to(torch.bfloat16)
+    w = (1 + 0.1 * torch.randn(D, device="cuda", generator=g)).to(torch.bfloat16)
+    rstd = torch.rsqrt(x.float().pow(2).mean(-1) + 1e-6)
+    dx_big, dw_big = torch.empty_like(x), torch.zeros(D, device="cuda", dtype=torch.bfloat16)
+    ops.rmsnorm_bwd(x, w, rstd, dy, dres, dx_big, dw_big, False)
+    dw_sum = torch.zeros(D, device="cuda")
+    for q in range(4):
+        sl = slice(q * 32768, (q + 1) * 32768)
+        dx_q, dw_q = torch.empty((32768, D), device="cuda", dtype=torch.bfloat16), torch.zeros(D, device="cuda", dtype=torch.bfloat16)
+        ops.rmsnorm_bwd(x[sl], w, rstd[sl], dy[sl], dres[sl], dx_q, dw_q, False)
+        assert torch.equal(dx_q, dx_big[sl]), q
+        dw_sum += dw_q.float()
+    torch.testing.assert_close(dw_big.float(), dw_sum, rtol=3e-2, atol=2.0)   # (bf16 outputs of sums over 131072 / 32768 rows)
+
+
 # ------------------------------------------------------------------------------------------------ RoPE
 @pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("H,hd,S,M", [(4, 64, 10, 30), (1, 256, 8, 64), (16, 64, 33, 33)])
