@@ -182,7 +182,10 @@ def setup(args):
     torch.cuda.set_device(local)
     if world > 1 or args.force_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("MASTER_PORT", str(_free_port()))
+        if world == 1:  # (--force-dist rehearsal; with more ranks every rank must be given the SAME port by its launcher)
+            os.environ.setdefault("MASTER_PORT", str(_free_port()))
+        elif "MASTER_PORT" not in os.environ:
+            raise SystemExit("bench.py: WORLD_SIZE > 1 needs MASTER_PORT in the environment (torch.distributed.run sets it)")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
         assert dist.get_world_size() == world
     return world, rank, local, (dist if (world > 1 or args.force_dist) else None)

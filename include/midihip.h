@@ -231,6 +231,10 @@ int mh_attn_bwd(const void* qkv, const void* dout, const float* lse, const float
  * is selected (mh_set_option("attn_v3")): use the two calls above.                                                      */
 int mh_attn_bwd_o(const void* qkv, const void* o, const void* dout, const float* lse, float* delta, void* dqkv, int64_t B,
                   int64_t S, int H, float scale, const float* cos_t, const float* sin_t, int dtype, void* stream);
+/* measurement aid, A/B library only (the production library returns MH_ERR_UNSUPPORTED): the production bf16 forward with shader-clock
+ * stamps at the seams of each key tile's segments; stamps: uint32 [16][4][32][9] (tools/attn_timeline.py decodes them).        */
+int mh_attn_fwd_timeline(const void* qkv, void* o, float* lse, int64_t B, int64_t S, int H, float scale, int lazy,
+                         uint32_t* stamps, void* stream);
 /* NOTE: lse and delta are laid out [B,H,Sp] with Sp = S rounded up to a multiple of 64 (entries past S unused).
  * The *_plain variants run the exact-fp32-math thread-per-row kernels for either dtype; tests use them to
  * cross-check the MFMA kernels on the device.                                                              */

@@ -11,6 +11,8 @@ from __future__ import annotations
 import ctypes
 from typing import Optional
 
+import sys
+
 import torch
 
 from .lib import MH_BF16, MH_F32, lib
@@ -82,8 +84,7 @@ class MHComm:
     def __del__(self):
         # (not during interpreter teardown: ncclCommDestroy would run against a HIP runtime / librccl that may already be
         #  finalising; the process exit frees the communicator)
-        import sys
-        if sys is None or sys.is_finalizing():
+        if sys is None or sys.is_finalizing():  # (module globals are cleared during teardown)
             return
         try:
             self.close()

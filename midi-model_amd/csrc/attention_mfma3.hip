@@ -78,15 +78,33 @@ __device__ inline float xhalf_max(float v) {  // max with the other wave half's 
 // B=16, S=4096, 684 us complete: no v_exp -40, no row maximum -8, no P V MFMAs -100, no Q K^T MFMAs -68, no MFMAs -151, no
 // fragment reads -55, neither -278; staging + barriers + the sums alone 333 us.)
 // TR: tV is the row-major V tile [key][d] and the V^T fragments are transpose reads (no prepared [B,H,64,Sp] copy of V).
-template <bool MASK, bool TR>
+// LZ (r06, bit 7 of attn_v3): the reference maximum is LAZY.  The probabilities are taken against the row's reference maximum as
+// it stands -- no row maximum, no half-wave exchange, no compare: 16 v_max3 + ~6 of the ~145 VALU of a tile -- and the tile's
+// partial row sum, which is computed anyway, is the overflow detector: max p <= sum p, so a sum below LZ_BOUND = 2^40 proves that
+// every probability of the lane is (the reference may lag the true maximum by 40 binades instead of RESCALE_THR = 4: floating
+// point keeps the relative precision of P, O and l; only overflow to inf has to be excluded).  A sum that is larger, infinite
+// or NaN (first tile: m = -inf) in ANY lane sends the wave through the classic path -- maximum, rescale under EXEC, the
+// probabilities again from the scores, which the fast path leaves intact (P goes straight into its packed bf16 fragments).
+constexpr float LZ_BOUND = 1099511627776.f;  // 2^40
+// TL (A/B library only): s_memtime at the seams of the tile's segments, ts[2..6] (mh_attn_fwd_timeline; the values are read at the
+// end of the tile, behind one s_waitcnt lgkmcnt(0) at a point where no LDS operation is outstanding -- an SMEM result in
+// flight only makes hipcc's counted LDS waits conservative)
+__device__ inline uint64_t tl_now() {
+  uint64_t t;
+  asm volatile("s_memtime %0" : "=s"(t));
+  return t;
+}
+template <bool MASK, bool TR, bool LZ = false, bool TL = false>
 __device__ inline void fwd3_tile(const char* tK, const char* tV, const int (&trof)[2][2], const int (&foff)[4],
-                                 const bf16x8 (&qf)[4], f32x16 (&oacc)[2], float& m, float& l, int hi, int qrel, float sc) {
+                                 const bf16x8 (&qf)[4], f32x16 (&oacc)[2], float& m, float& l, int hi, int qrel, float sc,
+                                 uint64_t* ts = nullptr) {
   bf16x8 kf[2][4];
 #pragma unroll
   for (int s = 0; s < 4; ++s)
 #pragma unroll
     for (int kb = 0; kb < 2; ++kb) kf[kb][s] = ldsv(tK + foff[s] + kb * 4096);
   __builtin_amdgcn_sched_barrier(0);
+  if constexpr (TL) ts[2] = tl_now();  // K fragment reads issued
   f32x16 sacc[2] = {zero16(), zero16()};
 #pragma unroll
   for (int s = 0; s < 4; ++s)
@@ -116,6 +134,83 @@ __device__ inline void fwd3_tile(const char* tK, const char* tV, const int (&tro
       for (int db = 0; db < 2; ++db) vf[t][db] = ldsv(tV + foff[t] + db * 4096);
   }
   __builtin_amdgcn_sched_barrier(0);
+  if constexpr (TL) {
+    ts[3] = tl_now();  // S MFMAs and V^T reads issued
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  if constexpr (LZ) {
+    if (MASK) {
+#pragma unroll
+      for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+          if (kb * 32 + 16 * (r >> 3) + (r & 7) > qrel - 8 * hi) sacc[kb][r] = -INFINITY;  // (see below)
+    }
+    bf16x8 pf[4];
+    float ps;
+    auto probabilities = [&]() {  // P against the current m -> packed fragments + this lane's partial row sum; sacc untouched
+      float ps0 = 0.f, ps1 = 0.f;
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        union {
+          bf16x8 v;
+          bf16x2 h[4];
+        } u;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const float p0 = fast_exp2(__builtin_fmaf(sacc[t >> 1][8 * (t & 1) + 2 * i], sc, -m));
+          const float p1 = fast_exp2(__builtin_fmaf(sacc[t >> 1][8 * (t & 1) + 2 * i + 1], sc, -m));
+          ps0 += p0;
+          ps1 += p1;
+          u.h[i] = __builtin_convertvector(f32x2{p0, p1}, bf16x2);
+        }
+        pf[t] = u.v;
+      }
+      ps = ps0 + ps1;
+    };
+    probabilities();
+    if (__builtin_expect(__any(!(ps <= LZ_BOUND)), 0)) {  // (wave-uniform; also the first tile of every row: m = -inf)
+      float mx = -INFINITY;
+#pragma unroll
+      for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) mx = fmaxf(mx, sacc[kb][r]);
+      mx = xhalf_max(mx) * sc;
+      if (mx > m + RESCALE_THR) {
+        const float mn = fmaxf(m, mx);
+        const float alpha = fast_exp2(m - mn);
+#pragma unroll
+        for (int db = 0; db < 2; ++db)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) oacc[db][r] *= alpha;
+        l *= alpha;
+        m = mn;
+      }
+      probabilities();
+    }
+    l += ps;
+    if constexpr (TL) {
+      __builtin_amdgcn_sched_barrier(0);
+      ts[4] = tl_now();  // softmax arithmetic issued
+    }
+    if (TR) {
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the transpose reads (asm: invisible to hipcc's counters)
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    if constexpr (TL) {
+      ts[5] = tl_now();  // V^T fragments landed
+      __builtin_amdgcn_sched_barrier(0);
+    }
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+      for (int db = 0; db < 2; ++db) oacc[db] = mfma32(TR ? join8(vr[t][db][0], vr[t][db][1]) : vf[t][db], pf[t], oacc[db]);
+    if constexpr (TL) {
+      __builtin_amdgcn_sched_barrier(0);
+      ts[6] = tl_now();  // P V MFMAs issued
+    }
+    return;
+  }
   float mx = -INFINITY;
 #pragma unroll
   for (int kb = 0; kb < 2; ++kb)
@@ -155,17 +250,32 @@ __device__ inline void fwd3_tile(const char* tK, const char* tV, const int (&tro
   bf16x8 pf[4];
 #pragma unroll
   for (int t = 0; t < 4; ++t) pf[t] = pack8_pk(sacc[t >> 1], 8 * (t & 1));
+  if constexpr (TL) {
+    __builtin_amdgcn_sched_barrier(0);
+    ts[4] = tl_now();  // softmax arithmetic issued
+  }
   if (TR) {
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the transpose reads (asm: invisible to hipcc's counters)
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  if constexpr (TL) {
+    ts[5] = tl_now();  // V^T fragments landed
     __builtin_amdgcn_sched_barrier(0);
   }
 #pragma unroll
   for (int t = 0; t < 4; ++t)
 #pragma unroll
     for (int db = 0; db < 2; ++db) oacc[db] = mfma32(TR ? join8(vr[t][db][0], vr[t][db][1]) : vf[t][db], pf[t], oacc[db]);
+  if constexpr (TL) {
+    __builtin_amdgcn_sched_barrier(0);
+    ts[6] = tl_now();  // P V MFMAs issued
+  }
 }
 
-template <int WPS, bool TR, int NS = 2 /* K/V stages in LDS: tile kt + NS - 1 is requested while tile kt is computed */>
+constexpr int TL_TILES = 32, TL_FIRST = 8, TL_STAMPS = 9;  // timeline build: tiles TL_FIRST .. +31 of a workgroup's loop, 9 stamps each
+constexpr int TL_BYTES = 4 * TL_TILES * TL_STAMPS * 4;       // 4 waves x 32-bit stamps = 4608 bytes behind the stages (still 3 workgroups per CU)
+template <int WPS, bool TR, int NS = 2 /* K/V stages in LDS: tile kt + NS - 1 is requested while tile kt is computed */, bool LZ = false,
+          bool TL = false /* timeline build: `vt` is the uint32 output [16 workgroups][4 waves][TL_TILES][TL_STAMPS] */>
 __global__ __launch_bounds__(256, WPS) void attn_fwd3_kernel(const bf16* __restrict__ qkv, const bf16* __restrict__ vt,
                                                           bf16* __restrict__ o, float* __restrict__ lse, int S, int Sp, int H,
                                                           float sc /* scale*log2(e) */, int BH, int nqt,
@@ -187,7 +297,18 @@ __global__ __launch_bounds__(256, WPS) void attn_fwd3_kernel(const bf16* __restr
   const int qld = (qrow < S) ? qrow : S - 1;
 
   const bf16* kbase = qkv + b * S * D3 + D + (int64_t)h * HD;
-  const bf16* vtbase = TR ? kbase + D : vt + bh * HD * Sp;  // (TR: V row-major, straight out of the fused qkv rows)
+  const bf16* vtbase = (TR || TL) ? kbase + D : vt + bh * HD * Sp;  // (TR: V row-major, straight out of the fused qkv rows)
+  uint64_t ts[TL_STAMPS];
+  uint32_t* tl_lds = reinterpret_cast<uint32_t*>(smem + NS * 2 * TILE64) + wave * TL_TILES * TL_STAMPS;
+  auto tl_flush = [&](int kt) {  // (TL) the tile's stamps -> LDS, low words
+    if constexpr (TL) {
+      asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(ts[0]), "+s"(ts[1]), "+s"(ts[2]), "+s"(ts[3]), "+s"(ts[4]), "+s"(ts[5]), "+s"(ts[6]), "+s"(ts[7]), "+s"(ts[8])::"memory");
+      if (kt >= TL_FIRST && kt < TL_FIRST + TL_TILES && lane == 0) {
+#pragma unroll
+        for (int i = 0; i < TL_STAMPS; ++i) tl_lds[(kt - TL_FIRST) * TL_STAMPS + i] = (uint32_t)ts[i];
+      }
+    }
+  };
 
   bf16x8 qf[4];
   {
@@ -245,22 +366,45 @@ __global__ __launch_bounds__(256, WPS) void attn_fwd3_kernel(const bf16* __restr
     cb = (cb + 1 == NS) ? 0 : cb + 1;
   };
   int kt = 0;
+  if constexpr (TL) {
+#pragma unroll
+    for (int i = 0; i < TL_STAMPS; ++i) ts[i] = 0;
+  }
   for (; kt < n_full; ++kt) {
+    if constexpr (TL) ts[0] = tl_now();  // top of the tile
     stage_next(kt);
+    if constexpr (TL) ts[1] = tl_now();  // LDS-DMA requests issued
     const char* cur = smem + cb * 2 * TILE64;
-    fwd3_tile<false, TR>(cur, cur + TILE64, trof, foff, qf, oacc, m, l, hi, 0, sc);
-    advance(kt);
+    fwd3_tile<false, TR, LZ, TL>(cur, cur + TILE64, trof, foff, qf, oacc, m, l, hi, 0, sc, ts);
+    if constexpr (TL) {
+      wait_next(kt);
+      ts[7] = tl_now();  // the next tile's requests have landed (this wave's)
+      __syncthreads();
+      ts[8] = tl_now();  // barrier passed
+      cb = (cb + 1 == NS) ? 0 : cb + 1;
+      tl_flush(kt);
+    } else {
+      advance(kt);
+    }
   }
   if (kt <= kt_last) {
     stage_next(kt);
     const char* cur = smem + cb * 2 * TILE64;
-    fwd3_tile<true, TR>(cur, cur + TILE64, trof, foff, qf, oacc, m, l, hi, qrow - kt * 64, sc);
+    fwd3_tile<true, TR, LZ>(cur, cur + TILE64, trof, foff, qf, oacc, m, l, hi, qrow - kt * 64, sc);
     advance(kt);
     ++kt;
   }
   for (; kt <= kt_last; ++kt) {
     stage_next(kt);
     advance(kt);
+  }
+  if constexpr (TL) {  // workgroups 0, 8, .. 120 (the first sixteen of XCD 0: the heaviest query tiles of head 0) hand their stamps out
+    __syncthreads();
+    if ((blockIdx.x & 7) == 0 && (blockIdx.x >> 3) < 16) {
+      uint32_t* out = reinterpret_cast<uint32_t*>(const_cast<bf16*>(vt)) + (blockIdx.x >> 3) * (TL_BYTES / 4);
+      const uint32_t* src = reinterpret_cast<const uint32_t*>(smem + NS * 2 * TILE64);
+      for (int i = tid; i < TL_BYTES / 4; i += 256) out[i] = src[i];
+    }
   }
   const float lt = l + __shfl_xor(l, 32, 64);
   if (qrow < S) {
@@ -742,27 +886,60 @@ int mh_attn_fwd_mfma3(const void* qkv, const void* vt, void* o, float* lse, int6
   const int nt_all = (int)((S + 127) / 128), BH = (int)(B * H);
   const int nt = nt_all - (int)(q_start / 128);  // query tiles holding rows >= q_start (the first of them may start below it)
   const unsigned grid = (unsigned)(nt * 8 * ((BH + 7) / 8));
-#define MH_FWD(WPS, TR_)                                                                                                    \
-  attn_fwd3_kernel<WPS, TR_><<<grid, 256, 4 * TILE64, st>>>((const bf16*)qkv, (const bf16*)vt, (bf16*)o, lse, (int)S, (int)Sp, H, \
-                                                          scale * LOG2E, BH, nt, nt_all)
-#define MH_FWD3S(WPS, TR_)                                                                                                  \
-  attn_fwd3_kernel<WPS, TR_, 3><<<grid, 256, 6 * TILE64, st>>>((const bf16*)qkv, (const bf16*)vt, (bf16*)o, lse, (int)S, (int)Sp, \
-                                                             H, scale * LOG2E, BH, nt, nt_all)
+#define MH_FWD(WPS, TR_, LZ_)                                                                                                    \
+  attn_fwd3_kernel<WPS, TR_, 2, LZ_><<<grid, 256, 4 * TILE64, st>>>((const bf16*)qkv, (const bf16*)vt, (bf16*)o, lse, (int)S, (int)Sp, H, \
+                                                                 scale * LOG2E, BH, nt, nt_all)
+#define MH_FWD3S(WPS, TR_, LZ_)                                                                                                  \
+  attn_fwd3_kernel<WPS, TR_, 3, LZ_><<<grid, 256, 6 * TILE64, st>>>((const bf16*)qkv, (const bf16*)vt, (bf16*)o, lse, (int)S, (int)Sp, \
+                                                                  H, scale * LOG2E, BH, nt, nt_all)
   const bool tr = (vt == nullptr);  // no prepared V^T copy: transpose reads
+  const bool lz = (g_attn_v3 & 128) != 0;  // lazy reference maximum (fwd3_tile)
   // (register budget: with transpose reads the 256-register build measured 1-2 % ahead, with the prepared copy the
   //  168-register one; both fit three waves per SIMD -- profiles/r02_run18_attn_forms_ab.txt)
-  if (tr && (g_attn_v3 & 64)) {  // three stages: -3 % at S = 2048, -1...-3 % at 4096 (profiles/r02_run22_*); the same in the
+  if (tr && g_attn_v3_wps == 4) {  // A/B: 128 registers, two stages (32 KiB): four workgroups per CU
+    if (lz) MH_FWD(4, true, true); else MH_FWD(4, true, false);
+  } else if (tr && (g_attn_v3 & 64)) {  // three stages: -3 % at S = 2048, -1...-3 % at 4096 (profiles/r02_run22_*); the same in the
                                  // backward pair measured +1.5 % (their tiles are twice as long) and is not built
-    if (g_attn_v3_wps == 3) MH_FWD3S(3, true); else MH_FWD3S(2, true);
+    if (lz) {
+      if (g_attn_v3_wps == 3) MH_FWD3S(3, true, true); else MH_FWD3S(2, true, true);
+    } else {
+      if (g_attn_v3_wps == 3) MH_FWD3S(3, true, false); else MH_FWD3S(2, true, false);
+    }
   } else if (tr) {
-    if (g_attn_v3_wps == 3) MH_FWD(3, true); else MH_FWD(2, true);
+    if (g_attn_v3_wps == 3) MH_FWD(3, true, false); else MH_FWD(2, true, false);
   } else {
-    if (g_attn_v3_wps == 2) MH_FWD(2, false); else MH_FWD(3, false);
+    if (g_attn_v3_wps == 2) MH_FWD(2, false, false); else MH_FWD(3, false, false);
   }
 #undef MH_FWD
 #undef MH_FWD3S
   MH_LAUNCH_CHECK();
   return MH_OK;
+}
+
+// A/B library only: the production forward (three stages, transpose reads; lazy = the r06 lazy reference maximum) with s_memtime
+// stamps at the seams of every tile's segments; `stamps` receives uint32 [16 workgroups][4 waves][32 tiles][9]: low words of the
+// shader clock at: top of the tile, LDS-DMA issued, K reads issued, S MFMAs + V^T reads issued, softmax issued, V^T landed,
+// P V MFMAs issued, next tile landed (vmcnt), barrier passed -- for tiles 8 .. 39 of the workgroups' loops (tools/attn_timeline.py).
+extern "C" int mh_attn_fwd_timeline(const void* qkv, void* o, float* lse, int64_t B, int64_t S, int H, float scale, int lazy,
+                                    uint32_t* stamps, void* stream) {
+#ifdef MH_AB_BUILDS
+  MH_REQUIRE(stamps != nullptr && S >= 128 && S * 3 * H * HD < (int64_t(1) << 31), "attn_fwd_timeline: bad arguments");
+  hipStream_t st = (hipStream_t)stream;
+  const int64_t Sp = (S + 63) / 64 * 64;
+  const int nt_all = (int)((S + 127) / 128), BH = (int)(B * H), nt = nt_all;
+  const unsigned grid = (unsigned)(nt * 8 * ((BH + 7) / 8));
+  if (lazy)
+    attn_fwd3_kernel<2, true, 3, true, true><<<grid, 256, 6 * TILE64 + TL_BYTES, st>>>((const bf16*)qkv, (const bf16*)stamps, (bf16*)o, lse, (int)S,
+                                                                                   (int)Sp, H, scale * LOG2E, BH, nt, nt_all);
+  else
+    attn_fwd3_kernel<2, true, 3, false, true><<<grid, 256, 6 * TILE64 + TL_BYTES, st>>>((const bf16*)qkv, (const bf16*)stamps, (bf16*)o, lse, (int)S,
+                                                                                    (int)Sp, H, scale * LOG2E, BH, nt, nt_all);
+  MH_LAUNCH_CHECK();
+  return MH_OK;
+#else
+  mh_set_error("attn_fwd_timeline: only in the A/B library (libmidihip_ab.so)");
+  return MH_ERR_UNSUPPORTED;
+#endif
 }
 
 int mh_attn_bwd_mfma3(const void* qkv, const void* dout, const float* lse, const float* delta, const void* qt, const void* kt,

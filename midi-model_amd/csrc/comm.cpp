@@ -209,12 +209,14 @@ extern "C" int mh_comm_broadcast(void* comm, void* buf, int64_t count, int dtype
 }
 
 extern "C" int mh_comm_destroy(void* comm) {
-  Comm* c = as_comm(comm);
-  MH_REQUIRE(c != nullptr, "comm_destroy: not a (live) communicator handle");
+  // the membership test and the removal are ONE critical section: of two threads destroying the same handle exactly one gets it
+  // (a collective racing a destroy on another thread is still the caller's bug, as with ncclCommDestroy itself)
+  Comm* c = nullptr;
   {
     std::lock_guard<std::mutex> lk(g_live_mu);
-    g_live.erase(comm);
+    if (comm != nullptr && g_live.erase(comm) == 1) c = static_cast<Comm*>(comm);
   }
+  MH_REQUIRE(c != nullptr && c->magic == MAGIC, "comm_destroy: not a (live) communicator handle");
   if (c->have_mean) {
     g_api.RedOpDestroy(c->mean_bf16, c->comm);
     g_api.RedOpDestroy(c->mean_f32, c->comm);

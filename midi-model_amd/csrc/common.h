@@ -68,6 +68,42 @@ __device__ inline float mh_sigmoid(float g) {
 }
 __device__ inline float mh_silu(float g) { return g * mh_sigmoid(g); }
 
+// eight at a time, in two-element vectors: the multiplies and the addition become v_pk_mul_f32 / v_pk_add_f32 (one issue slot
+// for two elements; hipcc does not pack the scalar spelling across the transcendentals).  IEEE operations either way: the
+// same bits as mh_silu.  For the VALU-bound epilogues of the projection GEMMs (no MFMA runs beside them).
+typedef __attribute__((ext_vector_type(2))) float mh_f32x2;
+__device__ inline void mh_silu8(const float (&g)[8], float (&s)[8]) {
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const mh_f32x2 gv = {g[2 * i], g[2 * i + 1]};
+    const mh_f32x2 x = gv * -1.4426950408889634f;
+    const mh_f32x2 d = mh_f32x2{__builtin_amdgcn_exp2f(x[0]), __builtin_amdgcn_exp2f(x[1])} + 1.f;
+    const mh_f32x2 o = gv * mh_f32x2{__builtin_amdgcn_rcpf(d[0]), __builtin_amdgcn_rcpf(d[1])};
+    s[2 * i] = o[0];
+    s[2 * i + 1] = o[1];
+  }
+}
+
+// SwiGLU backward of eight elements, the expressions of swiglu_bwd_kernel (elementwise.hip) on two-element vectors:
+// dg = dv u (sig (1 + g (1 - sig))), du = dv (g sig).  The same IEEE operations in the same order (the contraction
+// 1 + g (1 - sig) -> fma is taken by both spellings), 14 issue slots per pair of elements instead of 23.
+__device__ inline void mh_dswiglu8(const float (&dv)[8], const float (&g)[8], const float (&u)[8], float (&dg)[8], float (&du)[8]) {
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const mh_f32x2 gv = {g[2 * i], g[2 * i + 1]}, uv = {u[2 * i], u[2 * i + 1]}, dvv = {dv[2 * i], dv[2 * i + 1]};
+    const mh_f32x2 x = gv * -1.4426950408889634f;
+    const mh_f32x2 d = 1.f + mh_f32x2{__builtin_amdgcn_exp2f(x[0]), __builtin_amdgcn_exp2f(x[1])};
+    const mh_f32x2 sig = {__builtin_amdgcn_rcpf(d[0]), __builtin_amdgcn_rcpf(d[1])};
+    const mh_f32x2 silu = gv * sig;
+    const mh_f32x2 og = dvv * uv * (sig * (1.f + gv * (1.f - sig)));
+    const mh_f32x2 ou = dvv * silu;
+    dg[2 * i] = og[0];
+    dg[2 * i + 1] = og[1];
+    du[2 * i] = ou[0];
+    du[2 * i + 1] = ou[1];
+  }
+}
+
 // eight fp32 -> one bf16x8 as four two-element conversions (v_cvt_pk_bf16_f32 each), and back (shift / mask)
 typedef __attribute__((ext_vector_type(2))) float f32x2;
 typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;

@@ -541,7 +541,7 @@ extern "C" int mh_row_rstd(const void* x, int64_t ldx, const float* parts, int n
                            int dtype, void* stream) {
   MH_REQUIRE(M > 0 && D > 0 && rstd != nullptr && ((x != nullptr) != (parts != nullptr)), "row_rstd: give x OR parts (M=%ld D=%d)", (long)M, D);
   if (parts != nullptr) {
-    MH_REQUIRE(nparts > 0, "row_rstd: nparts = %d", nparts);
+    MH_REQUIRE(nparts > 0 && (int64_t)nparts * 64 == D, "row_rstd: nparts = %d must be D / 64 (D = %d): one sum of squares per 64 columns", nparts, D);
     rstd_from_parts_kernel<<<(unsigned)((M + 63) / 64), 256, 0, (hipStream_t)stream>>>(parts, nparts, M, 1.0f / (float)D, eps, rstd);
   } else {
     MH_REQUIRE(D % 8 == 0 && ldx % 8 == 0 && ldx >= D && ((uintptr_t)x & 15) == 0, "row_rstd: rows must be 16-byte aligned");

@@ -102,6 +102,38 @@ __device__ inline bf16x8 frag(const char* tile, int row0, int fi, int fg) {
   }
 }
 
+// ---- epilogue helpers (r06) ---------------------------------------------------------------------------------------------
+// Output rows are addressed as  wave-uniform tile base (a buffer descriptor) + a per-lane 32-bit byte offset computed ONCE +
+// a scalar byte offset per store: no 64-bit VALU address arithmetic, no per-row compare -- rows past M fall outside the
+// descriptor's range and the hardware drops their stores (the epilogues used to spend 2-4 VALU per output element on
+// `m * ld + n`, its 64-bit compare against M and, in the RoPE epilogue, a 64-bit `m % S` per row).
+typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
+// (base and size are wave-uniform by construction -- kernel arguments, blockIdx and the wave id; the readfirstlane makes that
+//  provable, or hipcc wraps every buffer access in a waterfall loop: cdna_hip_programming.md T20)
+__device__ inline __amdgpu_buffer_rsrc_t tile_rsrc(const void* base, int64_t bytes) {
+  const unsigned n = bytes <= 0 ? 0u : (bytes > 0xfffffff0ll ? 0xfffffff0u : (unsigned)bytes);
+  const uint64_t b = (uint64_t)(uintptr_t)base;
+  const uint64_t bu = (uint64_t)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)b) |
+                      ((uint64_t)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(b >> 32)) << 32);
+  return __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<void*>((uintptr_t)bu), 0, (unsigned)__builtin_amdgcn_readfirstlane((int)n), 0x00020000);
+}
+__device__ inline u32x4 as_u32x4(const bf16x8& v) {
+  union {
+    bf16x8 b;
+    u32x4 u;
+  } x;
+  x.b = v;
+  return x.u;
+}
+__device__ inline bf16x8 as_bf16x8(const u32x4& v) {
+  union {
+    bf16x8 b;
+    u32x4 u;
+  } x;
+  x.u = v;
+  return x.b;
+}
+
 // ---- second main loop (r03): K-step 64, whole-line LDS-DMA, two phases per K-tile -------------------------------------
 // What r01/r02 measured on the loop below (profiles/r01_run5_gemm_pp256_ablation.txt): the complete kernel runs at the rate of
 // its LDS-DMA alone (0.90 us per 32-deep step against 0.65 us for the MFMAs alone), and that rate is set by the number of
@@ -201,7 +233,14 @@ __device__ __forceinline__ void p8_main_loop(char* smem, const bf16* __restrict_
       klb[0][it] = (r < N) ? (int)kend - krow : INT_MIN;        // (k0 + krow < kend)
       klb[1][it] = (r < N) ? (int)kend - krow - 32 : INT_MIN;   // second K-half: k0 + 32 + krow < kend
     } else {
-      const int64_t rb = (EPI == 2) ? n0 + lr : n0 + (lr >> 5) * 64 + (lr & 31);                // + N/2 or + 32 for h = 1
+      // EPI 2 / 3 (r06): the 32 columns of a wave's region half are staged PERMUTED -- LDS row n2*16 + j takes column
+      // (j >> 2) * 8 + n2 * 4 + (j & 3) -- so that the two fragments n2 = 0, 1 of a lane (MFMA rows j = 4 fg + e) are the EIGHT
+      // CONSECUTIVE columns 8 fg .. 8 fg + 7: the SwiGLU / RoPE epilogues then work on whole 16-byte pieces in registers (gate and up,
+      // a column and its rotation partner are the same lane's) and turn bf16 results through LDS.  Free: the permutation only
+      // changes which 128-byte line of W a group of eight lanes requests; the fragment reads are the same conflict-free pattern.
+      constexpr bool PERM = (EPI == 2 || EPI == 3);
+      const int lrp = PERM ? ((lr & ~31) | (((lr & 15) >> 2) << 3) | (((lr >> 4) & 1) << 2) | (lr & 3)) : lr;
+      const int64_t rb = (EPI == 2) ? n0 + lrp : n0 + (lrp >> 5) * 64 + (lrp & 31);              // + N/2 or + 32 for h = 1
       const int64_t rb1 = (EPI == 2) ? rb + N / 2 : rb + 32;
       pb[it] = B + (rb < N ? rb : 0) * ldb + ch * 8;
       klb[0][it] = (rb < N) ? (int)kend - ch * 8 : INT_MIN;
@@ -570,6 +609,57 @@ __global__ __launch_bounds__(512, 2) void gemm_pp256_kernel(const bf16* __restri
   // is already half lines; turning them through LDS measured 5 % slower inside the training step).
   // Rounding the tile to bf16 before the turn (half the LDS traffic when there is no residual) measured no faster.
   if constexpr (EPI == 1) {
+    if (m0 + QBM <= M && n0 + QBN <= N && ldc < (1 << 22) && ldr < (1 << 22)) {
+      // r06: interior tile -- the form below with descriptor addressing (tile_rsrc: no 64-bit address arithmetic or bounds
+      // tests per line) and the SwiGLU derivative on two-element vectors (mh_dswiglu8: the epilogue is VALU-bound, ~1900
+      // instructions per wave before).  Same operations, same roundings.
+      char* wreg = smem + wave * 16384;
+      const int lrow = lane >> 3, c = lane & 7;
+      const __amdgpu_buffer_rsrc_t rg = tile_rsrc(R + m0 * ldr + n0 + wn * 64, (255 * ldr + N + 64) * 2);
+      const __amdgpu_buffer_rsrc_t rc = tile_rsrc(C + m0 * ldc + n0 + wn * 64, (255 * ldc + N + 64) * 2);
+      const unsigned vo_r = (unsigned)(((grp * 128 + lrow) * (int)ldr + c * 8) * 2), so_r = (unsigned)ldr * 16u;  // + 8 rows per step
+      const unsigned vo_c = (unsigned)(((grp * 128 + lrow) * (int)ldc + c * 8) * 2), so_c = (unsigned)ldc * 16u;
+      const unsigned up_off = (unsigned)N * 2u;  // the up / d up half of a row
+      // gate / up lines: the first half's are requested before its turn, the second half's in two groups of four as the first
+      // half's lines leave their registers (all sixteen at once, as the general form does, spills beside the fast path's code)
+      bf16x8 gq[2][8], uq[2][8];
+      auto request = [&](int half, int i0) {
+#pragma unroll
+        for (int i = i0; i < i0 + 4; ++i) {
+          gq[half][i] = as_bf16x8(__builtin_amdgcn_raw_buffer_load_b128(rg, vo_r, (unsigned)(half * 8 + i) * so_r, 0));
+          uq[half][i] = as_bf16x8(__builtin_amdgcn_raw_buffer_load_b128(rg, vo_r, (unsigned)(half * 8 + i) * so_r + up_off, 0));
+        }
+      };
+      request(0, 0);
+      request(0, 4);
+#pragma unroll
+      for (int half = 0; half < 2; ++half) {
+#pragma unroll
+        for (int fmh = 0; fmh < 4; ++fmh)
+#pragma unroll
+          for (int fn = 0; fn < 4; ++fn) {
+            const int row = fmh * 16 + fi, ch = fn * 4 + fg;
+            *reinterpret_cast<f32x4*>(wreg + row * 256 + ((ch ^ (row & 15)) << 4)) = acc[fn][half * 4 + fmh];
+          }
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          if (half == 0 && (i == 2 || i == 6)) request(1, i == 2 ? 0 : 4);
+          const int row = i * 8 + lrow;
+          const f32x4 lo = *reinterpret_cast<const f32x4*>(wreg + row * 256 + (((2 * c) ^ (row & 15)) << 4));
+          const f32x4 hi = *reinterpret_cast<const f32x4*>(wreg + row * 256 + (((2 * c + 1) ^ (row & 15)) << 4));
+          const float v[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+          float dv[8], g[8], u[8], dg[8], du[8];
+          expand8_bf16(cvt8_bf16(v), dv);  // d a rounded to bf16 first, as the unfused pair of launches stores it
+          expand8_bf16(gq[half][i], g);
+          expand8_bf16(uq[half][i], u);
+          mh_dswiglu8(dv, g, u, dg, du);
+          const unsigned so = (unsigned)(half * 8 + i) * so_c;
+          __builtin_amdgcn_raw_buffer_store_b128(as_u32x4(cvt8_bf16(dg)), rc, vo_c, so, 2 /* nt */);
+          __builtin_amdgcn_raw_buffer_store_b128(as_u32x4(cvt8_bf16(du)), rc, vo_c, so + up_off, 2);
+        }
+      }
+      return;
+    }
     // SwiGLU backward as the epilogue of down_proj's dgrad (mh_gemm_dswiglu): the tile is d a = dx * Wd (M x I); R holds
     // gate|up of the forward ([M, 2 I]) and C receives d gate | d up.  Same whole-line turn through LDS; the gate and up
     // lines of a 64-row half are requested before its turn.  d a is rounded to bf16 first, as the unfused pair of
@@ -633,6 +723,76 @@ __global__ __launch_bounds__(512, 2) void gemm_pp256_kernel(const bf16* __restri
     }
     return;
   }
+  if constexpr (EPI == 2 && ML == 1) {
+    // r06 form (the K-step-64 loop stages W's rows permuted: see p8_main_loop).  Lane (fi, fg) holds, for each of its eight rows
+    // fm*16 + fi, gate columns 8 fg .. 8 fg + 7 of the wave's 32 in acc[0][fm] | acc[1][fm] and the matching up columns in
+    // acc[2][fm] | acc[3][fm]: the whole SwiGLU chain (LlamaMLP.forward, modeling_llama.py:174-176; roundings as mh_swiglu_fwd)
+    // runs in registers and only bf16 results are turned through the wave's LDS region into whole 64-byte row pieces -- a
+    // quarter of the LDS traffic of the fp32 turn, one 16-byte write per 8 outputs, no address arithmetic per store.
+    char* wreg = smem + wave * 16384;
+    const int64_t I = N >> 1, colw = n0 + wn * 32;
+    bf16* act = const_cast<bf16*>(R);
+    const int64_t rows_left = (M - m0 < QBM) ? M - m0 : QBM;
+    const __amdgpu_buffer_rsrc_t ra = tile_rsrc(act + m0 * ldr + colw, ((rows_left - 1) * ldr + 32) * 2);
+    const __amdgpu_buffer_rsrc_t rc = tile_rsrc(C != nullptr ? C + m0 * ldc + colw : nullptr, C != nullptr ? ((rows_left - 1) * ldc + I + 32) * 2 : 0);
+    const int r4 = lane >> 2, c4 = lane & 3;
+    const unsigned vo_a = (unsigned)(((grp * 128 + r4) * (int)ldr + c4 * 8) * 2), so_a = (unsigned)ldr * 32u;   // + 16 rows per step
+    const unsigned vo_c = (unsigned)(((grp * 128 + r4) * (int)ldc + c4 * 8) * 2), so_c = (unsigned)ldc * 32u;
+    const bool keep = (C != nullptr);  // (gate|up is read again by the backward only)
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+#pragma unroll
+      for (int fmh = 0; fmh < 4; ++fmh) {
+        const int fm = half * 4 + fmh;
+        float gf[8], uf[8];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          gf[e] = acc[0][fm][e];
+          gf[4 + e] = acc[1][fm][e];
+          uf[e] = acc[2][fm][e];
+          uf[4 + e] = acc[3][fm][e];
+        }
+        if constexpr (NRM == 2) {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            gf[e] *= rs[fm];
+            uf[e] *= rs[fm];
+          }
+        }
+        const bf16x8 og = cvt8_bf16(gf), ou = cvt8_bf16(uf);
+        float gr[8], ur[8], sv[8], sr[8], av[8];
+        expand8_bf16(og, gr);
+        expand8_bf16(ou, ur);
+        mh_silu8(gr, sv);
+        expand8_bf16(cvt8_bf16(sv), sr);  // round(silu(gate)), modeling_llama.py:174-176 in bf16
+#pragma unroll
+        for (int e = 0; e < 8; ++e) av[e] = sr[e] * ur[e];
+        const bf16x8 oa = cvt8_bf16(av);
+        // row r of the 64-row half: 64 bytes; 16-byte chunk c at slot c ^ ((r >> 1) & 3) (8 lanes of a write = 8 rows, one
+        // chunk: distinct 16-byte slots of a 128-byte bank row)
+        const int row = fmh * 16 + fi, off = row * 64 + ((fg ^ ((row >> 1) & 3)) << 4);
+        *reinterpret_cast<bf16x8*>(wreg + off) = oa;
+        if (keep) {
+          *reinterpret_cast<bf16x8*>(wreg + 4096 + off) = og;
+          *reinterpret_cast<bf16x8*>(wreg + 8192 + off) = ou;
+        }
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {  // 16 rows x 64 B per instruction
+        const int row = i * 16 + r4, off = row * 64 + ((c4 ^ ((row >> 1) & 3)) << 4);
+        const unsigned so = (unsigned)(half * 4 + i);
+        const u32x4 va = *reinterpret_cast<const u32x4*>(wreg + off);
+        __builtin_amdgcn_raw_buffer_store_b128(va, ra, vo_a, so * so_a, 0);
+        if (keep) {
+          const u32x4 vg = *reinterpret_cast<const u32x4*>(wreg + 4096 + off);
+          const u32x4 vu = *reinterpret_cast<const u32x4*>(wreg + 8192 + off);
+          __builtin_amdgcn_raw_buffer_store_b128(vg, rc, vo_c, so * so_c, 0);
+          __builtin_amdgcn_raw_buffer_store_b128(vu, rc, vo_c, so * so_c + (unsigned)I * 2u, 0);
+        }
+      }
+    }
+    return;
+  }
   if constexpr (EPI == 2) {
     // C = gate|up [M, 2 I] (kept for the backward), R = the activation a = round(silu(gate)) * up [M, I] (written here:
     // LlamaMLP.forward, modeling_llama.py:174-176, roundings as mh_swiglu_fwd).  The wave's 64 fp32 columns are 32 gate +
@@ -681,6 +841,85 @@ __global__ __launch_bounds__(512, 2) void gemm_pp256_kernel(const bf16* __restri
         }
         *reinterpret_cast<bf16x8*>(act + m * ldr + col) = oa;
       }
+    }
+    return;
+  }
+  if constexpr (EPI == 3 && ML == 1) {
+    // r06 form (W's rows staged permuted: p8_main_loop).  A wave's 64 columns are ONE head; lane (fi, fg) holds, for each of its
+    // eight rows, columns 8 fg .. 8 fg + 7 of the head's first half in acc[0][fm] | acc[1][fm] and their rotation partners
+    // (+ 32) in acc[2][fm] | acc[3][fm]: the projection is rounded to bf16 (as the unfused pair mh_gemm, mh_rope stores it in
+    // between) and rotated in registers with the SAME products and the same fma as before (apply_rotary_pos_emb,
+    // modeling_llama.py:151-169; table [pos][cos | -sin | +sin] in bf16, :126), then the bf16 rows are turned through LDS into
+    // whole 128-byte lines.  Position of row m: pos0 + m % S, kept as a 32-bit running value (16 rows per step).
+    const int64_t nw = n0 + wn * 64;
+    if (nw >= N) return;  // (N % 64 == 0: a wave's head exists or not; no barrier follows)
+    char* wreg = smem + wave * 16384;
+    const bool rot = nw < 2 * (N / 3);  // (wave-uniform; the v heads take the plain path)
+    const bf16* tab = R;
+    const unsigned S_ = (unsigned)(ldr & 0xffffffff), pos0 = (unsigned)(ldr >> 32);
+    const unsigned mrow = (unsigned)m0 + (unsigned)(grp * 128 + fi), Mu = (unsigned)M;  // (M < 2^31 - 256: launcher)
+    const unsigned p0 = mrow % S_;
+    bf16x8 cq[8], s1q[8], s2q[8];
+    if (rot) {
+#pragma unroll
+      for (int fm = 0; fm < 8; ++fm) {
+        unsigned pf = p0 + 16u * fm;
+        if (S_ >= 128u) pf = (pf >= S_) ? pf - S_ : pf;
+        else pf %= S_;
+        const unsigned pidx = (mrow + 16u * fm < Mu) ? pos0 + pf : pos0;  // (rows past M are never stored: any valid table row)
+        const bf16* t = tab + (size_t)pidx * 96 + fg * 8;
+        cq[fm] = *reinterpret_cast<const bf16x8*>(t);
+        s1q[fm] = *reinterpret_cast<const bf16x8*>(t + 32);
+        s2q[fm] = *reinterpret_cast<const bf16x8*>(t + 64);
+      }
+    }
+#pragma unroll
+    for (int fm = 0; fm < 8; ++fm) {
+      float x1[8], x2[8];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        x1[e] = acc[0][fm][e];
+        x1[4 + e] = acc[1][fm][e];
+        x2[e] = acc[2][fm][e];
+        x2[4 + e] = acc[3][fm][e];
+      }
+      if constexpr (NRM == 2) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          x1[e] *= rs[fm];
+          x2[e] *= rs[fm];
+        }
+      }
+      bf16x8 b1 = cvt8_bf16(x1), b2 = cvt8_bf16(x2);  // the projection as the unfused path stores it
+      if (rot) {
+        float v1[8], v2[8], cf[8], s1[8], s2[8], o1[8], o2[8];
+        expand8_bf16(b1, v1);
+        expand8_bf16(b2, v2);
+        expand8_bf16(cq[fm], cf);
+        expand8_bf16(s1q[fm], s1);
+        expand8_bf16(s2q[fm], s2);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          o1[e] = __builtin_fmaf(v1[e], cf[e], v2[e] * s1[e]);
+          o2[e] = __builtin_fmaf(v2[e], cf[e], v1[e] * s2[e]);
+        }
+        b1 = cvt8_bf16(o1);
+        b2 = cvt8_bf16(o2);
+      }
+      // row r of the wave's 128: 128 bytes, 16-byte chunk c at slot c ^ (r & 7) (8 lanes of a write = 8 rows, one chunk)
+      const int row = fm * 16 + fi;
+      *reinterpret_cast<bf16x8*>(wreg + row * 128 + ((fg ^ (row & 7)) << 4)) = b1;
+      *reinterpret_cast<bf16x8*>(wreg + row * 128 + (((4 + fg) ^ (row & 7)) << 4)) = b2;
+    }
+    const int64_t rows_left = (M - m0 < QBM) ? M - m0 : QBM;
+    const __amdgpu_buffer_rsrc_t rc = tile_rsrc(C + m0 * ldc + nw, ((rows_left - 1) * ldc + 64) * 2);
+    const int r8 = lane >> 3, c8 = lane & 7;
+    const unsigned vo = (unsigned)(((grp * 128 + r8) * (int)ldc + c8 * 8) * 2), so8 = (unsigned)ldc * 16u;  // + 8 rows per step
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {  // 8 rows x 128 B per instruction
+      const int row = i * 8 + r8;
+      const u32x4 v = *reinterpret_cast<const u32x4*>(wreg + row * 128 + ((c8 ^ (row & 7)) << 4));
+      __builtin_amdgcn_raw_buffer_store_b128(v, rc, vo, (unsigned)i * so8, 2 /* nt: C is not read again by this kernel */);
     }
     return;
   }
@@ -760,6 +999,76 @@ __global__ __launch_bounds__(512, 2) void gemm_pp256_kernel(const bf16* __restri
   const bool use_r = (R != nullptr && beta != 0.f);
   const bool line_ok = !partial && (ldc & 7) == 0 && ((uintptr_t)C & 15) == 0 &&
                        (!use_r || ((ldr & 7) == 0 && ((uintptr_t)R & 15) == 0));
+  if (line_ok && m0 + QBM <= M && n0 + QBN <= N && ldc < (1 << 22) && ldr < (1 << 22)) {
+    // r06: an INTERIOR tile (every tile of the benchmarked shapes but the ragged logits columns): the whole-line turn below with
+    // its addresses as descriptor + one per-lane offset + scalar offsets (tile_rsrc), no bounds tests.  Same arithmetic.
+    char* wreg = smem + wave * 16384;
+    const int lrow = lane >> 3, c = lane & 7;
+    const __amdgpu_buffer_rsrc_t rc = tile_rsrc(C + m0 * ldc + n0 + wn * 64, (255 * ldc + 64) * 2);
+    const __amdgpu_buffer_rsrc_t rr = tile_rsrc(use_r ? R + m0 * ldr + n0 + wn * 64 : nullptr, use_r ? (255 * ldr + 64) * 2 : 0);
+    const unsigned vo_c = (unsigned)(((grp * 128 + lrow) * (int)ldc + c * 8) * 2), so_c = (unsigned)ldc * 16u;  // + 8 rows per step
+    const unsigned vo_r = (unsigned)(((grp * 128 + lrow) * (int)ldr + c * 8) * 2), so_r = (unsigned)ldr * 16u;
+    float* auxp = nullptr;
+    if constexpr (NRM == 1) auxp = aux + ((n0 + wn * 64) >> 6) * M + m0 + grp * 128 + lrow;
+    // (one loop per residual choice: `use_r` comes out of a float compare, which hipcc evaluates on the VALU and then treats as
+    //  divergent -- an exec-mask branch around every store)
+    auto turn = [&](auto with_r) {
+    constexpr bool use_r = decltype(with_r)::value;
+    bf16x8 rv[2][8];
+    if (use_r) {
+#pragma unroll
+      for (int half = 0; half < 2; ++half)
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+          rv[half][i] = as_bf16x8(__builtin_amdgcn_raw_buffer_load_b128(rr, vo_r, (unsigned)(half * 8 + i) * so_r, 0));
+    }
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+#pragma unroll
+      for (int fmh = 0; fmh < 4; ++fmh)
+#pragma unroll
+        for (int fn = 0; fn < 4; ++fn) {
+          const int row = fmh * 16 + fi, ch = fn * 4 + fg;
+          *reinterpret_cast<f32x4*>(wreg + row * 256 + ((ch ^ (row & 15)) << 4)) = acc[fn][half * 4 + fmh];
+        }
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {  // 8 rows x 128 B per instruction
+        const int row = i * 8 + lrow;
+        const f32x4 lo = *reinterpret_cast<const f32x4*>(wreg + row * 256 + (((2 * c) ^ (row & 15)) << 4));
+        const f32x4 hi = *reinterpret_cast<const f32x4*>(wreg + row * 256 + (((2 * c + 1) ^ (row & 15)) << 4));
+        float v[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+        if (use_r) {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) v[e] = alpha * v[e] + beta * (float)rv[half][i][e];
+        } else {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) v[e] = alpha * v[e];
+        }
+        bf16x8 o;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o[e] = (bf16)v[e];
+        __builtin_amdgcn_raw_buffer_store_b128(as_u32x4(o), rc, vo_c, (unsigned)(half * 8 + i) * so_c, 2 /* nt */);
+        if constexpr (NRM == 1) {  // (see the general form below)
+          union {
+            bf16x8 v8;
+            bf16x2 h[4];
+          } u;
+          u.v8 = o;
+          float ss = 0.f;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) ss = __builtin_amdgcn_fdot2_f32_bf16(u.h[e], u.h[e], ss, false);
+          ss += dpp_move<0xB1>(ss);
+          ss += dpp_move<0x4E>(ss);
+          ss += dpp_move<0x141>(ss);
+          if (c == 0) auxp[half * 64 + i * 8] = ss;
+        }
+      }
+    }
+    };
+    if (__builtin_amdgcn_readfirstlane((int)use_r)) turn(std::true_type{});
+    else turn(std::false_type{});
+    return;
+  }
   if (line_ok) {
     char* wreg = smem + wave * 16384;
     const int lrow = lane >> 3, c = lane & 7;
@@ -985,6 +1294,7 @@ int mh_gemm_pp256_bf16(const void* A, int64_t lda, int ta, const void* B, int64_
 // (rowscale != NULL: every row of the product times rowscale[m] first -- the folded RMSNorm, NRM 2 above)
 int mh_gemm_pp256_swiglu_bf16(const void* A, int64_t lda, const void* W, int64_t ldw, void* GU, int64_t ldgu, void* ACT,
                               int64_t ldact, int64_t M, int64_t I, int64_t K, hipStream_t st, const float* rowscale) {
+  MH_REQUIRE(ldgu < (1 << 22) && ldact < (1 << 22), "gemm_swiglu: row strides beyond 2^22 elements are not supported (32-bit tile offsets)");
   if (rowscale != nullptr) {
     MH_REQUIRE(g_mh_gemm_k64 != 0 && M % 4 == 0, "gemm_swiglu: the row-scaled form needs the K-step-64 main loop and M %% 4 == 0");
     return launch_one<false, false, 0, 2, 1, 2>(A, lda, W, ldw, GU, ldgu, ACT, ldact, M, 2 * I, K, 1.f, 0.f, 1, nullptr, st,
@@ -997,6 +1307,7 @@ int mh_gemm_pp256_swiglu_bf16(const void* A, int64_t lda, const void* W, int64_t
 // [q | k | v] = A * W^T with the rotary embedding applied to the q and k heads in the epilogue; gemm.hip validates
 int mh_gemm_pp256_rope_bf16(const void* A, int64_t lda, const void* W, int64_t ldw, void* C, int64_t ldc, const void* table,
                             int64_t S, int64_t pos0, int64_t M, int64_t N, int64_t K, hipStream_t st, const float* rowscale) {
+  MH_REQUIRE(ldc < (1 << 22) && M < (int64_t(1) << 31) - 256, "gemm_rope: row stride beyond 2^22 elements / more than 2^31 rows are not supported (32-bit tile offsets and positions)");
   if (rowscale != nullptr) {
     MH_REQUIRE(g_mh_gemm_k64 != 0 && M % 4 == 0, "gemm_rope: the row-scaled form needs the K-step-64 main loop and M %% 4 == 0");
     return launch_one<false, false, 0, 3, 1, 2>(A, lda, W, ldw, C, ldc, table, S | (pos0 << 32), M, N, K, 1.f, 0.f, 1, nullptr, st,

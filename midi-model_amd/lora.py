@@ -81,6 +81,8 @@ class LoraAdapter:
             ops.gemm_nt(self.B[name], self.A[name], w, K=self.r, alpha=self.scale, beta=1.0,
                         res=self.base[off:off + o * i].view(o, i), tb=True)
         self.dirty = False
+        if hasattr(model, "weights_written"):
+            model.weights_written()  # (kernel writes into the flat buffer: derived data of the weights is stale)
 
     def compute_grads(self, model) -> None:
         """adapter gradients from the accumulated gradient of the effective weights"""

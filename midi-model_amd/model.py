@@ -109,6 +109,8 @@ class MIDIModel(nn.Module):
         self._ropes = {}
         self._tables = None
         self._sessions = _SessionPool()  # idle decode sessions (decode.py)
+        self._weights_epoch = 0          # bumped by every writer that bypasses torch's version counters (weights_written)
+        self._fold_cache = {}            # stack name -> (key, folded weights): folded_weights()
         self._reset_parameters()
         self._repack()
 
@@ -173,6 +175,36 @@ class MIDIModel(nn.Module):
         self._tables = None
         self._sessions = _SessionPool()  # idle decode sessions (decode.py)
         self._W = {k: self._stack_views(k, flat) for k in ("net", "net_token")}
+        self._fold_cache = {}
+        self._weights_epoch = getattr(self, "_weights_epoch", 0) + 1
+
+    # --------------------------------------------------------------------- derived data of the weights
+    def weights_written(self) -> None:
+        """Tell the model that its flat parameter buffer was written through a raw pointer (mh_adamw, a LoRA materialisation, a
+        broadcast): torch's version counters do not see those writes, the caches of data DERIVED from the weights
+        (folded_weights) are keyed on this epoch as well."""
+        self._weights_epoch += 1
+
+    def folded_weights(self, pre: str = "net"):
+        """engine.fold_norm_weights of stack ``pre`` -- [(wqkv * n1, wgu * n2) per layer], the weights the forward-only blocks with
+        folded RMSNorms multiply by (engine.layer_forward_folded) -- kept on the model and re-derived lazily, in place, when a
+        parameter changed: keyed on the parameters' version counters (every torch-side write: load_state_dict, an optimizer
+        from torch.optim, ``p.data.copy_``) and on the epoch raw-pointer writers bump (weights_written).  So the public
+        ``forward`` under no_grad reaches the folded blocks from 8192 rows up without paying the fold per call (~0.7 ms of
+        elementwise launches for tv2o-medium).  277 MB for tv2o-medium in bf16."""
+        st = getattr(self, pre)
+        versions = tuple(p._version for lyr in st.layers for p in lyr.parameters())
+        key = (self._weights_epoch, self._flat.data_ptr(), versions)
+        hit = self._fold_cache.get(pre)
+        if hit is not None and hit[0] == key:
+            return hit[1]
+        with self._sessions.lock:  # (app.py:496 runs up to ten generators on one model: one of them derives, the others wait)
+            hit = self._fold_cache.get(pre)
+            if hit is None or hit[0] != key:
+                with torch.no_grad():
+                    folded = engine.fold_norm_weights(self._W[pre], out=hit[1] if hit is not None else None)
+                self._fold_cache[pre] = hit = (key, folded)
+        return hit[1]
 
     def _apply(self, fn, recurse=True):
         out = super()._apply(fn, recurse)
@@ -317,7 +349,8 @@ class MIDIModel(nn.Module):
                 spec = self._specs["net"]
                 e = torch.empty((B * S, spec.D), dtype=self.dtype, device=self.device)
                 ops.embed_sum_fwd(x.view(B * S, T), self._W["net"].embed, e)
-                y, _ = engine.stack_forward(spec, self._W["net"], e, B, S, self.rope("net"), save=False)
+                y, _ = engine.stack_forward(spec, self._W["net"], e, B, S, self.rope("net"), save=False,
+                                            folded=self._folded_for(spec, e))
                 return y.view(B, S, spec.D)
             from .autograd import NetFn
             params = self._stack_params("net")
@@ -331,7 +364,7 @@ class MIDIModel(nn.Module):
                 if st is None:
                     st = KVState(spec, B, max(ops.round_up(S + 64, 64), 256), e)
                     cache._mh_state = st
-                y = engine.stack_prefill(spec, self._W["net"], e, B, S, self.rope("net"), st)
+                y = engine.stack_prefill(spec, self._W["net"], e, B, S, self.rope("net"), st, folded=self._folded_for(spec, e))
                 return y.view(B, S, spec.D)
             if st.B != B:
                 raise ValueError(f"cache was built for batch {st.B}, got {B}")
@@ -339,6 +372,12 @@ class MIDIModel(nn.Module):
                 return engine.stack_decode(spec, self._W["net"], e, self.rope("net"), st).view(B, 1, spec.D)
             # chunked continuation: the S new events attend to the cached ones and causally to each other
             return engine.stack_extend(spec, self._W["net"], e, B, S, self.rope("net"), st).view(B, S, spec.D)
+
+    def _folded_for(self, spec, e: torch.Tensor):
+        """the kept folded weights when a forward-only pass over ``e`` [rows, D] will run the folded-norm blocks, else None"""
+        if e.shape[0] >= engine.FOLD_MIN_ROWS_PREFOLDED and ops.norm_fold_ok(e, spec.D, spec.hd, spec.I):
+            return self.folded_weights(spec.name)
+        return None
 
     def forward_token(self, hidden_state=None, x=None, cache=None) -> torch.Tensor:
         """hidden_state (N, n_embd) and/or x (N, t) int64 -> logits (N, [1]+t, vocab)   [midi_model.py:116-135]"""

@@ -244,6 +244,7 @@ class TrainMIDIModel(MIDIModel):
                   self.weight_decay, bc1, bc2, coef)
         ops.adamw(flat[nm:], g[nm:], o["m"][nm:], o["v"][nm:], lr, self.betas[0], self.betas[1], self.eps, 0.0,
                   bc1, bc2, coef)
+        self.weights_written()  # (raw-pointer write: data derived from the weights -- MIDIModel.folded_weights -- is stale now)
         self.global_step += 1
         self._micro = 0
 
@@ -262,8 +263,7 @@ class TrainMIDIModel(MIDIModel):
         Lightning ``.ckpt``: ``state_dict``, ``global_step``, ``optimizer_states[0]`` = the ``torch.optim.AdamW.state_dict()`` of
         the reference's two parameter groups (per-parameter ``step`` / ``exp_avg`` / ``exp_avg_sq``), ``lr_schedulers[0]`` = the
         LambdaLR position (with the ``lr_lambdas`` / ``verbose`` / ``_get_lr_called_within_step`` keys
-        ``LambdaLR.load_state_dict`` expects) and the ``pytorch-lightning_version`` / ``loops`` / ``callbacks`` keys Lightning
-        looks up first.  Tested direction: a reference-layout checkpoint -> ``load_training_state`` and our own round trip, and
+        ``LambdaLR.load_state_dict`` expects) and the ``pytorch-lightning_version`` / ``callbacks`` keys (no ``loops``: see below).  Tested direction: a reference-layout checkpoint -> ``load_training_state`` and our own round trip, and
         the scheduler / optimizer dictionaries loaded into the real torch objects (tests/test_host_logic.py); Lightning itself is
         not installable here.  Ours on top: the accumulation phase (``mh_micro``) and, inside an accumulation window, the gradient
         accumulated so far."""
@@ -299,7 +299,9 @@ class TrainMIDIModel(MIDIModel):
                                "base_lrs": [self.lr, self.lr], "_last_lr": [lr_now, lr_now], "lr_lambdas": [None, None],
                                "verbose": False, "_get_lr_called_within_step": False}],
             "pytorch-lightning_version": "2.4.0",
-            "loops": {}, "callbacks": {},
+            # (no "loops" key: Lightning's restore_loops skips a checkpoint that has none, while an EMPTY dict would be indexed
+            #  with ["fit_loop"]; Lightning's own global_step then restarts at 0 -- ours and the scheduler's come from the keys above)
+            "callbacks": {},
             "hyper_parameters": dict(lr=self.lr, weight_decay=self.weight_decay, warmup=self.warmup, max_step=self.max_step),
             "mh_micro": int(self._micro),
         }
@@ -481,6 +483,7 @@ class TrainMIDIModel(MIDIModel):
         ops.adamw(lo.flat, lo.grad, o["m"], o["v"], lr, self.betas[0], self.betas[1], self.eps, self.weight_decay,
                   bc1, bc2, coef)
         lo.materialize(self)  # live weights follow the adapters at once: generate()/forward()/state_dict() right after a step
+        self.weights_written()
         self.global_step += 1
         self._micro = 0
 
@@ -693,3 +696,4 @@ class TrainMIDIModel(MIDIModel):
                 self.comm.broadcast_(self._flat, root=src)
         elif dist.is_available() and dist.is_initialized() and dist.get_world_size(self.process_group) > 1:
             dist.broadcast(self._flat, src=src, group=self.process_group)
+        self.weights_written()
