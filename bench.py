@@ -339,27 +339,82 @@ def measure_block(args, B: int, S: int, steps: int, warmup: int, dist=None):
     with torch.no_grad():
         x = torch.empty((B * S, spec.D), dtype=dtype, device="cuda")
         ops.embed_sum_fwd(ev.view(B * S, -1), W.embed, x)
-        x, _ = engine.layer_forward(spec, W.layers[0], x, B, S, rope)   # input of block 1: a real residual stream
         lw = W.layers[1]
-        # r05: the forward-only block as a prefill of this size runs it (engine.stack_forward, save=False): both RMSNorms folded
-        # around the projections.  The folded weight copies are derived data of static inference weights (made once, outside the
-        # timed loop, as a decode session keeps them); the row statistics of the block's input are those the previous block's down
-        # projection leaves behind.
+        # The forward-only block as MIDIModel.forward runs it under no_grad from 8192 rows up (r06: the folded weight copies are kept
+        # on the model, MIDIModel.folded_weights, re-derived only when a parameter changed): both RMSNorms folded around the
+        # projections (engine.layer_forward_folded).  Block 1 is timed on what block 0 of the same path hands it: the residual
+        # stream and its row statistics ([D / 64, M] partial sums of squares left by block 0's down projection).
         folded_form = (not args.block_save) and not args.block_unfolded and ops.norm_fold_ok(x, spec.D, spec.hd, spec.I)
         parts_in = None
+        fold_ms = None
         if folded_form:
-            fold = engine.fold_norm_weights(W)[1]
-            # (the statistics of x in the layout the previous block's down projection leaves them: [D / 64, M] partial sums of squares)
-            parts_in = x.float().pow(2).view(B * S, spec.D // 64, 64).sum(-1).t().contiguous()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            folds = model.folded_weights("net")          # the one-off cost a first forward (or one after a weight update) pays
+            torch.cuda.synchronize()
+            fold_ms = 1e3 * (time.perf_counter() - t0)
+            assert model.folded_weights("net") is folds  # (kept: nothing changed)
+            fold = folds[1]
+            x, parts_in = engine.layer_forward_folded(spec, W.layers[0], folds[0], x, B, S, rope, None)
+        else:
+            x, _ = engine.layer_forward(spec, W.layers[0], x, B, S, rope)   # input of block 1: a real residual stream
 
         def step(i):  # (save=False: the forward-only form a prompt prefill runs -- gate|up is not written for a backward)
             if folded_form:
                 return engine.layer_forward_folded(spec, lw, fold, x, B, S, rope, parts_in)[0]
             return engine.layer_forward(spec, lw, x, B, S, rope, save=args.block_save)[0]
 
-        for i in range(warmup):
+        # warm-up: W steps AND at least 0.5 s of this very work -- the part ramps its clocks over tens of milliseconds of load, and three
+        # 2.8 ms blocks from idle were timed on the ramp (r05: per-launch minima 10 % under the averages inside one 13-step run)
+        t_w = time.perf_counter()
+        i = 0
+        while i < warmup or time.perf_counter() - t_w < 0.5:
             step(i)
+            i += 1
+            if i % 8 == 0:
+                torch.cuda.synchronize()
+        warm_steps = i
         dt, _ = timed(step, steps, dist, torch.cuda.synchronize)
+        # the same block with its two RMSNorm passes (the form below 8192 rows, and the r04 number), and the PUBLIC call:
+        # MIDIModel.forward(events) under no_grad = embedding + 12 blocks + final norm, with the path it takes counted
+        unfolded_ms = api = None
+        if folded_form:
+            for i in range(warmup):
+                engine.layer_forward(spec, lw, x, B, S, rope, save=False)
+            dtu, _ = timed(lambda i: engine.layer_forward(spec, lw, x, B, S, rope, save=False)[0], steps, dist, torch.cuda.synchronize)
+            unfolded_ms = 1e3 * dtu / steps
+            calls = {"folded": 0, "unfolded": 0}
+            real_f, real_u = engine.layer_forward_folded, engine.layer_forward
+
+            def count_f(*a, **k):
+                calls["folded"] += 1
+                return real_f(*a, **k)
+
+            def count_u(*a, **k):
+                calls["unfolded"] += 1
+                return real_u(*a, **k)
+
+            engine.layer_forward_folded, engine.layer_forward = count_f, count_u
+            try:
+                model(ev)
+                n_f, n_u = calls["folded"], calls["unfolded"]
+            finally:
+                engine.layer_forward_folded, engine.layer_forward = real_f, real_u
+            n_api = max(3, steps // 3)
+            dta, _ = timed(lambda i: model(ev), n_api, dist, torch.cuda.synchronize)
+            prof_api = []
+            lib().profile = prof_api
+            model(ev)
+            torch.cuda.synchronize()
+            lib().profile = None
+            _, api_by_name = summarize_launches(prof_api, 1.0, 1)
+            api_kern = {k: {"us_per_call": 1e3 * t / n, "calls": n} for k, (t, n) in sorted(api_by_name.items(), key=lambda kv: -kv[1][0])}
+            api = {"call": "MIDIModel.forward(x) under torch.no_grad(), x = (16, 4096, 8) int64 event ids" if (B, S) == (16, 4096) else
+                           f"MIDIModel.forward(x) under torch.no_grad(), x = ({B}, {S}, 8)",
+                   "ms_per_call": 1e3 * dta / n_api, "blocks": spec.L, "folded_block_calls": n_f, "unfolded_block_calls": n_u,
+                   "ms_per_block_incl_embedding_and_final_norm": 1e3 * dta / n_api / spec.L,
+                   "frac_of_peak_whole_call": block_flops_per_event(S, spec.D, spec.I) * B * S * spec.L / (dta / n_api) / 1e12 / PEAK_BF16_TFLOPS,
+                   "kernels": api_kern}
         # the per-kernel breakdown comes from a second pass with HIP events around every launch (the event markers
         # between the kernels cost the timed pass 1-2 %, as in train mode)
         prof = []
@@ -380,7 +435,10 @@ def measure_block(args, B: int, S: int, steps: int, warmup: int, dist=None):
                 "epilogue), causal flash attention, o + residual, RMSNorm, gate|up + SwiGLU (projection epilogue), down + residual",
         "form": ("training forward (activations kept for the backward)" if args.block_save else
                  "forward only (prefill / validation: gate|up not stored)" + ("; both RMSNorms folded around the projections" if folded_form else "")),
-        "norms_folded": bool(folded_form),
+        "norms_folded": bool(folded_form), "warmup_steps": warm_steps,
+        "api_path": ("MIDIModel.forward under no_grad takes THIS form from 8192 rows up (folded weights kept on the model)" if folded_form
+                     else "not the form MIDIModel.forward takes at this size (it folds the norms)"),
+        "fold_ms_one_off": fold_ms, "ms_per_block_unfolded": unfolded_ms, "api_forward": api,
         "batch": B, "seq_len": S, "dtype": args.dtype, "ms_per_block": 1e3 * dt / steps, "events_per_s": B * S * steps / dt,
         "flops_per_event": block_flops_per_event(S, spec.D, spec.I),
         "roofline": {"bound": "mfma", "achieved": ach, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": ach / PEAK_BF16_TFLOPS,
@@ -638,11 +696,11 @@ def main():
             dist.destroy_process_group()
         return
     if args.mode == "block":
-        b = measure_block(args, args.block_batch, args.block_seq, max(args.steps, 10), max(args.warmup, 3), dist)
+        b = measure_block(args, args.block_batch, args.block_seq, max(args.steps, 30), max(args.warmup, 3), dist)
         if rank == 0:
             print(json.dumps({"metric": f"MIDI events/sec through ONE net block forward, {args.config}, seq={args.block_seq}",
-                              "value": world * b["events_per_s"], "unit": "events/s", "n_gpus": world, "steps": max(args.steps, 10),
-                              "warmup": max(args.warmup, 3), "ms_per_step": b["ms_per_block"], "higher_is_better": True,
+                              "value": world * b["events_per_s"], "unit": "events/s", "n_gpus": world, "steps": max(args.steps, 30),
+                              "warmup": b["warmup_steps"], "ms_per_step": b["ms_per_block"], "higher_is_better": True,
                               "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
                               "config": {"workload": f"{args.config} {args.dtype} fused transformer-block forward, batch {args.block_batch} "
                                                      f"x {args.block_seq} events (north_star target: >= 0.40 of bf16 MFMA peak)"},
@@ -861,7 +919,7 @@ def main():
         torch.cuda.empty_cache()
     if world == 1 and not multi and not args.no_extras:
         # the other two measurements the judge asks for, in the same driver-run line (N=1 only: replicas add nothing)
-        for key, fn in (("block", lambda: measure_block(args, args.block_batch, args.block_seq, 10, 3)),
+        for key, fn in (("block", lambda: measure_block(args, args.block_batch, args.block_seq, 30, 3)),
                         ("generate", lambda: measure_generate(args, 1, 0, None, 5, 1)),
                         ("large", lambda: measure_large(args, "tv2o-large", 16, 4096, 5, 1)),
                         ("large_2x_hidden", lambda: measure_large(args, "2x-hidden", 16, 4096, 5, 1))):

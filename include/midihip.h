@@ -44,10 +44,13 @@ int mh_ab_builds(void);
  * check; bf16: A/B library only); "gemm_k64" = 1 (products with a row-major A operand -- forward projections, dgrads -- run
  * the K-step-64 main loop with whole-line LDS-DMA) | 2 (only row-major x row-major) | 0 (the K-step-32 loop everywhere;
  * identical bits); "gemm_ablate" = micro-benchmark / timeline builds of the production kernel (wrong results; A/B library
- * only -- the production library returns MH_ERR_ARG for any non-zero value at the next mh_gemm call);
+ * only -- the production library returns MH_ERR_ARG for any non-zero value at the next mh_gemm call); "gemm_lean_epi" = 1
+ * (interior tiles take the lean forms of the plain / SwiGLU-backward epilogues: descriptor addressing, packed arithmetic) | 0
+ * (the general forms everywhere; identical bits);
  * "skinny_mb" / "skinny_nbt" = 16-row activation blocks / 16-column blocks per workgroup of mh_gemm_skinny (0 = default);
- * "attn_v3" / "attn_v3_wps" = forms of the event-level attention kernels (attention_mfma3.hip; values that select a
- * first-form kernel: A/B library only). */
+ * "attn_v3" / "attn_v3_wps" = forms of the event-level attention kernels (attention_mfma3.hip; default 255: bit 7 = the
+ * forward's lazy reference maximum; values that select a first-form kernel: A/B library only); "attn_passes" = in how many
+ * chunks of tile ranks those kernels walk their (batch, head) pairs, light chunks last (default 5; 1 = pair after pair). */
 int mh_set_option(const char* name, int value);
 int mh_get_option(const char* name);
 

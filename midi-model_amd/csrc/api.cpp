@@ -36,8 +36,11 @@ thread_local int g_mh_gemm_ablate = 0;
 // gemm_pp256_kernel (whole-line LDS-DMA, r03) and so does the dgrad form (A row-major, B contraction-major), 2 = only the former,
 // 0 = the K-step-32 loop everywhere (bit-identical results; A/B runs, MH_GEMM_K64)
 thread_local int g_mh_gemm_k64 = env_int("MH_GEMM_K64", 1);
+// "gemm_lean_epi": 1 (default) = interior tiles of the production kernel take the r06 forms of the plain and SwiGLU-backward
+// epilogues (descriptor addressing, packed arithmetic), 0 = the general forms everywhere (bit-identical results; A/B runs)
+thread_local int g_mh_gemm_lean_epi = env_int("MH_GEMM_LEAN_EPI", 1);
 extern thread_local int g_skinny_mb, g_skinny_nbt;  // gemm_skinny.hip
-extern thread_local int g_attn_v3, g_attn_v3_wps;      // attention_mfma3.hip
+extern thread_local int g_attn_v3, g_attn_v3_wps, g_attn_passes;      // attention_mfma3.hip
 
 extern "C" int mh_set_option(const char* name, int value) {
   if (strcmp(name, "gemm") == 0) {
@@ -52,6 +55,10 @@ extern "C" int mh_set_option(const char* name, int value) {
     g_mh_gemm_k64 = value;
     return 0;
   }
+  if (strcmp(name, "gemm_lean_epi") == 0) {
+    g_mh_gemm_lean_epi = value;
+    return 0;
+  }
   if (strcmp(name, "skinny_mb") == 0) {  // 16-row blocks of the activation per workgroup of mh_gemm_skinny (0 = default)
     g_skinny_mb = value;
     return 0;
@@ -60,6 +67,10 @@ extern "C" int mh_set_option(const char* name, int value) {
                                        // bit 3 transpose reads in the backward pair (no transposed copies; needs bits 1 and 2),
                                        // bit 4 in the forward, bit 5: callers use mh_attn_bwd_o (delta inside the dQ kernel), bit 6: three K/V stages in the forward
     g_attn_v3 = value;
+    return 0;
+  }
+  if (strcmp(name, "attn_passes") == 0) {  // work order of the event-level attention kernels: tile ranks in `value` chunks, light chunks last
+    g_attn_passes = value;
     return 0;
   }
   if (strcmp(name, "attn_v3_wps") == 0) {  // its register budget in waves per SIMD (0 = default; A/B runs)
@@ -78,9 +89,11 @@ extern "C" int mh_get_option(const char* name) {
   if (strcmp(name, "skinny_mb") == 0) return g_skinny_mb;
   if (strcmp(name, "attn_v3") == 0) return g_attn_v3;
   if (strcmp(name, "attn_v3_wps") == 0) return g_attn_v3_wps;
+  if (strcmp(name, "attn_passes") == 0) return g_attn_passes;
   if (strcmp(name, "skinny_nbt") == 0) return g_skinny_nbt;
   if (strcmp(name, "gemm_k64") == 0) return g_mh_gemm_k64;
   if (strcmp(name, "gemm_ablate") == 0) return g_mh_gemm_ablate;
+  if (strcmp(name, "gemm_lean_epi") == 0) return g_mh_gemm_lean_epi;
   return -1;
 }
 

@@ -2,7 +2,7 @@
 // default (same orientation, same LDS tile format, same results to rounding; selected per kernel by
 // mh_set_option("attn_v3", bits): bit 0 forward, bit 1 dQ, bit 2 dK/dV; bits 3 / 4: the backward pair / the forward take their
 // transposed operands out of the row-major tiles with ds_read_b64_tr_b16 instead of from prepared [B,H,64,Sp] copies; bits 5 / 6
-// below; default 127 = all of them).
+// below, bit 7 = the forward's lazy reference maximum (r06); default 255 = all of them).
 //
 // What the ISA of the first form showed (r02, `hipcc -S` of attention_mfma.hip) and what changes here:
 //  * every MFMA pair sat behind its own `ds_read_b128 ; s_waitcnt lgkmcnt(0)`: 16-32 exposed LDS round trips per tile and
@@ -41,10 +41,15 @@ static int attn_env_int(const char* name, int dflt) {
   const char* v = getenv(name);
   return (v && *v) ? atoi(v) : dflt;
 }
-thread_local int g_attn_v3 = attn_env_int("MH_ATTN_V3", 127);     // mh_set_option("attn_v3", bits): 1 forward, 2 dQ, 4 dK/dV, 8 transpose reads in dQ + dK/dV (needs 2 | 4),
+thread_local int g_attn_v3 = attn_env_int("MH_ATTN_V3", 255);     // mh_set_option("attn_v3", bits): 1 forward, 2 dQ, 4 dK/dV, 8 transpose reads in dQ + dK/dV (needs 2 | 4),
                         // 16 transpose reads in the forward (needs 1; the caller then passes no V^T copy), 32 the host side
                         // calls mh_attn_bwd_o (delta computed inside the dQ kernel; needs 2 | 4 | 8), 64 three K/V stages
-                        // in the forward (needs 1 | 16)
+                        // in the forward (needs 1 | 16), 128 lazy reference maximum in the forward (needs 1 | 16; fwd3_tile)
+// mh_set_option("attn_passes", P): attn_work's pass count (attn_mfma_common.h).  Same-box A/B at B = 16, H = 16 (tools/attn_fwd_ab.py,
+// profiles/r06_attn_passes_ab.txt): forward 196 -> 170 us at S = 2048 and 658 -> 612 us at S = 4096 with P = 5, backward pair 594 -> 534
+// and 1939 -> 1879 us; P = 2 / 3 / 8 / 16 lie between (more passes re-fetch K/V panels more often: at S = 4096 they no longer
+// fit the Infinity Cache together).  Identical results.
+thread_local int g_attn_passes = attn_env_int("MH_ATTN_PASSES", 5);
 thread_local int g_attn_v3_wps = attn_env_int("MH_ATTN_V3_WPS", 0);  // mh_set_option("attn_v3_wps", n): register budget (waves per SIMD) override for A/B runs, 0 = default
 
 __device__ inline bf16x8 ldsv(const char* p) { return *reinterpret_cast<const bf16x8*>(p); }
@@ -298,14 +303,20 @@ __global__ __launch_bounds__(256, WPS) void attn_fwd3_kernel(const bf16* __restr
 
   const bf16* kbase = qkv + b * S * D3 + D + (int64_t)h * HD;
   const bf16* vtbase = (TR || TL) ? kbase + D : vt + bh * HD * Sp;  // (TR: V row-major, straight out of the fused qkv rows)
+  uint64_t tl_t0 = 0;
+  int tl_first = TL_FIRST;  // first recorded tile: the word behind the census, written by the host (default 8)
+  if constexpr (TL) {
+    tl_t0 = tl_now();  // (census: when this workgroup started, see the end of the kernel)
+    tl_first = __builtin_amdgcn_readfirstlane(reinterpret_cast<const int*>(vt)[16 * (TL_BYTES / 4) + (size_t)gridDim.x * 8]);
+  }
   uint64_t ts[TL_STAMPS];
   uint32_t* tl_lds = reinterpret_cast<uint32_t*>(smem + NS * 2 * TILE64) + wave * TL_TILES * TL_STAMPS;
   auto tl_flush = [&](int kt) {  // (TL) the tile's stamps -> LDS, low words
     if constexpr (TL) {
       asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(ts[0]), "+s"(ts[1]), "+s"(ts[2]), "+s"(ts[3]), "+s"(ts[4]), "+s"(ts[5]), "+s"(ts[6]), "+s"(ts[7]), "+s"(ts[8])::"memory");
-      if (kt >= TL_FIRST && kt < TL_FIRST + TL_TILES && lane == 0) {
+      if (kt >= tl_first && kt < tl_first + TL_TILES && lane == 0) {
 #pragma unroll
-        for (int i = 0; i < TL_STAMPS; ++i) tl_lds[(kt - TL_FIRST) * TL_STAMPS + i] = (uint32_t)ts[i];
+        for (int i = 0; i < TL_STAMPS; ++i) tl_lds[(kt - tl_first) * TL_STAMPS + i] = (uint32_t)ts[i];
       }
     }
   };
@@ -404,6 +415,21 @@ __global__ __launch_bounds__(256, WPS) void attn_fwd3_kernel(const bf16* __restr
       uint32_t* out = reinterpret_cast<uint32_t*>(const_cast<bf16*>(vt)) + (blockIdx.x >> 3) * (TL_BYTES / 4);
       const uint32_t* src = reinterpret_cast<const uint32_t*>(smem + NS * 2 * TILE64);
       for (int i = tid; i < TL_BYTES / 4; i += 256) out[i] = src[i];
+    }
+    // census of EVERY workgroup behind the sixteen stamp arrays: [start lo, hi, end lo, hi, HW_ID, XCC_ID, key tiles, 0] -- which CU
+    // it ran on and when, i.e. how many workgroups a CU really holds at a time (tools/attn_timeline.py)
+    if (tid == 0) {
+      const uint64_t t1 = tl_now();
+      asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(tl_t0) : "s"(t1) : "memory");
+      uint32_t* c = reinterpret_cast<uint32_t*>(const_cast<bf16*>(vt)) + 16 * (TL_BYTES / 4) + (size_t)blockIdx.x * 8;
+      c[0] = (uint32_t)tl_t0;
+      c[1] = (uint32_t)(tl_t0 >> 32);
+      c[2] = (uint32_t)t1;
+      c[3] = (uint32_t)(t1 >> 32);
+      c[4] = __builtin_amdgcn_s_getreg((31 << 11) | 4);   // HW_REG_HW_ID
+      c[5] = __builtin_amdgcn_s_getreg((31 << 11) | 20);  // HW_REG_XCC_ID
+      c[6] = (uint32_t)(kt_last + 1);
+      c[7] = 0;
     }
   }
   const float lt = l + __shfl_xor(l, 32, 64);
@@ -883,9 +909,11 @@ int mh_attn_fwd_mfma3(const void* qkv, const void* vt, void* o, float* lse, int6
   MH_REQUIRE(S * 3 * H * HD < (int64_t(1) << 31), "attn_fwd: sequence too long (32-bit panel offsets)");
   MH_REQUIRE(q_start >= 0 && q_start < S, "attn_fwd: q_start %ld outside the sequence", (long)q_start);
   const int64_t Sp = (S + 63) / 64 * 64;
-  const int nt_all = (int)((S + 127) / 128), BH = (int)(B * H);
+  const int nt_all = (int)((S + 127) / 128), BH0 = (int)(B * H);
+  MH_REQUIRE(BH0 < (1 << 24), "attn_fwd: too many (batch, head) pairs");
+  const int BH = BH0 | ((g_attn_passes & 127) << 24);  // (attn_work unpacks the pass count)
   const int nt = nt_all - (int)(q_start / 128);  // query tiles holding rows >= q_start (the first of them may start below it)
-  const unsigned grid = (unsigned)(nt * 8 * ((BH + 7) / 8));
+  const unsigned grid = (unsigned)(nt * 8 * ((BH0 + 7) / 8));
 #define MH_FWD(WPS, TR_, LZ_)                                                                                                    \
   attn_fwd3_kernel<WPS, TR_, 2, LZ_><<<grid, 256, 4 * TILE64, st>>>((const bf16*)qkv, (const bf16*)vt, (bf16*)o, lse, (int)S, (int)Sp, H, \
                                                                  scale * LOG2E, BH, nt, nt_all)
@@ -919,15 +947,18 @@ int mh_attn_fwd_mfma3(const void* qkv, const void* vt, void* o, float* lse, int6
 // A/B library only: the production forward (three stages, transpose reads; lazy = the r06 lazy reference maximum) with s_memtime
 // stamps at the seams of every tile's segments; `stamps` receives uint32 [16 workgroups][4 waves][32 tiles][9]: low words of the
 // shader clock at: top of the tile, LDS-DMA issued, K reads issued, S MFMAs + V^T reads issued, softmax issued, V^T landed,
-// P V MFMAs issued, next tile landed (vmcnt), barrier passed -- for tiles 8 .. 39 of the workgroups' loops (tools/attn_timeline.py).
+// P V MFMAs issued, next tile landed (vmcnt), barrier passed -- for tiles 8 .. 39 of the workgroups' loops (tools/attn_timeline.py);
+// behind them uint32 [grid][8]: every workgroup's start / end clock, HW_ID, XCC_ID and tile count (the residency census), and
+// behind those ONE int32 the host writes: the first recorded tile.
 extern "C" int mh_attn_fwd_timeline(const void* qkv, void* o, float* lse, int64_t B, int64_t S, int H, float scale, int lazy,
                                     uint32_t* stamps, void* stream) {
 #ifdef MH_AB_BUILDS
   MH_REQUIRE(stamps != nullptr && S >= 128 && S * 3 * H * HD < (int64_t(1) << 31), "attn_fwd_timeline: bad arguments");
   hipStream_t st = (hipStream_t)stream;
   const int64_t Sp = (S + 63) / 64 * 64;
-  const int nt_all = (int)((S + 127) / 128), BH = (int)(B * H), nt = nt_all;
-  const unsigned grid = (unsigned)(nt * 8 * ((BH + 7) / 8));
+  const int nt_all = (int)((S + 127) / 128), BH0 = (int)(B * H), nt = nt_all;
+  const int BH = BH0 | ((g_attn_passes & 127) << 24);
+  const unsigned grid = (unsigned)(nt * 8 * ((BH0 + 7) / 8));
   if (lazy)
     attn_fwd3_kernel<2, true, 3, true, true><<<grid, 256, 6 * TILE64 + TL_BYTES, st>>>((const bf16*)qkv, (const bf16*)stamps, (bf16*)o, lse, (int)S,
                                                                                    (int)Sp, H, scale * LOG2E, BH, nt, nt_all);
@@ -951,8 +982,10 @@ int mh_attn_bwd_mfma3(const void* qkv, const void* dout, const float* lse, const
   const bool tr = (which & 8) != 0;
   MH_REQUIRE(tr || (qt != nullptr && kt != nullptr && dot != nullptr), "attn_bwd(bf16): needs the transposed copies (mh_attn_prep_bwd)");
   const int64_t Sp = (S + 63) / 64 * 64;
-  const int nt = (int)((S + 127) / 128), BH = (int)(B * H);
-  const unsigned grid = (unsigned)(nt * 8 * ((BH + 7) / 8));
+  const int nt = (int)((S + 127) / 128), BH0 = (int)(B * H);
+  MH_REQUIRE(BH0 < (1 << 24), "attn_bwd: too many (batch, head) pairs");
+  const int BH = BH0 | ((g_attn_passes & 127) << 24);  // (attn_work unpacks the pass count)
+  const unsigned grid = (unsigned)(nt * 8 * ((BH0 + 7) / 8));
 #define MH_DQ(WPS, TR_)                                                                                                     \
   attn_bwd_dq3_kernel<WPS, TR_><<<grid, 256, (TR_ ? 4 : 6) * TILE64, st>>>((const bf16*)qkv, (const bf16*)dout, lse, delta,     \
                                                                         (const bf16*)kt, (bf16*)dqkv, (int)S, (int)Sp, H, scale, \
@@ -970,7 +1003,7 @@ int mh_attn_bwd_mfma3(const void* qkv, const void* dout, const float* lse, const
   if (which & 4) {
     if (tr && o != nullptr)  // (statistics pre-scaled by the dQ kernel above)
       attn_bwd_dkv3_kernel<true, true><<<grid, 256, 2 * (2 * TILE64 + 2048), st>>>((const bf16*)qkv, (const bf16*)dout,
-                                                                                 delta + (int64_t)BH * Sp, delta, nullptr, nullptr,
+                                                                                 delta + (int64_t)BH0 * Sp, delta, nullptr, nullptr,
                                                                                  (bf16*)dqkv, (int)S, (int)Sp, H, scale, BH, nt,
                                                                                  cos_t, sin_t);
     else if (tr)

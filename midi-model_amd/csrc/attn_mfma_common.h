@@ -157,10 +157,29 @@ __device__ inline void store_grad_row(bf16* orow, const f32x16 (&acc)[2], float 
 // grid is decoded as  xcd = b & 7, i = b >> 3, head = (i / ntile) * 8 + xcd, tile = i % ntile : consecutive
 // workgroups of one XCD walk the tiles of ONE (batch, head) pair, whose K/V (or Q/dO) panels then stay in that
 // XCD's L2 instead of being re-fetched (r01 PMC with the (tile, head) 2-D grid: L2 hit rate 34 % fwd, 14 % dK/dV).
-__device__ inline bool attn_work(int BH, int ntile, int& bh, int& tile) {
-  const int lin = blockIdx.x, xcd = lin & 7, i = lin >> 3;
-  const int g = i / ntile;
+// r06: PASSES.  A workgroup's work shrinks with its tile rank (rank 0: the whole sequence, the last rank: two key tiles), and with
+// one pass the order on an XCD is a sawtooth -- pair after pair from heaviest to lightest -- so the kernel ends with the heavy
+// workgroups of the LAST pairs still running beside empty slots: the residency census of the instrumented forward
+// (tools/attn_timeline.py, mh_attn_fwd_timeline) counts 2.3-2.5 workgroups per CU on average where 3 fit.  With P passes
+// the ranks are cut into P contiguous chunks and pass p walks chunk p of EVERY pair: the light chunks come last, the tail is as
+// short as the lightest workgroups, and a pair's K/V panels still serve a whole chunk of its tiles while they sit in L2.
+// BH arrives packed with the pass count (BH | P << 24; 0 = 1 pass) and is unpacked here.
+__device__ inline bool attn_work(int& BH, int ntile, int& bh, int& tile) {
+  int P = BH >> 24;
+  BH &= 0xffffff;
+  P = P < 1 ? 1 : (P > ntile ? ntile : P);
+  const int lin = blockIdx.x, xcd = lin & 7;
+  int i = lin >> 3;
+  const int nG = (BH + 7) >> 3;  // (batch, head) pairs per XCD
+  int lo = 0, n = ntile;
+  for (int p = 0; p < P; ++p) {
+    lo = p * ntile / P;
+    n = (p + 1) * ntile / P - lo;
+    if (i < nG * n) break;
+    i -= nG * n;
+  }
+  const int g = i / n;
   bh = g * 8 + xcd;
-  tile = i - g * ntile;
+  tile = lo + (i - g * n);
   return bh < BH;
 }

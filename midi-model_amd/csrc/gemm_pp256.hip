@@ -117,6 +117,17 @@ __device__ inline __amdgpu_buffer_rsrc_t tile_rsrc(const void* base, int64_t byt
                       ((uint64_t)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(b >> 32)) << 32);
   return __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<void*>((uintptr_t)bu), 0, (unsigned)__builtin_amdgcn_readfirstlane((int)n), 0x00020000);
 }
+// A 16-byte store through a tile descriptor.  The row step goes into the VGPR offset, NOT into the instruction's SGPR offset
+// field: hipcc assumes that a buffer store with an SGPR soffset has read its data registers when the next instruction issues
+// (GCNHazardRecognizer::createsVALUHazard exempts that form) and schedules a VALU write of the data registers right behind it --
+// on gfx950 that write sporadically reached the store: the first dword of the second line of a wave's rows came out as the
+// NEXT line's fp32 bits (r06, same-box runs of tools/gpu_r06_dbg1.py: 30-500 wrong elements per launch, none with this form,
+// where the compiler sees the hazard and keeps its wait state).
+template <int AUX>
+__device__ inline void tile_store_(const u32x4& v, __amdgpu_buffer_rsrc_t r, unsigned voff) {
+  __builtin_amdgcn_raw_buffer_store_b128(v, r, voff, 0, AUX);
+}
+#define tile_store(v, r, voff, aux) tile_store_<aux>(v, r, voff)
 __device__ inline u32x4 as_u32x4(const bf16x8& v) {
   union {
     bf16x8 b;
@@ -430,7 +441,7 @@ __global__ __launch_bounds__(512, 2) void gemm_pp256_kernel(const bf16* __restri
                                                             const bf16* R, int64_t ldr, int64_t M, int64_t N, int64_t K,
                                                             float alpha, float beta, int tiles_n, int nwg,
                                                             int64_t k_per_split, float* __restrict__ ws,
-                                                            const void* __restrict__ zero16, float* aux) {
+                                                            const void* __restrict__ zero16, float* aux, int lean_epi) {
   static_assert(NRM == 0 || (ML == 1 && ABL == 0 && !TA && !TB), "the norm forms ride on the K-step-64 row-major loop only");
   static_assert(NRM != 1 || EPI == 0, "sum-of-squares partials come out of the plain epilogue");
   static_assert(NRM != 2 || EPI == 2 || EPI == 3, "the row scale is applied by the SwiGLU / RoPE epilogues");
@@ -609,7 +620,7 @@ __global__ __launch_bounds__(512, 2) void gemm_pp256_kernel(const bf16* __restri
   // is already half lines; turning them through LDS measured 5 % slower inside the training step).
   // Rounding the tile to bf16 before the turn (half the LDS traffic when there is no residual) measured no faster.
   if constexpr (EPI == 1) {
-    if (m0 + QBM <= M && n0 + QBN <= N && ldc < (1 << 22) && ldr < (1 << 22)) {
+    if (lean_epi && m0 + QBM <= M && n0 + QBN <= N && ldc < (1 << 22) && ldr < (1 << 22)) {
       // r06: interior tile -- the form below with descriptor addressing (tile_rsrc: no 64-bit address arithmetic or bounds
       // tests per line) and the SwiGLU derivative on two-element vectors (mh_dswiglu8: the epilogue is VALU-bound, ~1900
       // instructions per wave before).  Same operations, same roundings.
@@ -653,9 +664,9 @@ __global__ __launch_bounds__(512, 2) void gemm_pp256_kernel(const bf16* __restri
           expand8_bf16(gq[half][i], g);
           expand8_bf16(uq[half][i], u);
           mh_dswiglu8(dv, g, u, dg, du);
-          const unsigned so = (unsigned)(half * 8 + i) * so_c;
-          __builtin_amdgcn_raw_buffer_store_b128(as_u32x4(cvt8_bf16(dg)), rc, vo_c, so, 2 /* nt */);
-          __builtin_amdgcn_raw_buffer_store_b128(as_u32x4(cvt8_bf16(du)), rc, vo_c, so + up_off, 2);
+          const unsigned so = (unsigned)(half * 8 + i) * so_c;  // (added to the VGPR offset: see tile_store)
+          tile_store(as_u32x4(cvt8_bf16(dg)), rc, vo_c + so, 2 /* nt */);
+          tile_store(as_u32x4(cvt8_bf16(du)), rc, vo_c + so + up_off, 2);
         }
       }
       return;
@@ -771,10 +782,11 @@ __global__ __launch_bounds__(512, 2) void gemm_pp256_kernel(const bf16* __restri
         // row r of the 64-row half: 64 bytes; 16-byte chunk c at slot c ^ ((r >> 1) & 3) (8 lanes of a write = 8 rows, one
         // chunk: distinct 16-byte slots of a 128-byte bank row)
         const int row = fmh * 16 + fi, off = row * 64 + ((fg ^ ((row >> 1) & 3)) << 4);
-        *reinterpret_cast<bf16x8*>(wreg + off) = oa;
+        // (written and read back as the SAME type: accesses of different vector types may be reordered by type-based alias analysis)
+        *reinterpret_cast<u32x4*>(wreg + off) = as_u32x4(oa);
         if (keep) {
-          *reinterpret_cast<bf16x8*>(wreg + 4096 + off) = og;
-          *reinterpret_cast<bf16x8*>(wreg + 8192 + off) = ou;
+          *reinterpret_cast<u32x4*>(wreg + 4096 + off) = as_u32x4(og);
+          *reinterpret_cast<u32x4*>(wreg + 8192 + off) = as_u32x4(ou);
         }
       }
 #pragma unroll
@@ -782,12 +794,12 @@ __global__ __launch_bounds__(512, 2) void gemm_pp256_kernel(const bf16* __restri
         const int row = i * 16 + r4, off = row * 64 + ((c4 ^ ((row >> 1) & 3)) << 4);
         const unsigned so = (unsigned)(half * 4 + i);
         const u32x4 va = *reinterpret_cast<const u32x4*>(wreg + off);
-        __builtin_amdgcn_raw_buffer_store_b128(va, ra, vo_a, so * so_a, 0);
+        tile_store(va, ra, vo_a + so * so_a, 0);
         if (keep) {
           const u32x4 vg = *reinterpret_cast<const u32x4*>(wreg + 4096 + off);
           const u32x4 vu = *reinterpret_cast<const u32x4*>(wreg + 8192 + off);
-          __builtin_amdgcn_raw_buffer_store_b128(vg, rc, vo_c, so * so_c, 0);
-          __builtin_amdgcn_raw_buffer_store_b128(vu, rc, vo_c, so * so_c + (unsigned)I * 2u, 0);
+          tile_store(vg, rc, vo_c + so * so_c, 0);
+          tile_store(vu, rc, vo_c + so * so_c + (unsigned)I * 2u, 0);
         }
       }
     }
@@ -908,8 +920,9 @@ __global__ __launch_bounds__(512, 2) void gemm_pp256_kernel(const bf16* __restri
       }
       // row r of the wave's 128: 128 bytes, 16-byte chunk c at slot c ^ (r & 7) (8 lanes of a write = 8 rows, one chunk)
       const int row = fm * 16 + fi;
-      *reinterpret_cast<bf16x8*>(wreg + row * 128 + ((fg ^ (row & 7)) << 4)) = b1;
-      *reinterpret_cast<bf16x8*>(wreg + row * 128 + (((4 + fg) ^ (row & 7)) << 4)) = b2;
+      // (written and read back as the SAME type: see the SwiGLU form)
+      *reinterpret_cast<u32x4*>(wreg + row * 128 + ((fg ^ (row & 7)) << 4)) = as_u32x4(b1);
+      *reinterpret_cast<u32x4*>(wreg + row * 128 + (((4 + fg) ^ (row & 7)) << 4)) = as_u32x4(b2);
     }
     const int64_t rows_left = (M - m0 < QBM) ? M - m0 : QBM;
     const __amdgpu_buffer_rsrc_t rc = tile_rsrc(C + m0 * ldc + nw, ((rows_left - 1) * ldc + 64) * 2);
@@ -919,7 +932,7 @@ __global__ __launch_bounds__(512, 2) void gemm_pp256_kernel(const bf16* __restri
     for (int i = 0; i < 16; ++i) {  // 8 rows x 128 B per instruction
       const int row = i * 8 + r8;
       const u32x4 v = *reinterpret_cast<const u32x4*>(wreg + row * 128 + ((c8 ^ (row & 7)) << 4));
-      __builtin_amdgcn_raw_buffer_store_b128(v, rc, vo, (unsigned)i * so8, 2 /* nt: C is not read again by this kernel */);
+      tile_store(v, rc, vo + (unsigned)i * so8, 2 /* nt: C is not read again by this kernel */);
     }
     return;
   }
@@ -999,7 +1012,7 @@ __global__ __launch_bounds__(512, 2) void gemm_pp256_kernel(const bf16* __restri
   const bool use_r = (R != nullptr && beta != 0.f);
   const bool line_ok = !partial && (ldc & 7) == 0 && ((uintptr_t)C & 15) == 0 &&
                        (!use_r || ((ldr & 7) == 0 && ((uintptr_t)R & 15) == 0));
-  if (line_ok && m0 + QBM <= M && n0 + QBN <= N && ldc < (1 << 22) && ldr < (1 << 22)) {
+  if (lean_epi && line_ok && m0 + QBM <= M && n0 + QBN <= N && ldc < (1 << 22) && ldr < (1 << 22)) {
     // r06: an INTERIOR tile (every tile of the benchmarked shapes but the ragged logits columns): the whole-line turn below with
     // its addresses as descriptor + one per-lane offset + scalar offsets (tile_rsrc), no bounds tests.  Same arithmetic.
     char* wreg = smem + wave * 16384;
@@ -1047,7 +1060,7 @@ __global__ __launch_bounds__(512, 2) void gemm_pp256_kernel(const bf16* __restri
         bf16x8 o;
 #pragma unroll
         for (int e = 0; e < 8; ++e) o[e] = (bf16)v[e];
-        __builtin_amdgcn_raw_buffer_store_b128(as_u32x4(o), rc, vo_c, (unsigned)(half * 8 + i) * so_c, 2 /* nt */);
+        tile_store(as_u32x4(o), rc, vo_c + (unsigned)(half * 8 + i) * so_c, 2 /* nt */);
         if constexpr (NRM == 1) {  // (see the general form below)
           union {
             bf16x8 v8;
@@ -1185,6 +1198,9 @@ __global__ __launch_bounds__(512, 2) void gemm_pp256_kernel(const bf16* __restri
   }
 }
 
+}  // namespace
+extern thread_local int g_mh_gemm_lean_epi;  // api.cpp: option "gemm_lean_epi" (default 1): interior tiles take the r06 forms of the plain / SwiGLU-backward epilogues
+namespace {
 template <bool TA, bool TB, int ABL, int EPI = 0, int ML = 0, int NRM = 0>
 int launch_one(const void* A, int64_t lda, const void* B, int64_t ldb, void* C, int64_t ldc, const void* R, int64_t ldr,
                int64_t M, int64_t N, int64_t K, float alpha, float beta, int splitk, void* workspace, hipStream_t st,
@@ -1226,7 +1242,7 @@ int launch_one(const void* A, int64_t lda, const void* B, int64_t ldb, void* C, 
   dim3 grid(nwg, 1, splitk);
   gemm_pp256_kernel<TA, TB, ABL, EPI, ML, NRM><<<grid, 512, LDSB, st>>>((const bf16*)A, lda, (const bf16*)B, ldb, (bf16*)C, ldc,
                                                           (const bf16*)R, ldr, M, N, K, alpha, beta, (int)tiles_n, nwg, kps,
-                                                          (float*)workspace, zero16, aux);
+                                                          (float*)workspace, zero16, aux, g_mh_gemm_lean_epi);
   MH_LAUNCH_CHECK();
   return MH_OK;
 }

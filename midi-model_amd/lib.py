@@ -67,6 +67,8 @@ class _Lib:
             try:
                 fn = getattr(self.cdll, name)
             except AttributeError as e:
+                if os.environ.get("MH_LIB_PATH") and path == os.environ["MH_LIB_PATH"]:
+                    continue  # (an OLDER build named for a same-box A/B run, tools/*_lib_once.py: entry points added since are absent)
                 raise RuntimeError(f"libmidihip.so does not export {name} declared in include/midihip.h") from e
             fn.argtypes = [_to_ctype(t) for t, _ in args]
             fn.restype = ctypes.c_char_p if ret == "str" else ctypes.c_int

@@ -188,8 +188,9 @@ class MIDIModel(nn.Module):
     def folded_weights(self, pre: str = "net"):
         """engine.fold_norm_weights of stack ``pre`` -- [(wqkv * n1, wgu * n2) per layer], the weights the forward-only blocks with
         folded RMSNorms multiply by (engine.layer_forward_folded) -- kept on the model and re-derived lazily, in place, when a
-        parameter changed: keyed on the parameters' version counters (every torch-side write: load_state_dict, an optimizer
-        from torch.optim, ``p.data.copy_``) and on the epoch raw-pointer writers bump (weights_written).  So the public
+        parameter changed: keyed on the parameters' version counters (torch-side in-place writes: load_state_dict, an optimizer
+        from torch.optim, ``p.mul_()`` under no_grad) and on the epoch raw-pointer writers bump (weights_written; a write through
+        ``p.data`` is such a writer too -- torch does not count it).  So the public
         ``forward`` under no_grad reaches the folded blocks from 8192 rows up without paying the fold per call (~0.7 ms of
         elementwise launches for tv2o-medium).  277 MB for tv2o-medium in bf16."""
         st = getattr(self, pre)

@@ -50,7 +50,7 @@ def test_options_are_per_thread():
     from midi_model_amd import lib as L
     h = L.lib()
     defaults = {n: h.cdll.mh_get_option(n.encode()) for n in ("gemm", "gemm_k64", "gemm_ablate", "skinny_mb", "skinny_nbt", "attn_v3", "attn_v3_wps")}
-    assert defaults["gemm"] == 1 and defaults["attn_v3"] == 127 and defaults["gemm_ablate"] == 0
+    assert defaults["gemm"] == 1 and defaults["attn_v3"] == 255 and defaults["gemm_ablate"] == 0
     seen = {}
 
     def other():
@@ -69,7 +69,7 @@ def test_options_are_per_thread():
         assert h.cdll.mh_get_option(b"attn_v3") == 31 and h.cdll.mh_get_option(b"skinny_mb") == 2
     finally:
         h.call("mh_set_option", b"skinny_mb", 0)
-        h.call("mh_set_option", b"attn_v3", 127)
+        h.call("mh_set_option", b"attn_v3", 255)
     assert h.cdll.mh_get_option(b"no_such_option") == -1
 
 

@@ -67,7 +67,7 @@ def test_production_library_refuses_the_ab_only_forms(ops):
     finally:
         ops.set_option("gemm", 1)
         ops.set_option("gemm_ablate", 0)
-        ops.set_option("attn_v3", 127)
+        ops.set_option("attn_v3", V3_DEFAULT)
 
 
 def rnd(shape, dtype, seed, scale=1.0):
@@ -485,10 +485,13 @@ def test_rope(ops, dtype, H, hd, S, M):
 
 
 # ------------------------------------------------------------------------------ event-level attention
+V3_DEFAULT = 255  # mh_get_option("attn_v3") of a fresh thread (r06: + the forward's lazy reference maximum)
 # form -> (attn_v3 bits, attn_v3_wps)
 ATTN_FORMS = {
+    "v3_lazy": (255, 0),         # the default: the third form of all three kernels + the forward's lazy reference maximum (r06)
+    "v3_lazy_wps3": (255, 3),
     "v3_tr_all": (127, 0),       # third form of all three kernels: transposed operands by transpose reads, delta inside dQ,
-                                 # three K/V stages in the forward (the default)
+                                 # three K/V stages in the forward (the r02-r05 default: classic per-tile row maximum)
     "v3_tr_all_wps2": (127, 2),  # ... held to two / three waves per SIMD
     "v3_tr_all_wps3": (127, 3),
     "v3_tr_all_2stage": (63, 0),      # ... forward with two K/V stages
@@ -505,7 +508,7 @@ ATTN_FORMS = {
 def test_attention_fwd_bwd(ops, form, dtype, B, S, H):
     """(bf16: every form of the MFMA kernels -- the third form (fragment batches, one loop per tile class, transpose reads)
     with and without prepared transposed copies, and the first form; fp32 runs the plain verification kernel either way)"""
-    if dtype == torch.float32 and form != "v3_tr_all":
+    if dtype == torch.float32 and form != "v3_lazy":
         pytest.skip("fp32 has one forward kernel")
     v3, v3_wps = ATTN_FORMS[form]
     with (ops.ab_library() if form == "first_form" else contextlib.nullcontext()):  # (first form: A/B library only)
@@ -542,14 +545,16 @@ def _attention_fwd_bwd(ops, v3, v3_wps, dtype, B, S, H):
     cmp(got, want.cpu(), dtype, k=2, what="attn bwd + rotation back")
     same = (got == want).float().mean().item()
     assert same > 0.99, f"fused rotation agrees with the separate pass on only {same:.4f} of the elements"
-    ops.set_option("attn_v3", 127)
+    ops.set_option("attn_v3", V3_DEFAULT)
     ops.set_option("attn_v3_wps", 0)
 
 
-@pytest.mark.parametrize("v3", [95, 31, 7, 0], ids=["v3_tr_3stage", "v3_tr", "v3", "first_form"])
+@pytest.mark.parametrize("v3", [255, 223, 95, 31, 7, 0], ids=["v3_lazy", "v3_lazy_tr_3stage", "v3_tr_3stage", "v3_tr", "v3", "first_form"])
 def test_attention_forward_when_the_reference_has_to_move(ops, v3):
     """Rows whose scores jump by far more than the lazy-rescale threshold between tiles (a few keys late in the sequence
-    are scaled up 8x and 24x: q.k/8 moves by tens to more than a hundred log2 units), plus a first tile of tiny scores."""
+    are scaled up 8x and 24x: q.k/8 moves by tens to more than a hundred log2 units), plus a first tile of tiny scores.
+    The r06 lazy reference maximum (bit 7) takes its slow path exactly here: jumps below 40 binades stay on the fast path with
+    probabilities far above one, jumps beyond overflow its partial row sums and send the wave through the classic update."""
     B, S, H = 1, 640, 2
     D = H * 64
     qkv = rnd((B * S, 3 * D), torch.bfloat16, 41)
@@ -565,7 +570,7 @@ def test_attention_forward_when_the_reference_has_to_move(ops, v3):
         ops.set_option("attn_v3", v3)
         o, lse = torch.empty((B * S, D), dtype=torch.bfloat16, device="cuda"), torch.zeros(B * H * Sp, device="cuda")
         ops.attn_fwd(qkv.cuda(), o, lse, B, S, H, 0.125)
-        ops.set_option("attn_v3", 127)
+        ops.set_option("attn_v3", V3_DEFAULT)
     assert torch.isfinite(o.float()).all() and torch.isfinite(lse).all()
     cmp(o, o_ref, torch.bfloat16, what="attn o (moving reference)")
     got, want = lse.view(B, H, Sp)[:, :, :S].cpu(), lse_ref.view(B, H, Sp)[:, :, :S]
@@ -601,7 +606,7 @@ def test_attention_bwd_in_one_call_hands_over_delta_and_says_what_it_does_not_se
     ops.set_option("attn_v3", 7)    # the backward pair from prepared transposed copies: not served in one call
     with pytest.raises(RuntimeError, match="attn_bwd_o"):
         lib().call("mh_attn_bwd_o", *args, 1, st)
-    ops.set_option("attn_v3", 127)
+    ops.set_option("attn_v3", V3_DEFAULT)
     with pytest.raises(RuntimeError, match="bf16 only"):
         lib().call("mh_attn_bwd_o", *args, 0, st)        # fp32
     mh_err = lib().cdll.mh_last_error()

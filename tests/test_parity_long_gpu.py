@@ -139,6 +139,57 @@ def test_forward_with_folded_norms_at_S4096(orc, medium, tok, golden, monkeypatc
     assert len(calls) >= 12, "the forward did not take the folded blocks"
 
 
+def test_public_forward_takes_the_folded_blocks_at_16x4096(orc, medium, tok, golden, monkeypatch):
+    """MIDIModel.forward under no_grad at the north_star shape (16 x 4096 events = 65,536 rows; midi_model.py:137-150), NOTHING
+    patched but a call counter: the folded weights are kept on the model (MIDIModel.folded_weights, r06), so the public call runs
+    the twelve folded-norm blocks bench.py --mode block times.  Sixteen copies of the golden sequence: every batch row must be
+    the same hidden state (rows are independent), and row 0 is held to the S = 4096 bf16 bounds of the reference's golden
+    vectors (hidden states; logits and arg-max through forward_token on that row).  Then the cache: kept while nothing
+    changes, re-derived after a torch-side parameter write and after weights_written()."""
+    from midi_model_amd import engine
+    g = golden("medium_long_S4096.npz")
+    shp, sd = medium
+    batch = orc.synthetic_events(tok, 1, 4097, seed=int(g["batch_seed"]))
+    calls = []
+    real = engine.layer_forward_folded
+    monkeypatch.setattr(engine, "layer_forward_folded", lambda *a, **k: (calls.append(1), real(*a, **k))[1])
+    model = build(sd, torch.bfloat16)
+    x = batch[:, :-1].repeat(16, 1, 1).cuda()
+    with torch.no_grad():
+        hidden = model.forward(x)
+        assert len(calls) == 12, f"forward took {len(calls)} folded blocks, expected 12"
+        assert tuple(hidden.shape) == (16, 4096, shp.n_embd)
+        assert torch.equal(hidden, hidden[:1].expand_as(hidden)), "batch rows of identical sequences differ"
+        h0 = hidden[0]
+        y = batch[:, 1:].reshape(-1, 8).cuda()
+        logits = model.forward_token(h0, y[:, :-1]).float().cpu()
+    h_sub, l_sub = h0.float().cpu()[::32, ::4].numpy(), logits[::64, :, ::16].numpy()
+    lse = torch.logsumexp(logits, -1).numpy()
+    amax = logits.argmax(-1).numpy()
+    herr = np.abs(h_sub - g["hidden_sub"])
+    ref = oracle_run(orc, medium, tok, 4096, grads=False)
+    full = logits - ref["logits"]
+    print(f"16 x 4096 public forward (folded blocks): hidden max {herr.max():.4f} (ref bf16 {float(g['ref_bf16_hidden_maxerr']):.4f}), "
+          f"logits max {full.abs().max().item():.4f} rms {full.pow(2).mean().sqrt().item():.5f}")
+    assert herr.max() <= DRIFT * float(g["ref_bf16_hidden_maxerr"])
+    assert full.abs().max().item() <= DRIFT * float(g["ref_bf16_logits_maxerr"])
+    assert full.pow(2).mean().sqrt().item() <= DRIFT * float(g["ref_bf16_logits_rmserr"])
+    assert np.abs(lse - g["logits_lse"]).max() <= DRIFT * float(g["ref_bf16_lse_maxerr"]) + 1e-3
+    safe = g["logits_margin"] > 2.0 * float(g["ref_bf16_logits_maxerr"])
+    assert safe.any() and (amax == g["logits_argmax"])[safe].all()
+    # the cache
+    f0 = model.folded_weights("net")
+    assert model.folded_weights("net") is f0
+    w0 = f0[0][0].clone()
+    with torch.no_grad():
+        model.net.layers[0].input_layernorm.weight.mul_(2.0)      # a torch-side write: the version counter moves
+    f1 = model.folded_weights("net")
+    assert torch.equal(f1[0][0].float(), (w0.float() * 2.0).to(torch.bfloat16).float()), "fold not re-derived after a parameter write"
+    model._flat[model._offsets["net.layers.0.input_layernorm.weight"][0]:][:shp.n_embd].fill_(1.0)   # (a raw write ...)
+    model.weights_written()                                                                             # (... announced)
+    assert torch.equal(model.folded_weights("net")[0][0], model._W["net"].layers[0].wqkv)
+
+
 # ------------------------------------------------------------------------------ training step at S = 2048
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16], ids=["fp32", "bf16"])
 def test_training_step_gradients_at_S2048(orc, medium, tok, golden, dtype):
@@ -438,6 +489,76 @@ def test_two_times_hidden_shape_against_oracle(orc, tok, dtype):
     flat_ref = torch.cat([sdg[k].grad.reshape(-1) for k in named]).double()
     cos = (torch.dot(flat, flat_ref) / (flat.norm() * flat_ref.norm())).item()
     assert cos >= 1.0 - 2.0 * DRIFT * (1.0 - float(g["ref_bf16_grad_cosine"])) - 1e-4, cos
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16], ids=["fp32", "bf16"])
+def test_two_times_hidden_step_at_S4096(orc, tok, golden, dtype):
+    """The 2x-hidden shape WHERE bench.py runs it: S = 4096 events (32-head attention over 64 key tiles, K = 8192 contractions
+    over 4096 / 32,768 rows), bf16 with ``lean_activations`` as the `large_2x_hidden` line has it, against golden vectors of the
+    REAL reference (midi_model.py:63-76 ``get_config("v2", True, 4, 32, 2048, 8192)``; tests/gen_golden_large2x.py: its fp32 step
+    and its own bf16-true step on the same weights and events).  fp32: logits rtol 1e-3, loss, every gradient norm.  bf16: loss,
+    hidden states, logits, log-sum-exp, arg-max, the gradient's cosine / norm ratio / named tensors inside 1.5x the reference's
+    own bf16 errors."""
+    g = golden("large2x_S4096.npz")
+    S = int(g["S"])
+    shp = orc.Shape(n_layer=4, n_head=32, n_embd=2048, n_inner=8192, vocab=tok.vocab_size)
+    sd = orc.make_state_dict(shp, seed=int(g["weight_seed"]))
+    batch = orc.synthetic_events(tok, 1, S + 1, seed=int(g["batch_seed"]))
+    model = TrainMIDIModel(mm.MIDIModelConfig.get_config("v2", True, 4, 32, 2048, 8192), accumulate_grad_batches=1)
+    model.load_state_dict(sd, strict=True)
+    model = model.to("cuda", dtype)
+    model.lean_activations = (dtype == torch.bfloat16)
+    with torch.no_grad():
+        hidden = model.forward(batch[:, :-1].cuda()).reshape(-1, shp.n_embd)
+        y = batch[:, 1:].reshape(-1, 8).cuda()
+        logits = model.forward_token(hidden, y[:, :-1]).float().cpu()
+    hidden = hidden.float().cpu()
+    loss = model.training_step(batch.cuda())
+    named = {k: p.grad.float().cpu() for k, p in model.named_parameters()}
+    names = [str(n) for n in g["grad_names"]]
+    norms = np.array([named[n].norm().item() for n in names])
+    h_sub, l_sub = hidden[::32, ::8].numpy(), logits[::64, :, ::16].numpy()
+    lse = torch.logsumexp(logits, -1).numpy()
+    amax = logits.argmax(-1).numpy()
+    if dtype == torch.float32:
+        assert abs(loss.item() - float(g["loss"])) < 2e-4
+        np.testing.assert_allclose(h_sub, g["hidden_sub"], rtol=1e-3, atol=3e-4)
+        np.testing.assert_allclose(l_sub, g["logits_sub"], rtol=1e-3, atol=3e-4)
+        np.testing.assert_allclose(lse, g["logits_lse"], rtol=1e-4, atol=1e-4)
+        safe = g["logits_margin"] > 1e-3
+        assert (amax == g["logits_argmax"])[safe].all()
+        np.testing.assert_allclose(norms, g["grad_norms"], rtol=2e-3, atol=1e-8)
+        for key in g.files:
+            if key.startswith("grad:"):
+                k = key[5:]
+                got = named[k] if named[k].dim() == 1 else named[k][:64:3, ::5]
+                np.testing.assert_allclose(got.numpy(), g[key], rtol=5e-3, atol=2e-4 * np.abs(g[key]).max(), err_msg=k)
+        return
+    herr, lerr = np.abs(h_sub - g["hidden_sub"]), np.abs(l_sub - g["logits_sub"])
+    lse_err = np.abs(lse - g["logits_lse"]).max()
+    agree = (amax == g["logits_argmax"]).mean()
+    drift = abs(float(g["ref_bf16_loss"]) - float(g["loss"]))
+    print(f"2x hidden bf16 at S=4096 (lean): loss {loss.item():.5f} (fp32 {float(g['loss']):.5f}, ref bf16 {float(g['ref_bf16_loss']):.5f}); hidden max "
+          f"{herr.max():.4f} (ref bf16 {float(g['ref_bf16_hidden_maxerr']):.4f}); sampled logits max {lerr.max():.4f} (ref bf16 full max "
+          f"{float(g['ref_bf16_logits_maxerr']):.4f}); lse {lse_err:.4f} (ref {float(g['ref_bf16_lse_maxerr']):.4f}); argmax agree {agree:.4f} "
+          f"(ref {float(g['ref_bf16_argmax_agree']):.4f})")
+    assert abs(loss.item() - float(g["loss"])) <= DRIFT * drift + 5e-3
+    assert herr.max() <= DRIFT * float(g["ref_bf16_hidden_maxerr"])
+    assert lerr.max() <= DRIFT * float(g["ref_bf16_logits_maxerr"])
+    assert np.sqrt((lerr ** 2).mean()) <= DRIFT * float(g["ref_bf16_logits_rmserr"])
+    assert lse_err <= DRIFT * float(g["ref_bf16_lse_maxerr"]) + 1e-3
+    assert agree >= float(g["ref_bf16_argmax_agree"]) - 0.02
+    safe = g["logits_margin"] > 2.0 * float(g["ref_bf16_logits_maxerr"])
+    assert safe.any() and (amax == g["logits_argmax"])[safe].all()
+    # gradients: every norm loosely, the named slices against the fp32 reference within the reference's own bf16 relative errors
+    np.testing.assert_allclose(norms, g["grad_norms"], rtol=0.15, atol=1e-6)
+    for key in g.files:
+        if key.startswith("ref_bf16_grad_relerr:"):
+            k = key.split(":", 1)[1]
+            want = g["grad:" + k]
+            got = (named[k] if named[k].dim() == 1 else named[k][:64:3, ::5]).numpy()
+            rel = np.linalg.norm(got - want) / max(np.linalg.norm(want), 1e-20)
+            assert rel <= 2.0 * DRIFT * float(g[key]) + 5e-3, (k, rel, float(g[key]))
 
 
 # ------------------------------------------------------------------------------ the benchmarked BATCH shapes (r03)

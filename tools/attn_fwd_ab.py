@@ -1,7 +1,8 @@
 #!/usr/bin/env python
 """Same-box A/B of forms of the event-level attention FORWARD (mh_set_option("attn_v3") values given on the command line):
 numerics against the default form on the same inputs (O max / rms difference, lse max difference) and interleaved timing with
-HIP events at B=16, H=16, S in {2048, 4096}.  Usage: python tools/attn_fwd_ab.py 127 255"""
+HIP events at B=16, H=16, S in {2048, 4096}.  A form is "bits" or "bits:wps" (attn_v3_wps: register budget / stages variant).
+Usage: python tools/attn_fwd_ab.py 127 255 127:4 255:4"""
 import os
 import sys
 
@@ -10,7 +11,16 @@ import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from midi_model_amd import ops  # noqa: E402
 
-forms = [int(x) for x in sys.argv[1:]] or [127, 255]
+forms = sys.argv[1:] or ["127", "255"]
+
+
+def select(f):  # "bits[:wps[:passes]]"
+    parts = f.split(":") + ["", ""]
+    ops.set_option("attn_v3", int(parts[0]))
+    ops.set_option("attn_v3_wps", int(parts[1]) if parts[1] else 0)
+    ops.set_option("attn_passes", int(parts[2]) if parts[2] else 5)
+
+
 B, H = 16, 16
 D = H * 64
 for S in (2048, 4096, 1000):
@@ -19,7 +29,7 @@ for S in (2048, 4096, 1000):
     Sp = (S + 63) // 64 * 64
     outs = {}
     for f in forms:
-        ops.set_option("attn_v3", f)
+        select(f)
         o = torch.empty((B * S, D), dtype=torch.bfloat16, device="cuda")
         lse = torch.zeros(B * H * Sp, device="cuda")
         ops.attn_fwd(qkv, o, lse, B, S, H, 0.125)
@@ -38,7 +48,7 @@ for S in (2048, 4096, 1000):
     lse = torch.zeros(B * H * Sp, device="cuda")
     for rep in range(12):
         for f in forms:
-            ops.set_option("attn_v3", f)
+            select(f)
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
             for _ in range(5):
@@ -48,7 +58,24 @@ for S in (2048, 4096, 1000):
             if rep >= 2:
                 times[f].append(e0.elapsed_time(e1) / 5 * 1e3)
     fl = 4.0 * 64 * S * (S + 1) / 2 * B * H
+    # the backward pair of the same form (same work order option), interleaved likewise
+    do = torch.randn((B * S, D), generator=g, device="cuda", dtype=torch.float32).to(torch.bfloat16)
+    dqkv = torch.empty_like(qkv)
+    btimes = {f: [] for f in forms}
+    for rep in range(8):
+        for f in forms:
+            select(f)
+            ops.attn_fwd(qkv, o, lse, B, S, H, 0.125)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(3):
+                ops.attn_bwd(qkv, o, do, lse, dqkv, B, S, H, 0.125)
+            e1.record()
+            torch.cuda.synchronize()
+            if rep >= 2:
+                btimes[f].append(e0.elapsed_time(e1) / 3 * 1e3)
     for f in forms:
-        t = sorted(times[f])
-        print(f"S={S} form {f}: median {t[len(t) // 2]:.1f} us (min {t[0]:.1f}, max {t[-1]:.1f}) = {fl / (t[len(t) // 2] * 1e-6) / 1e12:.0f} TFLOP/s")
-ops.set_option("attn_v3", 127)
+        t, bt = sorted(times[f]), sorted(btimes[f])
+        print(f"S={S} form {f}: fwd median {t[len(t) // 2]:.1f} us (min {t[0]:.1f}, max {t[-1]:.1f}) = {fl / (t[len(t) // 2] * 1e-6) / 1e12:.0f} TFLOP/s; "
+              f"bwd median {bt[len(bt) // 2]:.1f} us (min {bt[0]:.1f})")
+select("127")

@@ -17,6 +17,7 @@ from midi_model_amd.lib import lib  # noqa: E402
 
 S = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
 lazy = int(sys.argv[2]) if len(sys.argv) > 2 else 0
+first = int(sys.argv[3]) if len(sys.argv) > 3 else 8   # first recorded key tile of each workgroup's loop
 B, H = 16, 16
 D = H * 64
 g = torch.Generator(device="cuda").manual_seed(0)
@@ -25,7 +26,10 @@ o = torch.empty((B * S, D), device="cuda", dtype=torch.bfloat16)
 Sp = (S + 63) // 64 * 64
 lse = torch.zeros(B * H * Sp, device="cuda")
 NWG, NW, NT, NS = 16, 4, 32, 9
-st = torch.zeros(NWG * NW * NT * NS, dtype=torch.int32, device="cuda")
+nqt = (S + 127) // 128
+GRID = nqt * 8 * ((B * H + 7) // 8)
+st = torch.zeros(NWG * NW * NT * NS + GRID * 8 + 1, dtype=torch.int32, device="cuda")
+st[-1] = first
 stream = torch.cuda.current_stream().cuda_stream
 for _ in range(2):
     lib().call("mh_attn_fwd_timeline", qkv.data_ptr(), o.data_ptr(), lse.data_ptr(), B, S, H, 0.125, lazy, st.data_ptr(), stream)
@@ -47,10 +51,10 @@ e1.record()
 torch.cuda.synchronize()
 t_prod = e0.elapsed_time(e1) / 5 * 1e3
 print(f"# attention forward B={B} H={H} S={S} lazy={lazy}: production form {t_prod:.1f} us, instrumented build {t_tl:.1f} us per launch")
-a = (st.cpu().view(NWG, NW, NT, NS).to(torch.int64) & 0xffffffff)
+a = (st[:NWG * NW * NT * NS].cpu().view(NWG, NW, NT, NS).to(torch.int64) & 0xffffffff)
 names = ["LDS-DMA issue (4 requests)", "K reads issue (8 b128)", "S MFMAs + V^T reads issue", "softmax arithmetic",
          "wait V^T fragments", "P V MFMAs issue", "wait next tile's DMA (vmcnt)", "barrier"]
-print("# shader cycles per segment, averaged over the recorded tiles (8 .. 39 of the workgroup's loop); one line per wave")
+print(f"# shader cycles per segment, averaged over the recorded tiles ({first} .. {first + 31} of the workgroup's loop); one line per wave")
 print("# wg wave  " + "  ".join(f"{n[:14]:>14s}" for n in names) + "    tile period   valid tiles")
 tot = torch.zeros(len(names))
 cnt = 0
@@ -81,3 +85,42 @@ for w in range(min(NWG, 4)):
     rel = s[:, ok, 8].float()
     print(f"# wg {w}: barrier arrival spread (max - min over the 4 waves) mean {float((arr.max(0).values - arr.min(0).values).mean()):.0f} cycles; "
           f"release - last arrival mean {float((rel.min(0).values - arr.max(0).values).mean()):.0f}")
+
+# ---- residency census: every workgroup's [start, end] on its CU ------------------------------------------------------------
+c = (st[NWG * NW * NT * NS:-1].cpu().view(GRID, 8).to(torch.int64) & 0xffffffff)
+t0 = c[:, 0] | (c[:, 1] << 32)
+t1 = c[:, 2] | (c[:, 3] << 32)
+hw, xcc, tiles = c[:, 4], c[:, 5] & 0xf, c[:, 6]
+cu, sh, se = (hw >> 8) & 0xf, (hw >> 12) & 1, (hw >> 13) & 0x7
+key = (xcc << 12) | (se << 8) | (sh << 4) | cu
+ok = t1 > t0
+for x in range(8):
+    mk = ok & (xcc == x)
+    if int(mk.sum()):
+        span = (t1[mk].max() - t0[mk].min()).item()
+        print(f"# XCD {x}: {int(mk.sum())} workgroups, span {span} ticks = {span / t_tl:.0f} ticks per us of the instrumented launch; heaviest workgroup "
+              f"{int((t1 - t0)[mk].max())} ticks for {int(tiles[mk][(t1 - t0)[mk].argmax()])} tiles")
+print(f"# census: {int(ok.sum())} of {GRID} workgroups recorded; distinct (xcc, se, sh, cu) = {len(set(key[ok].tolist()))}; "
+      f"kernel span {(t1[ok].max() - t0[ok].min()).item()} ticks of s_memtime; workgroup life mean {float((t1 - t0)[ok].float().mean()):.0f} "
+      f"max {int((t1 - t0)[ok].max())}; ticks per key tile (life / tiles) mean {float(((t1 - t0)[ok].float() / tiles[ok].float()).mean()):.0f}")
+import collections
+per = collections.defaultdict(list)
+for k, a0, a1 in zip(key[ok].tolist(), t0[ok].tolist(), t1[ok].tolist()):
+    per[k].append((a0, a1))
+avg, peak = [], []
+for k, iv in per.items():
+    ev = sorted([(x, 1) for x, _ in iv] + [(y, -1) for _, y in iv])
+    cur = mx = 0
+    area = 0
+    last = ev[0][0]
+    for t, d in ev:
+        area += cur * (t - last)
+        last = t
+        cur += d
+        mx = max(mx, cur)
+    span = ev[-1][0] - ev[0][0]
+    avg.append(area / max(span, 1))
+    peak.append(mx)
+avg_t, peak_t = torch.tensor(avg), torch.tensor(peak)
+print(f"# workgroups resident per CU: time-average mean {float(avg_t.mean()):.2f} (min {float(avg_t.min()):.2f}, max {float(avg_t.max()):.2f}); "
+      f"peak mean {float(peak_t.float().mean()):.2f} (min {int(peak_t.min())}, max {int(peak_t.max())}); workgroups per CU mean {GRID / max(len(per), 1):.1f}")

@@ -50,4 +50,24 @@ rope = RopeTable(64, 10000.0, torch.device("cuda"), S)
 out_line.append(f"rope[{M}x{3 * D}x{D}] {timeit(lambda: ops.gemm_rope(x, wq, qkv, rope.fused(), S, 0, 64), 2.0 * M * 3 * D * D):6.0f}")
 out_line.append(f"swiglu[{M}x{2 * I}x{D}] {timeit(lambda: ops.gemm_swiglu(x, wg, None, act), 2.0 * M * 2 * I * D):6.0f}")
 chk += float(qkv.float().abs().mean()) + float(act.float().abs().mean())
+# r06: the row-scaled forms of the folded block, the training forms (gate|up stored; SwiGLU backward), the statistics producer
+rs = (0.5 + torch.rand((M,), device="cuda", generator=g)).float()
+out_line.append(f"rope_scaled {timeit(lambda: ops.gemm_rope(x, wq, qkv, rope.fused(), S, 0, 64, rowscale=rs), 2.0 * M * 3 * D * D):6.0f}")
+out_line.append(f"swiglu_scaled {timeit(lambda: ops.gemm_swiglu(x, wg, None, act, rowscale=rs), 2.0 * M * 2 * I * D):6.0f}")
+chk += float(qkv.float().abs().mean()) + float(act.float().abs().mean())
+Mt = 32768
+xt = x[:Mt]
+gu = torch.empty((Mt, 2 * I), device="cuda", dtype=torch.bfloat16)
+out_line.append(f"swiglu_train[{Mt}x{2 * I}x{D}] {timeit(lambda: ops.gemm_swiglu(xt, wg, gu, act[:Mt]), 2.0 * Mt * 2 * I * D):6.0f}")
+wd = (torch.randn((D, I), device="cuda", generator=g) * 0.05).to(torch.bfloat16)
+dgu = torch.empty_like(gu)
+out_line.append(f"dswiglu[{Mt}x{I}x{D}] {timeit(lambda: ops.gemm_dswiglu(xt, wd, gu, dgu), 2.0 * Mt * I * D):6.0f}")
+chk += float(gu.float().abs().mean()) + float(dgu.float().abs().mean())
+parts = torch.empty((D // 64, M), device="cuda")
+wo = (torch.randn((D, D), device="cuda", generator=g) * 0.05).to(torch.bfloat16)
+x2 = torch.empty((M, D), device="cuda", dtype=torch.bfloat16)
+out_line.append(f"rowss[{M}x{D}x{D}] {timeit(lambda: ops.gemm_rowss(x, wo, x2, parts, res=x), 2.0 * M * D * D):6.0f}")
+wdn = (torch.randn((D, I), device="cuda", generator=g) * 0.05).to(torch.bfloat16)
+out_line.append(f"rowss[{M}x{D}x{I}] {timeit(lambda: ops.gemm_rowss(act, wdn, x2, parts, res=x), 2.0 * M * D * I):6.0f}")
+chk += float(x2.float().abs().mean()) + float(parts.mean())
 print(f"{tag:>22s} TF: " + " | ".join(out_line) + f" | checksum {chk:.6f}", flush=True)
