@@ -106,6 +106,30 @@ def cpu_baseline(sample_S: int, seed: int = 0):
             "loss": float(loss.detach())}
 
 
+def cpu_baseline_config0(seed: int = 0):
+    """BASELINE.json configs[0]: tv2o-medium MIDIModel.forward on the CPU, batch 1 x 128 events, fp32 (the reference's own
+    CPU-runnable case) -- the oracle's forward on the host cores, best of three calls."""
+    orc = _load_oracle()
+    orc.FUSED_SDPA = True
+    import midi_model_amd as mm
+    cores = min(os.cpu_count() or 1, 32)
+    torch.set_num_threads(cores)
+    tok = mm.MIDITokenizerV2()
+    shp = orc.Shape(vocab=tok.vocab_size)
+    with torch.no_grad():
+        sd = orc.make_state_dict(shp, seed=seed)
+        x = orc.synthetic_events(tok, 1, 128, seed=seed)
+        best = None
+        for _ in range(3):
+            t0 = time.perf_counter()
+            h = orc.midi_forward(sd, shp, x)
+            dt = time.perf_counter() - t0
+            best = dt if best is None else min(best, dt)
+    assert tuple(h.shape) == (1, 128, shp.n_embd)
+    return {"value": 128 / best, "unit": "events/s", "ms_per_call": 1e3 * best, "cores": cores, "kind": "port",
+            "sample": "MIDIModel.forward, batch 1 x 128 events, fp32, CPU oracle (BASELINE.json configs[0]); best of 3 calls"}
+
+
 def cpu_baseline_generate(batch: int, n_events: int, seed: int = 0):
     """The oracle's KV-cached generate() (fp32, host cores): `batch` sequences x `n_events` new events, EOS masked."""
     orc = _load_oracle()
@@ -931,7 +955,7 @@ def main():
                 out[key] = {"error": repr(e)}
         if rank == 0 and not args.no_cpu_baseline and isinstance(out.get("generate"), dict) and "error" not in out["generate"]:
             try:  # the CPU oracle's generate() beside the GPU number (bounded sample: batch 64 x 8 events)
-                out["generate"]["cpu_baseline"] = cpu_baseline_generate(args.gen_batch, 8)
+                out["generate"]["cpu_baseline"] = cpu_baseline_generate(args.gen_batch, 32)  # batch 64 for 32 events
             except Exception as e:
                 out["generate"]["cpu_baseline"] = {"value": None, "unit": "events/s", "cores": os.cpu_count(), "kind": "port",
                                                    "sample": f"failed: {e!r}"}
@@ -939,6 +963,7 @@ def main():
         if world == 1 and not multi and not args.no_cpu_baseline:
             try:
                 out["cpu_baseline"] = cpu_baseline(args.cpu_sample_seq)
+                out["cpu_baseline"]["config0_forward"] = cpu_baseline_config0()
             except Exception as e:  # the baseline is a report, never a reason to lose the GPU number
                 out["cpu_baseline"] = {"value": None, "unit": "events/s", "cores": os.cpu_count(), "kind": "port",
                                        "sample": f"failed: {e!r}"}
