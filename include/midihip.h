@@ -114,6 +114,28 @@ int mh_gemm_rope_scaled(const void* A, int64_t lda, const void* W, int64_t ldw, 
                         int dtype, void* stream);
 int mh_gemm_swiglu_scaled(const void* A, int64_t lda, const void* W, int64_t ldw, void* GU, int64_t ldgu, void* ACT, int64_t ldact,
                           const float* rowscale, int64_t M, int64_t I, int64_t K, int dtype, void* stream);
+/* ---- the TRAINING form of the folded RMSNorm (r06; engine.layer_forward_train_folded / layer_backward_folded) ----------------------
+ * Forward: the q|k|v and gate|up projections take the residual stream x itself, multiply by W' = W (.) w (mh_scale_cols) and scale
+ * their rows by rstd (mh_gemm_rope_scaled / mh_gemm_swiglu_scaled / mh_gemm_nt_scaled); rstd comes from the producing projection's
+ * statistics (mh_gemm_rowss + mh_row_rstd): the normalised activations are never written, read or kept for the backward.
+ * Backward: the producers of the projections' output gradients store d z = rstd (.) d y (mh_gemm_dswiglu_scaled, mh_attn_bwd_o_scaled,
+ * mh_tokattn_bwd_scaled); t = d z W' (mh_gemm, the folded weights, contraction-major); dx = t - x (rstd^2 / D) rowdot(t, x) + dres
+ * (mh_rmsnorm_bwd_folded); the weight gradient G' = d z^T x is reduced by mh_gemm_splitk_reduce_fold, which applies the chain rule
+ * through the fold: dW = G' (.) w (+ beta R) and per-block partial column sums of dw = colsum(G' (.) W) in `colpart`
+ * [mh_splitk_fold_blocks(M), N] fp32 (fold them with mh_colsum).  bf16, production GEMM kernel. */
+int mh_gemm_nt_scaled(const void* A, int64_t lda, const void* B, int64_t ldb, void* C, int64_t ldc, const float* rowscale, int64_t M,
+                      int64_t N, int64_t K, int dtype, void* stream);
+int mh_gemm_dswiglu_scaled(const void* A, int64_t lda, const void* B, int64_t ldb, const void* GU, int64_t ldgu, void* DGU,
+                           int64_t lddgu, const float* rowscale, int64_t M, int64_t I, int64_t K, int dtype, void* stream);
+int mh_splitk_fold_blocks(int64_t M);
+int mh_gemm_splitk_reduce_fold(const void* workspace, void* C, int64_t ldc, const void* R, int64_t ldr, int64_t M, int64_t N,
+                               int splitk, float alpha, float beta, const void* wnorm, const void* W, int64_t ldw, float* colpart,
+                               int dtype, void* stream);
+int mh_rmsnorm_bwd_folded(const void* x, const float* rstd, const void* t, const void* dres, void* dx, int64_t M, int D, int dtype,
+                          void* stream);
+int mh_scale_cols(const void* W, int64_t ldw, const void* w, void* out, int64_t ldo, int64_t Nr, int K, int dtype, void* stream);
+/* mh_scale_cols for a list of contiguous [rows, K] matrices in ONE launch: jobs (device memory) = njobs x {W, w, out, rows} as int64 */
+int mh_scale_cols_batched(const int64_t* jobs, int njobs, int K, int dtype, void* stream);
 int mh_gemm_splitk_reduce(const void* workspace, void* C, int64_t ldc, const void* R, int64_t ldr, int64_t M,
                           int64_t N, int splitk, float alpha, float beta, int dtype, void* stream);
 /* Skinny projection of the decode step (replaces the per-token nn.Linear calls of LlamaAttention / LlamaMLP /
@@ -234,6 +256,10 @@ int mh_attn_bwd(const void* qkv, const void* dout, const float* lse, const float
  * is selected (mh_set_option("attn_v3")): use the two calls above.                                                      */
 int mh_attn_bwd_o(const void* qkv, const void* o, const void* dout, const float* lse, float* delta, void* dqkv, int64_t B,
                   int64_t S, int H, float scale, const float* cos_t, const float* sin_t, int dtype, void* stream);
+/* mh_attn_bwd_o with row m = b * S + position of dqkv multiplied by rowscale[m] in the kernels' stores (the folded RMSNorm's d z) */
+int mh_attn_bwd_o_scaled(const void* qkv, const void* o, const void* dout, const float* lse, float* delta, void* dqkv,
+                         const float* rowscale, int64_t B, int64_t S, int H, float scale, const float* cos_t, const float* sin_t,
+                         int dtype, void* stream);
 /* measurement aid, A/B library only (the production library returns MH_ERR_UNSUPPORTED): the production bf16 forward with shader-clock
  * stamps at the seams of each key tile's segments; stamps: uint32 [16][4][32][9] (tools/attn_timeline.py decodes them).        */
 int mh_attn_fwd_timeline(const void* qkv, void* o, float* lse, int64_t B, int64_t S, int H, float scale, int lazy,
@@ -255,6 +281,9 @@ int mh_tokattn_fwd(const void* qkv, void* o, int64_t N, int T, int H, float scal
                    int dtype, void* stream);
 int mh_tokattn_bwd(const void* qkv, const void* dout, void* dqkv, int64_t N, int T, int H, float scale, const float* cos_t,
                    const float* sin_t, int dtype, void* stream);
+/* the same with row m = n * T + t of dqkv multiplied by rowscale[m] in the stores (the folded RMSNorm's d z) */
+int mh_tokattn_bwd_scaled(const void* qkv, const void* dout, void* dqkv, const float* rowscale, int64_t N, int T, int H, float scale,
+                          const float* cos_t, const float* sin_t, int dtype, void* stream);
 
 /* ---- SwiGLU (TF:models/llama/modeling_llama.py:174-176) -------------------------------------------------
  * gu[M,2I] = [gate | up];  a = silu(gate) * up;  dgu = [da*up*silu'(gate) | da*silu(gate)]            */

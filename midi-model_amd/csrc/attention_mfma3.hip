@@ -50,7 +50,9 @@ thread_local int g_attn_v3 = attn_env_int("MH_ATTN_V3", 255);     // mh_set_opti
 // and 1939 -> 1879 us; P = 2 / 3 / 8 / 16 lie between (more passes re-fetch K/V panels more often: at S = 4096 they no longer
 // fit the Infinity Cache together).  Identical results.
 thread_local int g_attn_passes = attn_env_int("MH_ATTN_PASSES", 5);
-thread_local int g_attn_v3_wps = attn_env_int("MH_ATTN_V3_WPS", 0);  // mh_set_option("attn_v3_wps", n): register budget (waves per SIMD) override for A/B runs, 0 = default
+thread_local int g_attn_v3_wps = attn_env_int("MH_ATTN_V3_WPS", 0);
+// row scale of the NEXT backward launched by this thread (mh_attn_bwd_o_scaled sets it around its call; NULL otherwise)
+thread_local const float* g_attn_bwd_rowscale = nullptr;  // mh_set_option("attn_v3_wps", n): register budget (waves per SIMD) override for A/B runs, 0 = default
 
 __device__ inline bf16x8 ldsv(const char* p) { return *reinterpret_cast<const bf16x8*>(p); }
 // eight consecutive accumulator registers -> one bf16 operand fragment, as four explicit two-element conversions (each one
@@ -541,7 +543,8 @@ __global__ __launch_bounds__(256, WPS) void attn_bwd_dq3_kernel(const bf16* __re
                                                               const float* __restrict__ cos_t,
                                                               const float* __restrict__ sin_t,
                                                               const bf16* __restrict__ o_ /* != NULL: delta is computed here */,
-                                                              float* __restrict__ delta_w) {
+                                                              float* __restrict__ delta_w,
+                                                              const float* __restrict__ rowscale /* != NULL: row m of dqkv times rowscale[m] */) {
   extern __shared__ __attribute__((aligned(16))) char smem[];  // [stage][K | V | K^T], or [stage][K | V] with transpose reads
   constexpr int NT = TR ? 2 : 3;  // tiles per stage
   const int tid = threadIdx.x, lane = tid & 63;
@@ -661,7 +664,10 @@ __global__ __launch_bounds__(256, WPS) void attn_bwd_dq3_kernel(const bf16* __re
   }
   if (qrow < S) {
     bf16* orow = dqkv + (b * S + qrow) * D3 + (int64_t)h * HD;
-    store_grad_row(orow, dqacc, -scale, hi, cos_t, sin_t, qrow);  // (the accumulator holds -dQ)
+    // (rowscale, r06: the q|k|v projection sits behind a FOLDED RMSNorm -- the stored gradient is the one of the unscaled
+    //  product x W'^T, rstd (.) d qkv, which both the folded dgrad and the folded weight gradient take)
+    const float rsc = rowscale != nullptr ? rowscale[b * S + qrow] : 1.f;
+    store_grad_row(orow, dqacc, -scale * rsc, hi, cos_t, sin_t, qrow);  // (the accumulator holds -dQ)
   }
 }
 
@@ -785,7 +791,8 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv3_kernel(const bf16* __res
                                                                const bf16* __restrict__ qt_, const bf16* __restrict__ dot_,
                                                                bf16* __restrict__ dqkv, int S, int Sp, int H, float scale,
                                                                int BH, int nkt, const float* __restrict__ cos_t,
-                                                               const float* __restrict__ sin_t) {
+                                                               const float* __restrict__ sin_t,
+                                                               const float* __restrict__ rowscale /* see attn_bwd_dq3_kernel */) {
   // one stage: [Q | dO | Q^T | dO^T | lse (256 B of a KiB) | delta (256 B of a KiB)], with transpose reads [Q | dO | lse | delta]
   constexpr int NT = TR ? 2 : 4, STG = NT * TILE64 + 2048;
   extern __shared__ __attribute__((aligned(16))) char smem[];  // 2 stages
@@ -899,8 +906,9 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv3_kernel(const bf16* __res
   }
   if (krow < S) {
     bf16* krow_out = dqkv + (b * S + krow) * D3 + D + (int64_t)h * HD;
-    store_grad_row(krow_out, dkacc, -scale, hi, cos_t, sin_t, krow);  // (the accumulator holds -dK)
-    store_grad_row(krow_out + D, dvacc, 1.f, hi, nullptr, nullptr, 0);
+    const float rsc = rowscale != nullptr ? rowscale[b * S + krow] : 1.f;
+    store_grad_row(krow_out, dkacc, -scale * rsc, hi, cos_t, sin_t, krow);  // (the accumulator holds -dK)
+    store_grad_row(krow_out + D, dvacc, rsc, hi, nullptr, nullptr, 0);
   }
 }
 
@@ -990,7 +998,7 @@ int mh_attn_bwd_mfma3(const void* qkv, const void* dout, const float* lse, const
   attn_bwd_dq3_kernel<WPS, TR_><<<grid, 256, (TR_ ? 4 : 6) * TILE64, st>>>((const bf16*)qkv, (const bf16*)dout, lse, delta,     \
                                                                         (const bf16*)kt, (bf16*)dqkv, (int)S, (int)Sp, H, scale, \
                                                                         BH, nt, cos_t, sin_t, (const bf16*)o,         \
-                                                                        const_cast<float*>(delta))
+                                                                        const_cast<float*>(delta), g_attn_bwd_rowscale)
   if (which & 2) {
     if (g_attn_v3_wps == 2) {
       if (tr) MH_DQ(2, true); else MH_DQ(2, false);
@@ -1005,15 +1013,15 @@ int mh_attn_bwd_mfma3(const void* qkv, const void* dout, const float* lse, const
       attn_bwd_dkv3_kernel<true, true><<<grid, 256, 2 * (2 * TILE64 + 2048), st>>>((const bf16*)qkv, (const bf16*)dout,
                                                                                  delta + (int64_t)BH0 * Sp, delta, nullptr, nullptr,
                                                                                  (bf16*)dqkv, (int)S, (int)Sp, H, scale, BH, nt,
-                                                                                 cos_t, sin_t);
+                                                                                 cos_t, sin_t, g_attn_bwd_rowscale);
     else if (tr)
       attn_bwd_dkv3_kernel<true><<<grid, 256, 2 * (2 * TILE64 + 2048), st>>>((const bf16*)qkv, (const bf16*)dout, lse, delta, nullptr,
                                                                            nullptr, (bf16*)dqkv, (int)S, (int)Sp, H, scale, BH, nt,
-                                                                           cos_t, sin_t);
+                                                                           cos_t, sin_t, g_attn_bwd_rowscale);
     else
       attn_bwd_dkv3_kernel<false><<<grid, 256, 2 * DKV_STAGE, st>>>((const bf16*)qkv, (const bf16*)dout, lse, delta, (const bf16*)qt,
                                                                   (const bf16*)dot, (bf16*)dqkv, (int)S, (int)Sp, H, scale, BH, nt,
-                                                                  cos_t, sin_t);
+                                                                  cos_t, sin_t, g_attn_bwd_rowscale);
     MH_LAUNCH_CHECK();
   }
   return MH_OK;

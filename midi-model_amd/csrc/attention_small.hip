@@ -190,7 +190,8 @@ __global__ __launch_bounds__(256) void tokattn_fwd_kernel(const T* __restrict__ 
 template <typename T, int TN>
 __global__ __launch_bounds__(256) void tokattn_bwd_kernel(const T* __restrict__ qkv, const T* __restrict__ dout,
                                                           T* __restrict__ dqkv, int64_t NH, int Tn, int H, float scale,
-                                                          const float* __restrict__ cos_t, const float* __restrict__ sin_t) {
+                                                          const float* __restrict__ cos_t, const float* __restrict__ sin_t,
+                                                          const float* __restrict__ rowscale /* != NULL: row m of dqkv times rowscale[m] */) {
   const int lane = threadIdx.x & 63;
   const int64_t D = (int64_t)H * 256, D3 = 3 * D;
   // RoPE on load and its transpose on the way out (cos_t != nullptr): qkv is the unrotated projection output and dqkv
@@ -212,6 +213,9 @@ __global__ __launch_bounds__(256) void tokattn_bwd_kernel(const T* __restrict__ 
     T* ob = dqkv + n * Tn * D3 + off;
     float k[TK][4], v[TK][4], dk[TK][4], dv[TK][4];
     RawRow<T> qraw[TN ? TN : 1], doraw[TN ? TN : 1];
+    // (the sequence's <= 8 row scales in ONE load beside the operand rows -- lane t holds row t's; broadcast below by lane index:
+    //  a scalar load per stored row sat on the critical path of this bandwidth-bound kernel, +12 % on the launch)
+    const float rs_lane = (rowscale != nullptr && lane < Tn) ? rowscale[n * Tn + lane] : 1.f;
 #pragma unroll
     for (int t = 0; t < TK; ++t)
 #pragma unroll
@@ -290,12 +294,25 @@ __global__ __launch_bounds__(256) void tokattn_bwd_kernel(const T* __restrict__ 
         }
       }
       if (rot) rope_row<T>(dq, rope_c, rope_s, i, lane, -1.f, false);
+      if (rowscale != nullptr) {  // (the projection behind a folded RMSNorm takes rstd (.) d qkv: mh_tokattn_bwd_scaled)
+        const float rsc = __shfl(rs_lane, i, 64);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) dq[e] *= rsc;
+      }
       stp<T>(ob + i * D3, lane, dq);
     }
 #pragma unroll
     for (int t = 0; t < TK; ++t) {
       if (TN ? t < TN : t < Tn) {
         if (rot) rope_row<T>(dk[t], rope_c, rope_s, t, lane, -1.f, false);
+        if (rowscale != nullptr) {
+          const float rsc = __shfl(rs_lane, t, 64);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            dk[t][e] *= rsc;
+            dv[t][e] *= rsc;
+          }
+        }
         stp<T>(ob + t * D3 + D, lane, dk[t]);
         stp<T>(ob + t * D3 + 2 * D, lane, dv[t]);
       }
@@ -319,20 +336,30 @@ extern "C" int mh_tokattn_fwd(const void* qkv, void* o, int64_t N, int Tn, int H
   return MH_OK;
 }
 
-extern "C" int mh_tokattn_bwd(const void* qkv, const void* dout, void* dqkv, int64_t N, int Tn, int H, float scale,
-                              const float* cos_t, const float* sin_t, int dtype, void* stream) {
+static int tokattn_bwd_any(const void* qkv, const void* dout, void* dqkv, const float* rowscale, int64_t N, int Tn, int H, float scale,
+                           const float* cos_t, const float* sin_t, int dtype, void* stream) {
   MH_REQUIRE(N > 0 && Tn >= 1 && Tn <= TK && H >= 1, "tokattn_bwd: bad shape");
   const int64_t NH = N * H;
   int64_t g = (NH + 3) / 4;
   if (g > 32768) g = 32768;
   if (Tn == TK)
     DISPATCH_T(dtype, (tokattn_bwd_kernel<T, TK><<<(int)g, 256, 0, (hipStream_t)stream>>>(
-                          (const T*)qkv, (const T*)dout, (T*)dqkv, NH, Tn, H, scale, cos_t, sin_t)));
+                          (const T*)qkv, (const T*)dout, (T*)dqkv, NH, Tn, H, scale, cos_t, sin_t, rowscale)));
   else
     DISPATCH_T(dtype, (tokattn_bwd_kernel<T, 0><<<(int)g, 256, 0, (hipStream_t)stream>>>(
-                          (const T*)qkv, (const T*)dout, (T*)dqkv, NH, Tn, H, scale, cos_t, sin_t)));
+                          (const T*)qkv, (const T*)dout, (T*)dqkv, NH, Tn, H, scale, cos_t, sin_t, rowscale)));
   MH_LAUNCH_CHECK();
   return MH_OK;
+}
+extern "C" int mh_tokattn_bwd(const void* qkv, const void* dout, void* dqkv, int64_t N, int Tn, int H, float scale,
+                              const float* cos_t, const float* sin_t, int dtype, void* stream) {
+  return tokattn_bwd_any(qkv, dout, dqkv, nullptr, N, Tn, H, scale, cos_t, sin_t, dtype, stream);
+}
+// mh_tokattn_bwd with row m = n * T + t of dqkv multiplied by rowscale[m] in the stores (the folded RMSNorm's d z)
+extern "C" int mh_tokattn_bwd_scaled(const void* qkv, const void* dout, void* dqkv, const float* rowscale, int64_t N, int Tn, int H,
+                                     float scale, const float* cos_t, const float* sin_t, int dtype, void* stream) {
+  MH_REQUIRE(rowscale != nullptr, "tokattn_bwd_scaled: rowscale is NULL");
+  return tokattn_bwd_any(qkv, dout, dqkv, rowscale, N, Tn, H, scale, cos_t, sin_t, dtype, stream);
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -1068,6 +1095,21 @@ extern "C" int mh_attn_bwd(const void* qkv, const void* dout, const float* lse, 
   }
   mh_set_error("attn_bwd: bad dtype");
   return MH_ERR_ARG;
+}
+
+extern thread_local const float* g_attn_bwd_rowscale;  // attention_mfma3.hip
+extern thread_local int g_attn_v3;
+// mh_attn_bwd_o with every row m of dqkv multiplied by rowscale[m] (m = b * S + position) in the kernels' stores: the gradient
+// handed to a projection that sits behind a folded RMSNorm (engine.layer_backward_folded).  Third-form kernels only.
+extern "C" int mh_attn_bwd_o_scaled(const void* qkv, const void* o, const void* dout, const float* lse, float* delta, void* dqkv,
+                                    const float* rowscale, int64_t B, int64_t S, int H, float scale, const float* cos_t,
+                                    const float* sin_t, int dtype, void* stream) {
+  MH_REQUIRE(rowscale != nullptr, "attn_bwd_o_scaled: rowscale is NULL");
+  MH_REQUIRE((g_attn_v3 & 46) == 46, "attn_bwd_o_scaled: needs the third form of the backward kernels (attn_v3 bits 1, 2, 3, 5)");
+  g_attn_bwd_rowscale = rowscale;
+  const int rc = mh_attn_bwd_o(qkv, o, dout, lse, delta, dqkv, B, S, H, scale, cos_t, sin_t, dtype, stream);
+  g_attn_bwd_rowscale = nullptr;
+  return rc;
 }
 
 extern "C" int mh_attn_bwd_o(const void* qkv, const void* o, const void* dout, const float* lse, float* delta, void* dqkv,

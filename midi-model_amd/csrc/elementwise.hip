@@ -698,6 +698,151 @@ extern "C" int mh_rmsnorm_bwd(const void* x, const void* w, const float* rstd, c
   return MH_OK;
 }
 
+// ---- the backward of a FOLDED RMSNorm (r06; engine.layer_backward_folded) -----------------------------------------------------------
+// Forward: z = x W'^T with W' = W (.) w, y = rstd (.) z (LlamaRMSNorm + nn.Linear, TF:models/llama/modeling_llama.py:62-67).  The
+// producers of d y store d z = rstd (.) d y, the dgrad on the folded weights gives t = d z W' (= rstd (.) (d h (.) w) of the
+// unfolded graph), and what is left of the norm's backward is   dx = t - x (rstd^2 / D) rowdot(t, x) + dres   -- no weight vector,
+// no weight-gradient column sums (those come out of the weight-gradient reduction: mh_gemm_splitk_reduce_fold).  One wave per
+// row, the row in registers (D = NCH * 64 * 16 bytes) or two passes; non-temporal above the Infinity Cache size as mh_rmsnorm_bwd.
+template <typename T, int NCH, bool NT>
+__global__ __launch_bounds__(256) void rmsnorm_bwd_folded_kernel(const T* __restrict__ x, const float* __restrict__ rstd,
+                                                                 const T* __restrict__ t, const T* dres, T* dx, int64_t M, int D) {
+  constexpr int N = Pack<T>::N;
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  for (int64_t m = (int64_t)blockIdx.x * 4 + wv; m < M; m += (int64_t)gridDim.x * 4) {
+    const float r = rstd[m];
+    if constexpr (NCH > 0) {
+      Pack<T> xv[NCH], tv[NCH], rv[NCH];
+#pragma unroll
+      for (int k = 0; k < NCH; ++k) {
+        const int64_t c = m * D + (k * 64 + lane) * N;
+        if constexpr (NT) {
+          xv[k].v = __builtin_nontemporal_load(reinterpret_cast<const decltype(xv[k].v)*>(x + c));
+          tv[k].v = __builtin_nontemporal_load(reinterpret_cast<const decltype(tv[k].v)*>(t + c));
+          if (dres != nullptr) rv[k].v = __builtin_nontemporal_load(reinterpret_cast<const decltype(rv[k].v)*>(dres + c));
+        } else {
+          xv[k] = ld16(x + c);
+          tv[k] = ld16(t + c);
+          if (dres != nullptr) rv[k] = ld16(dres + c);
+        }
+      }
+      float dot = 0.f;
+#pragma unroll
+      for (int k = 0; k < NCH; ++k)
+#pragma unroll
+        for (int e = 0; e < N; ++e) dot += tv[k].get(e) * xv[k].get(e);
+      const float cf = r * r * wave_sum(dot) / (float)D;
+#pragma unroll
+      for (int k = 0; k < NCH; ++k) {
+        Pack<T> o;
+#pragma unroll
+        for (int e = 0; e < N; ++e) {
+          float d = tv[k].get(e) - xv[k].get(e) * cf;
+          if (dres != nullptr) d += rv[k].get(e);
+          o.set(e, d);
+        }
+        if constexpr (NT) __builtin_nontemporal_store(o.v, reinterpret_cast<decltype(o.v)*>(dx + m * D + (k * 64 + lane) * N));
+        else st16(dx + m * D + (k * 64 + lane) * N, o);
+      }
+    } else {
+      float dot = 0.f;
+      for (int c = lane * N; c < D; c += 64 * N) {
+        Pack<T> xv = ld16(x + m * D + c), tv = ld16(t + m * D + c);
+#pragma unroll
+        for (int e = 0; e < N; ++e) dot += tv.get(e) * xv.get(e);
+      }
+      const float cf = r * r * wave_sum(dot) / (float)D;
+      for (int c = lane * N; c < D; c += 64 * N) {
+        Pack<T> xv = ld16(x + m * D + c), tv = ld16(t + m * D + c), o, rv;
+        if (dres != nullptr) rv = ld16(dres + m * D + c);
+#pragma unroll
+        for (int e = 0; e < N; ++e) {
+          float d = tv.get(e) - xv.get(e) * cf;
+          if (dres != nullptr) d += rv.get(e);
+          o.set(e, d);
+        }
+        st16(dx + m * D + c, o);
+      }
+    }
+  }
+}
+
+extern "C" int mh_rmsnorm_bwd_folded(const void* x, const float* rstd, const void* t, const void* dres, void* dx, int64_t M, int D,
+                                     int dtype, void* stream) {
+  MH_REQUIRE(M > 0 && D % 8 == 0 && x != nullptr && rstd != nullptr && t != nullptr && dx != nullptr, "rmsnorm_bwd_folded: bad arguments M=%ld D=%d", (long)M, D);
+  const int blocks = (int)grid_for(M, 4, 65536);
+  const int nch = D / (dtype == MH_BF16 ? 512 : 256);
+  const bool reg = nch * (dtype == MH_BF16 ? 512 : 256) == D && (nch == 1 || nch == 2 || nch == 4);
+  const bool nt = M * (int64_t)D * (dtype == MH_BF16 ? 2 : 4) > (int64_t(192) << 20);
+#define MH_RMSBF(NCH_)                                                                                                    \
+  do {                                                                                                                   \
+    if (nt)                                                                                                              \
+      DISPATCH_T(dtype, (rmsnorm_bwd_folded_kernel<T, NCH_, true><<<blocks, 256, 0, (hipStream_t)stream>>>(                \
+                            (const T*)x, rstd, (const T*)t, (const T*)dres, (T*)dx, M, D)));                              \
+    else                                                                                                                 \
+      DISPATCH_T(dtype, (rmsnorm_bwd_folded_kernel<T, NCH_, false><<<blocks, 256, 0, (hipStream_t)stream>>>(               \
+                            (const T*)x, rstd, (const T*)t, (const T*)dres, (T*)dx, M, D)));                              \
+  } while (0)
+  if (reg && nch == 1) MH_RMSBF(1);
+  else if (reg && nch == 2) MH_RMSBF(2);
+  else if (reg && nch == 4) MH_RMSBF(4);
+  else MH_RMSBF(0);
+#undef MH_RMSBF
+  MH_LAUNCH_CHECK();
+  return MH_OK;
+}
+
+// out[n, k] = W[n, k] * w[k]: the norm weight folded into the projection that follows it (engine.fold_norm_weights; rounded once,
+// from the fp32 product, as the torch spelling `(W.float() * w.float()).to(bf16)` it replaces)
+template <typename T>
+__global__ __launch_bounds__(256) void scale_cols_kernel(const T* __restrict__ W, int64_t ldw, const T* __restrict__ w, T* __restrict__ out,
+                                                         int64_t ldo, int64_t Nr, int K) {
+  constexpr int N = Pack<T>::N;
+  const int cpr = K / N;
+  const int64_t total = Nr * cpr;
+  for (int64_t it = (int64_t)blockIdx.x * 256 + threadIdx.x; it < total; it += (int64_t)gridDim.x * 256) {
+    const int64_t n = it / cpr;
+    const int c = (int)(it - n * cpr) * N;
+    Pack<T> a = ld16(W + n * ldw + c), b = ld16(w + c), o;
+#pragma unroll
+    for (int e = 0; e < N; ++e) o.set(e, a.get(e) * b.get(e));
+    st16(out + n * ldo + c, o);
+  }
+}
+// the same for a LIST of matrices in one launch: jobs[j] = {W, w, out, rows} (device pointers as 64-bit integers, contiguous
+// [rows, K] matrices); blockIdx.y = job.  The training step re-derives thirty folded matrices after every optimizer step.
+template <typename T>
+__global__ __launch_bounds__(256) void scale_cols_batched_kernel(const int64_t* __restrict__ jobs, int K) {
+  constexpr int N = Pack<T>::N;
+  const int64_t* jb = jobs + 4 * (int64_t)blockIdx.y;
+  const T* W = reinterpret_cast<const T*>(jb[0]);
+  const T* w = reinterpret_cast<const T*>(jb[1]);
+  T* out = reinterpret_cast<T*>(jb[2]);
+  const int cpr = K / N;
+  const int64_t total = jb[3] * cpr;
+  for (int64_t it = (int64_t)blockIdx.x * 256 + threadIdx.x; it < total; it += (int64_t)gridDim.x * 256) {
+    const int c = (int)(it % cpr) * N;
+    Pack<T> a = ld16(W + it * N), b = ld16(w + c), o;
+#pragma unroll
+    for (int e = 0; e < N; ++e) o.set(e, a.get(e) * b.get(e));
+    st16(out + it * N, o);
+  }
+}
+extern "C" int mh_scale_cols_batched(const int64_t* jobs, int njobs, int K, int dtype, void* stream) {
+  MH_REQUIRE(jobs != nullptr && njobs > 0 && njobs < 65536 && K > 0 && K % 8 == 0, "scale_cols_batched: bad arguments");
+  DISPATCH_T(dtype, (scale_cols_batched_kernel<T><<<dim3(1024, (unsigned)njobs), 256, 0, (hipStream_t)stream>>>(jobs, K)));
+  MH_LAUNCH_CHECK();
+  return MH_OK;
+}
+extern "C" int mh_scale_cols(const void* W, int64_t ldw, const void* w, void* out, int64_t ldo, int64_t Nr, int K, int dtype, void* stream) {
+  MH_REQUIRE(Nr > 0 && K > 0 && K % 8 == 0 && ldw % 8 == 0 && ldo % 8 == 0 && ldw >= K && ldo >= K, "scale_cols: bad shape");
+  MH_REQUIRE((((uintptr_t)W | (uintptr_t)w | (uintptr_t)out) & 15) == 0, "scale_cols: 16-byte alignment");
+  DISPATCH_T(dtype, (scale_cols_kernel<T><<<grid_for(Nr * (K / 4), 256, 16384), 256, 0, (hipStream_t)stream>>>(
+                        (const T*)W, ldw, (const T*)w, (T*)out, ldo, Nr, K)));
+  MH_LAUNCH_CHECK();
+  return MH_OK;
+}
+
 // Column sums of the [nblk, D] fp32 partials, deterministic, in two stages so that more than D/256 blocks
 // work: stage A folds each of NSPLIT row ranges into the range's first row (in place: a block only touches
 // its own rows x 64 columns), stage B adds the NSPLIT surviving rows.

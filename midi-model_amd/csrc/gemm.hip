@@ -13,6 +13,8 @@
 //   * The MFMA is issued "swapped" (B rows as the MFMA row index) so each lane ends with 4 consecutive
 //     output columns -> 8/16-byte stores.
 //   * split-K (grid.z) for the weight-gradient shapes (small M,N, huge K): fp32 partials + reduce kernel.
+#include <type_traits>
+
 #include "common.h"
 
 __device__ __attribute__((aligned(16))) char g_zero16[16];
@@ -300,10 +302,29 @@ static int gemm_launch(const void* A, int64_t lda, int ta, const void* B, int64_
   return MH_OK;
 }
 
+template <bool FOLD>
+__global__ __launch_bounds__(256) void splitk_reduce4_kernel(const float* __restrict__ ws, bf16* __restrict__ C, int64_t ldc,
+                                                             const bf16* R, int64_t ldr, int64_t M, int64_t N, int splitk,
+                                                             float alpha, float beta, const bf16* __restrict__ wnorm,
+                                                             const bf16* __restrict__ W, int64_t ldw, float* __restrict__ colpart);
+
 template <typename T>
 static int splitk_reduce_launch(const void* workspace, void* C, int64_t ldc, const void* R, int64_t ldr, int64_t M,
                                 int64_t N, int splitk, float alpha, float beta, hipStream_t st) {
   MH_REQUIRE(M > 0 && N > 0 && splitk >= 1 && workspace != nullptr, "splitk_reduce: bad args");
+  if constexpr (std::is_same<T, bf16>::value) {
+    // r06: four columns per thread, 16-byte loads of the partials (the scalar form below moved 4 bytes per load: the reductions of
+    // a training step, 4.2 GB of partials, ran at 4.1 TB/s); same sums in the same order
+    if (N % 4 == 0 && ldc % 4 == 0 && (R == nullptr || ldr % 4 == 0) && (((uintptr_t)C | (uintptr_t)R) & 7) == 0 &&
+        ((uintptr_t)workspace & 15) == 0) {
+      const int64_t rows_y = M < 1024 ? M : 1024;
+      dim3 grid((unsigned)((N / 4 + 255) / 256), (unsigned)rows_y);
+      splitk_reduce4_kernel<false><<<grid, 256, 0, st>>>((const float*)workspace, (bf16*)C, ldc, (const bf16*)R, ldr, M, N, splitk, alpha,
+                                                         beta, nullptr, nullptr, 0, nullptr);
+      MH_LAUNCH_CHECK();
+      return MH_OK;
+    }
+  }
   const int64_t total = M * N;
   const int blocks = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
   splitk_reduce_kernel<T><<<blocks, 256, 0, st>>>((const float*)workspace, (T*)C, ldc, (const T*)R, ldr, M, N, splitk,
@@ -334,7 +355,9 @@ extern "C" int mh_gemm(const void* A, int64_t lda, int transA, const void* B, in
 }
 
 int mh_gemm_pp256_dswiglu_bf16(const void* A, int64_t lda, const void* B, int64_t ldb, const void* GU, int64_t ldgu,
-                               void* DGU, int64_t lddgu, int64_t M, int64_t I, int64_t K, hipStream_t st);  // gemm_pp256.hip
+                               void* DGU, int64_t lddgu, int64_t M, int64_t I, int64_t K, hipStream_t st, const float* rowscale);  // gemm_pp256.hip
+int mh_gemm_pp256_scaled_bf16(const void* A, int64_t lda, const void* B, int64_t ldb, void* C, int64_t ldc, int64_t M, int64_t N,
+                              int64_t K, const float* rowscale, hipStream_t st);  // gemm_pp256.hip
 
 int mh_gemm_pp256_swiglu_bf16(const void* A, int64_t lda, const void* W, int64_t ldw, void* GU, int64_t ldgu, void* ACT,
                               int64_t ldact, int64_t M, int64_t I, int64_t K, hipStream_t st, const float* rowscale);  // gemm_pp256.hip
@@ -424,7 +447,103 @@ extern "C" int mh_gemm_dswiglu(const void* A, int64_t lda, const void* B, int64_
                  lddgu >= 2 * I,
              "gemm_dswiglu: leading dimensions must be multiples of 8 elements and cover the rows");
   MH_REQUIRE((((uintptr_t)A | (uintptr_t)B | (uintptr_t)GU | (uintptr_t)DGU) & 15) == 0, "gemm_dswiglu: 16-byte alignment");
-  return mh_gemm_pp256_dswiglu_bf16(A, lda, B, ldb, GU, ldgu, DGU, lddgu, M, I, K, (hipStream_t)stream);
+  return mh_gemm_pp256_dswiglu_bf16(A, lda, B, ldb, GU, ldgu, DGU, lddgu, M, I, K, (hipStream_t)stream, nullptr);
+}
+
+extern "C" int mh_gemm_dswiglu_scaled(const void* A, int64_t lda, const void* B, int64_t ldb, const void* GU, int64_t ldgu,
+                                      void* DGU, int64_t lddgu, const float* rowscale, int64_t M, int64_t I, int64_t K, int dtype,
+                                      void* stream) {
+  MH_REQUIRE(dtype == MH_BF16 && g_mh_gemm_variant != 0, "gemm_dswiglu_scaled: served by the production bf16 kernel only");
+  MH_REQUIRE(rowscale != nullptr && ((uintptr_t)rowscale & 15) == 0, "gemm_dswiglu_scaled: rowscale must be a 16-byte aligned fp32 [M]");
+  MH_REQUIRE(M > 0 && I > 0 && K > 0 && I % 8 == 0, "gemm_dswiglu_scaled: bad shape M=%ld I=%ld K=%ld", (long)M, (long)I, (long)K);
+  MH_REQUIRE(lda % 8 == 0 && ldb % 8 == 0 && ldgu % 8 == 0 && lddgu % 8 == 0 && lda >= K && ldb >= I && ldgu >= 2 * I &&
+                 lddgu >= 2 * I,
+             "gemm_dswiglu_scaled: leading dimensions must be multiples of 8 elements and cover the rows");
+  MH_REQUIRE((((uintptr_t)A | (uintptr_t)B | (uintptr_t)GU | (uintptr_t)DGU) & 15) == 0, "gemm_dswiglu_scaled: 16-byte alignment");
+  return mh_gemm_pp256_dswiglu_bf16(A, lda, B, ldb, GU, ldgu, DGU, lddgu, M, I, K, (hipStream_t)stream, rowscale);
+}
+
+extern "C" int mh_gemm_nt_scaled(const void* A, int64_t lda, const void* B, int64_t ldb, void* C, int64_t ldc,
+                                 const float* rowscale, int64_t M, int64_t N, int64_t K, int dtype, void* stream) {
+  MH_REQUIRE(dtype == MH_BF16 && g_mh_gemm_variant != 0, "gemm_nt_scaled: served by the production bf16 kernel only");
+  MH_REQUIRE(rowscale != nullptr && ((uintptr_t)rowscale & 15) == 0, "gemm_nt_scaled: rowscale must be a 16-byte aligned fp32 [M]");
+  MH_REQUIRE(M > 0 && N > 0 && K > 0, "gemm_nt_scaled: empty problem");
+  MH_REQUIRE(lda % 8 == 0 && ldb % 8 == 0 && lda >= K && ldb >= K && ldc >= N, "gemm_nt_scaled: leading dimensions");
+  MH_REQUIRE((((uintptr_t)A | (uintptr_t)B) & 15) == 0, "gemm_nt_scaled: 16-byte alignment");
+  MH_REQUIRE(((M + 255) / 256) * ((N + 255) / 256) < (1ll << 30), "gemm_nt_scaled: too many tiles");
+  return mh_gemm_pp256_scaled_bf16(A, lda, B, ldb, C, ldc, M, N, K, rowscale, (hipStream_t)stream);
+}
+
+// ---- the weight gradient of a projection behind a FOLDED RMSNorm (r06) ------------------------------------------------------------
+// The folded forward multiplies x by W' = W (.) w (w = the norm weight, along the contraction), so the split-K weight-gradient
+// GEMM delivers G' = d z^T x, the gradient with respect to W'.  This reduction of its fp32 partials applies the chain rule in
+// the same pass:  dW[n,k] = alpha G'[n,k] w[k] (+ beta R[n,k]),  and block partials of  dw[k] = sum_n alpha G'[n,k] W[n,k]  (fp32,
+// [mh_splitk_fold_blocks(M)][N]; mh_colsum folds them, deterministic).  Rows of the output are the projection's output features.
+// Also the vectorised form of the plain reduction: four columns per thread, 16-byte partial loads.
+constexpr int SKF_MAX_BLOCKS = 256;
+extern "C" int mh_splitk_fold_blocks(int64_t M) { return (int)(M < SKF_MAX_BLOCKS ? (M < 1 ? 1 : M) : SKF_MAX_BLOCKS); }
+
+template <bool FOLD>
+__global__ __launch_bounds__(256) void splitk_reduce4_kernel(const float* __restrict__ ws, bf16* __restrict__ C, int64_t ldc,
+                                                             const bf16* R, int64_t ldr, int64_t M, int64_t N, int splitk,
+                                                             float alpha, float beta, const bf16* __restrict__ wnorm,
+                                                             const bf16* __restrict__ W, int64_t ldw, float* __restrict__ colpart) {
+  const int64_t c = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4;
+  if (c >= N) return;  // (N % 4 == 0: whole groups)
+  const int64_t total = M * N;
+  float wn[4] = {1.f, 1.f, 1.f, 1.f}, cs[4] = {0.f, 0.f, 0.f, 0.f};
+  if constexpr (FOLD) {
+    const bf16x4 w4 = *reinterpret_cast<const bf16x4*>(wnorm + c);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) wn[e] = (float)w4[e];
+  }
+  const bool use_r = (R != nullptr && beta != 0.f);
+  for (int64_t m = blockIdx.y; m < M; m += gridDim.y) {
+    f32x4 s = *reinterpret_cast<const f32x4*>(ws + m * N + c);
+    for (int z = 1; z < splitk; ++z) {
+      const f32x4 p = *reinterpret_cast<const f32x4*>(ws + (int64_t)z * total + m * N + c);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) s[e] += p[e];
+    }
+    float x[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) x[e] = alpha * s[e];
+    if constexpr (FOLD) {
+      const bf16x4 W4 = *reinterpret_cast<const bf16x4*>(W + m * ldw + c);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        cs[e] += x[e] * (float)W4[e];
+        x[e] *= wn[e];
+      }
+    }
+    if (use_r) {
+      const bf16x4 r4 = *reinterpret_cast<const bf16x4*>(R + m * ldr + c);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) x[e] += beta * (float)r4[e];
+    }
+    bf16x4 o;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) o[e] = (bf16)x[e];
+    *reinterpret_cast<bf16x4*>(C + m * ldc + c) = o;
+  }
+  if constexpr (FOLD) *reinterpret_cast<f32x4*>(colpart + (int64_t)blockIdx.y * N + c) = f32x4{cs[0], cs[1], cs[2], cs[3]};
+}
+
+extern "C" int mh_gemm_splitk_reduce_fold(const void* workspace, void* C, int64_t ldc, const void* R, int64_t ldr, int64_t M,
+                                          int64_t N, int splitk, float alpha, float beta, const void* wnorm, const void* W,
+                                          int64_t ldw, float* colpart, int dtype, void* stream) {
+  MH_REQUIRE(dtype == MH_BF16, "splitk_reduce_fold: bf16 only");
+  MH_REQUIRE(M > 0 && N > 0 && N % 4 == 0 && splitk >= 1 && workspace != nullptr && wnorm != nullptr && W != nullptr && colpart != nullptr,
+             "splitk_reduce_fold: bad args (N must be a multiple of 4)");
+  MH_REQUIRE(ldc % 4 == 0 && ldw % 4 == 0 && ldw >= N && (R == nullptr || ldr % 4 == 0) &&
+                 (((uintptr_t)C | (uintptr_t)W | (uintptr_t)wnorm | (uintptr_t)R) & 7) == 0 && ((uintptr_t)workspace & 15) == 0 &&
+                 ((uintptr_t)colpart & 15) == 0,
+             "splitk_reduce_fold: alignment");
+  dim3 grid((unsigned)((N / 4 + 255) / 256), (unsigned)mh_splitk_fold_blocks(M));
+  splitk_reduce4_kernel<true><<<grid, 256, 0, (hipStream_t)stream>>>((const float*)workspace, (bf16*)C, ldc, (const bf16*)R, ldr, M, N,
+                                                                      splitk, alpha, beta, (const bf16*)wnorm, (const bf16*)W, ldw, colpart);
+  MH_LAUNCH_CHECK();
+  return MH_OK;
 }
 
 extern "C" int mh_gemm_nt(const void* A, int64_t lda, const void* B, int64_t ldb, void* C, int64_t ldc,

@@ -442,9 +442,11 @@ __global__ __launch_bounds__(512, 2) void gemm_pp256_kernel(const bf16* __restri
                                                             float alpha, float beta, int tiles_n, int nwg,
                                                             int64_t k_per_split, float* __restrict__ ws,
                                                             const void* __restrict__ zero16, float* aux, int lean_epi) {
-  static_assert(NRM == 0 || (ML == 1 && ABL == 0 && !TA && !TB), "the norm forms ride on the K-step-64 row-major loop only");
+  static_assert(NRM == 0 || (ML == 1 && ABL == 0 && !TA && (!TB || (EPI == 1 && NRM == 2))), "the norm forms ride on the K-step-64 loops only");
   static_assert(NRM != 1 || EPI == 0, "sum-of-squares partials come out of the plain epilogue");
-  static_assert(NRM != 2 || EPI == 2 || EPI == 3, "the row scale is applied by the SwiGLU / RoPE epilogues");
+  // (r06: the row scale also on the plain epilogue -- the token-level q|k|v projection of the folded training forward -- and on the
+  //  SwiGLU-backward epilogue, which then delivers d z = rstd (.) d gate|up, the gradient of the UNSCALED product x W'^T: the
+  //  operand both the folded dgrad and the folded weight gradient take; engine.layer_backward_folded)
   extern __shared__ __attribute__((aligned(16))) char smem[];
   // ABL != 0 builds are micro-benchmarks with wrong results (tools/bench_gemm.py): 1 = no LDS-DMA after the pipeline
   // fill, 2 = no fragment reads, 4 = no MFMA, 8 = row-major pieces fetch whole 128-byte lines (8 rows x 128 B),
@@ -650,7 +652,9 @@ __global__ __launch_bounds__(512, 2) void gemm_pp256_kernel(const bf16* __restri
 #pragma unroll
           for (int fn = 0; fn < 4; ++fn) {
             const int row = fmh * 16 + fi, ch = fn * 4 + fg;
-            *reinterpret_cast<f32x4*>(wreg + row * 256 + ((ch ^ (row & 15)) << 4)) = acc[fn][half * 4 + fmh];
+            f32x4 t4 = acc[fn][half * 4 + fmh];
+            if constexpr (NRM == 2) t4 *= rs[half * 4 + fmh];  // (d a scaled by the row's rstd: SwiGLU' is linear in it)
+            *reinterpret_cast<f32x4*>(wreg + row * 256 + ((ch ^ (row & 15)) << 4)) = t4;
           }
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
@@ -703,7 +707,9 @@ __global__ __launch_bounds__(512, 2) void gemm_pp256_kernel(const bf16* __restri
 #pragma unroll
         for (int fn = 0; fn < 4; ++fn) {
           const int row = fmh * 16 + fi, ch = fn * 4 + fg;
-          *reinterpret_cast<f32x4*>(wreg + row * 256 + ((ch ^ (row & 15)) << 4)) = acc[fn][half * 4 + fmh];
+          f32x4 t4 = acc[fn][half * 4 + fmh];
+          if constexpr (NRM == 2) t4 *= rs[half * 4 + fmh];
+          *reinterpret_cast<f32x4*>(wreg + row * 256 + ((ch ^ (row & 15)) << 4)) = t4;
         }
       if (half == 0) request(1);
 #pragma unroll
@@ -1042,7 +1048,9 @@ __global__ __launch_bounds__(512, 2) void gemm_pp256_kernel(const bf16* __restri
 #pragma unroll
         for (int fn = 0; fn < 4; ++fn) {
           const int row = fmh * 16 + fi, ch = fn * 4 + fg;
-          *reinterpret_cast<f32x4*>(wreg + row * 256 + ((ch ^ (row & 15)) << 4)) = acc[fn][half * 4 + fmh];
+          f32x4 t4 = acc[fn][half * 4 + fmh];
+          if constexpr (NRM == 2) t4 *= rs[half * 4 + fmh];  // (plain epilogue with a row scale: mh_gemm_nt_scaled)
+          *reinterpret_cast<f32x4*>(wreg + row * 256 + ((ch ^ (row & 15)) << 4)) = t4;
         }
 #pragma unroll
       for (int i = 0; i < 8; ++i) {  // 8 rows x 128 B per instruction
@@ -1105,7 +1113,9 @@ __global__ __launch_bounds__(512, 2) void gemm_pp256_kernel(const bf16* __restri
 #pragma unroll
         for (int fn = 0; fn < 4; ++fn) {
           const int row = fmh * 16 + fi, ch = fn * 4 + fg;
-          *reinterpret_cast<f32x4*>(wreg + row * 256 + ((ch ^ (row & 15)) << 4)) = acc[fn][half * 4 + fmh];
+          f32x4 t4 = acc[fn][half * 4 + fmh];
+          if constexpr (NRM == 2) t4 *= rs[half * 4 + fmh];  // (plain epilogue with a row scale: mh_gemm_nt_scaled)
+          *reinterpret_cast<f32x4*>(wreg + row * 256 + ((ch ^ (row & 15)) << 4)) = t4;
         }
 #pragma unroll
       for (int i = 0; i < 8; ++i) {  // 8 rows x 128 B per instruction
@@ -1165,6 +1175,7 @@ __global__ __launch_bounds__(512, 2) void gemm_pp256_kernel(const bf16* __restri
       const int64_t n = n0 + wn * 64 + fn * 16 + fg * 4;
       if (n >= N) continue;
       f32x4 v = acc[fn][fm];
+      if constexpr (NRM == 2) v *= rs[fm];
       if (partial) {
         float* dst = wsz + m * N + n;
         if (vec_ok && n + 3 < N) {
@@ -1333,9 +1344,24 @@ int mh_gemm_pp256_rope_bf16(const void* A, int64_t lda, const void* W, int64_t l
   return launch_one<false, false, 0, 3>(A, lda, W, ldw, C, ldc, table, S | (pos0 << 32), M, N, K, 1.f, 0.f, 1, nullptr, st);
 }
 
+// C = rowscale (.) (A * B^T), both operands row-major (K-step-64 loop): the plain epilogue with the row scale of the folded
+// RMSNorm (NRM 2) -- the token-level q|k|v projection of the folded training forward, whose RoPE rides in the attention kernel
+int mh_gemm_pp256_scaled_bf16(const void* A, int64_t lda, const void* B, int64_t ldb, void* C, int64_t ldc, int64_t M, int64_t N,
+                              int64_t K, const float* rowscale, hipStream_t st) {
+  MH_REQUIRE(g_mh_gemm_k64 != 0 && M % 4 == 0, "gemm_nt_scaled: needs the K-step-64 main loop and M %% 4 == 0");
+  return launch_one<false, false, 0, 0, 1, 2>(A, lda, B, ldb, C, ldc, nullptr, 0, M, N, K, 1.f, 0.f, 1, nullptr, st,
+                                              const_cast<float*>(rowscale));
+}
+
 // d gate | d up = SwiGLU'(gate|up) applied to A * B^T (A row-major [M,K], B contraction-major [K,I]); gemm.hip validates
+// (rowscale != NULL: d a times rowscale[m] first, i.e. the result is rowscale (.) d gate|up -- the folded norm's d z)
 int mh_gemm_pp256_dswiglu_bf16(const void* A, int64_t lda, const void* B, int64_t ldb, const void* GU, int64_t ldgu,
-                               void* DGU, int64_t lddgu, int64_t M, int64_t I, int64_t K, hipStream_t st) {
+                               void* DGU, int64_t lddgu, int64_t M, int64_t I, int64_t K, hipStream_t st, const float* rowscale) {
+  if (rowscale != nullptr) {
+    MH_REQUIRE(g_mh_gemm_k64 == 1 && M % 4 == 0, "gemm_dswiglu_scaled: needs the K-step-64 dgrad loop and M %% 4 == 0");
+    return launch_one<false, true, 0, 1, 1, 2>(A, lda, B, ldb, DGU, lddgu, GU, ldgu, M, I, K, 1.f, 0.f, 1, nullptr, st,
+                                               const_cast<float*>(rowscale));
+  }
   if (g_mh_gemm_k64 == 1) return launch_one<false, true, 0, 1, 1>(A, lda, B, ldb, DGU, lddgu, GU, ldgu, M, I, K, 1.f, 0.f, 1, nullptr, st);
   return launch_one<false, true, 0, 1>(A, lda, B, ldb, DGU, lddgu, GU, ldgu, M, I, K, 1.f, 0.f, 1, nullptr, st);
 }

@@ -11,6 +11,8 @@ import math
 from dataclasses import dataclass, field
 from typing import Callable, List, Optional
 
+import os
+
 import torch
 
 from . import ops
@@ -205,6 +207,99 @@ def layer_forward_folded(spec: StackSpec, lw: LayerTensors, fold, x: torch.Tenso
     return x3, parts
 
 
+def train_fold_ok(spec: StackSpec, x: torch.Tensor) -> bool:
+    """whether the TRAINING forward / backward of stack ``spec`` over the rows ``x`` can run with its RMSNorms folded around
+    the projections (layer_forward_train_folded / layer_backward_folded): bf16 on the production GEMM with its K-step-64 loops,
+    the fused SwiGLU epilogues in both directions, whole 64-column statistics chunks, 4-row groups, and -- event-level stack --
+    the RoPE epilogue and the one-call attention backward"""
+    ok = (x.dtype == torch.bfloat16 and ops.swiglu_fused_ok(x, spec.I) and ops.dswiglu_ok(x, spec.I) and spec.D % 64 == 0
+          and x.shape[0] % 4 == 0 and ops.get_option("gemm_k64") == 1 and os.environ.get("MH_NORM_FOLD_TRAIN", "1") != "0")
+    if ok and spec.kind == "event":
+        ok = ops.rope_fused_ok(x, spec.hd) and ops.attn_bwd_scaled_ok(x)
+    return ok
+
+
+def layer_forward_train_folded(spec: StackSpec, lw: LayerTensors, fold, x: torch.Tensor, nseq: int, slen: int, rope: RopeTable,
+                               parts_in: Optional[torch.Tensor], lean: bool = False):
+    """layer_forward(save=True) with both RMSNorms folded around the projections (r06; LlamaDecoderLayer.forward,
+    TF:models/llama/modeling_llama.py:295-324, LlamaRMSNorm :62-67): the q|k|v and gate|up projections read the residual stream
+    itself against ``fold`` = (wqkv * n1, wgu * n2) and scale their rows by rstd, whose statistics the PRODUCING projections (o,
+    down: mh_gemm_rowss) leave behind.  The normalised activations h1 / h2 are never written, read or kept: two passes over the
+    residual stream and a fifth of the saved activations less per layer.  Both stacks (token-level: RoPE stays inside the attention
+    kernel, the q|k|v projection is the plain GEMM with a row scale).  Returns (output, its statistics, what the backward needs)."""
+    M, D = x.shape
+    H, I = spec.H, spec.I
+    wq_n, wgu_n = fold
+    rstd1 = _empty((M,), x, torch.float32)
+    if parts_in is not None:
+        ops.row_rstd(rstd1, D, spec.eps, parts=parts_in)
+    else:
+        ops.row_rstd(rstd1, D, spec.eps, x=x)
+    qkv = _empty((M, 3 * D), x)
+    o = _empty((M, D), x)
+    lse = None
+    if spec.kind == "event":
+        ops.gemm_rope(x, wq_n, qkv, rope.fused(), slen, 0, spec.hd, rowscale=rstd1)
+        lse = _empty((nseq * H * ops.round_up(slen, 64),), x, torch.float32)
+        ops.attn_fwd(qkv, o, lse, nseq, slen, H, spec.scale)
+    else:
+        ops.gemm_nt_scaled(x, wq_n, qkv, rstd1)
+        ops.tokattn_fwd(qkv, o, nseq, slen, H, spec.scale, rope.cos, rope.sin)
+    parts = _empty((D // 64, M), x, torch.float32)
+    x2 = _empty((M, D), x)
+    ops.gemm_rowss(o, lw.wo, x2, parts, res=x)
+    rstd2 = _empty((M,), x, torch.float32)
+    ops.row_rstd(rstd2, D, spec.eps, parts=parts)
+    gu = _empty((M, 2 * I), x)
+    a = _empty((M, I), x)
+    ops.gemm_swiglu(x2, wgu_n, gu, a, rowscale=rstd2)
+    parts3 = _empty((D // 64, M), x, torch.float32)
+    x3 = _empty((M, D), x)
+    ops.gemm_rowss(a, lw.wd, x3, parts3, res=x2)
+    return x3, parts3, (x, rstd1, qkv, o, lse, x2, rstd2, gu, None if lean else a)
+
+
+def layer_backward_folded(spec: StackSpec, lw: LayerTensors, lg: LayerTensors, fold, keep, dx: torch.Tensor, nseq: int, slen: int,
+                          rope: RopeTable, accumulate: bool) -> torch.Tensor:
+    """The backward of layer_forward_train_folded.  With z = x W'^T, y = rstd (.) z: the producers of d y store d z = rstd (.) d y
+    (the SwiGLU-backward epilogue, the attention backward's stores), t = d z W' is the dgrad on the folded weights,
+    dx = t - x (rstd^2 / D) rowdot(t, x) + dres the norm's backward without its weight, and the weight gradient G' = d z^T x
+    turns into dW = G' (.) w and dw = colsum(G' (.) W) inside its split-K reduction (ops.wgrad_folded)."""
+    x, rstd1, qkv, o, lse, x2, rstd2, gu, a = keep
+    M, D = dx.shape
+    H, I = spec.H, spec.I
+    wq_n, wgu_n = fold
+    # ---- MLP ----
+    if a is None:
+        a = _empty((M, I), dx)
+        ops.swiglu_fwd(gu, a)
+    dz2 = _empty((M, 2 * I), dx)
+    ops.gemm_dswiglu(dx, lw.wd, gu, dz2, rowscale=rstd2)     # rstd2 (.) SwiGLU'(gate|up) (dx @ wd)
+    linear_wgrad(dx, a, lg.wd, accumulate)
+    del a
+    t2 = _empty((M, D), dx)
+    ops.gemm_nt(dz2, wgu_n, t2, tb=True)                     # t2 = d z2 @ W'gu
+    ops.wgrad_folded(dz2, x2, lg.wgu, lw.n2, lw.wgu, lg.n2, accumulate)
+    del dz2
+    dx2 = _empty((M, D), dx)
+    ops.rmsnorm_bwd_folded(x2, rstd2, t2, dx, dx2)
+    # ---- attention ----
+    do = t2                                                  # reuse
+    ops.gemm_nt(dx2, lw.wo, do, tb=True)
+    linear_wgrad(dx2, o, lg.wo, accumulate)
+    dz1 = _empty((M, 3 * D), dx)
+    if spec.kind == "event":
+        ops.attn_bwd(qkv, o, do, lse, dz1, nseq, slen, H, spec.scale, rope.cos, rope.sin, rowscale=rstd1)
+    else:
+        ops.tokattn_bwd(qkv, do, dz1, nseq, slen, H, spec.scale, rope.cos, rope.sin, rowscale=rstd1)
+    t1 = do
+    ops.gemm_nt(dz1, wq_n, t1, tb=True)                      # t1 = d z1 @ W'qkv
+    ops.wgrad_folded(dz1, x, lg.wqkv, lw.n1, lw.wqkv, lg.n1, accumulate)
+    del dz1
+    ops.rmsnorm_bwd_folded(x, rstd1, t1, dx2, dx)
+    return dx
+
+
 def stack_forward(spec: StackSpec, W: StackTensors, x: torch.Tensor, nseq: int, slen: int, rope: RopeTable,
                   save: bool, kv_out: Optional[list] = None, lean: bool = False, folded=None):
     """x [nseq*slen, D] (inputs_embeds) -> last_hidden_state [nseq*slen, D].
@@ -227,6 +322,17 @@ def stack_forward(spec: StackSpec, W: StackTensors, x: torch.Tensor, nseq: int, 
         ops.rmsnorm_fwd(x, W.norm, y, None, spec.eps)
         return y, None
     saved = []
+    if save and folded is not None and kv_out is None and train_fold_ok(spec, x):
+        # the TRAINING forward with folded RMSNorms (r06): ``folded`` = the weights of this step (the caller re-derives them after
+        # every update: MIDIModel.folded_weights); the backward finds them in the context
+        parts = None
+        for lw, fold in zip(W.layers, folded):
+            x, parts, keep = layer_forward_train_folded(spec, lw, fold, x, nseq, slen, rope, parts, lean)
+            saved.append(keep)
+        y = _empty((M, D), x)
+        rstdf = _empty((M,), x, torch.float32)
+        ops.rmsnorm_fwd(x, W.norm, y, rstdf, spec.eps)
+        return y, (saved, x, rstdf, nseq, slen, folded)
     for lw in W.layers:
         x3, keep = layer_forward(spec, lw, x, nseq, slen, rope, kv_out, save, lean and save)
         if save:
@@ -243,11 +349,19 @@ def stack_backward(spec: StackSpec, W: StackTensors, G: StackTensors, ctx, dy: t
     """dy = d loss / d last_hidden_state  ->  d loss / d inputs_embeds; parameter gradients go to G
     (overwritten, or added to when `accumulate`).  `on_layer_done(i)` fires when layer i's gradients are
     final (layers finish in reverse order) — the data-parallel reducer hangs its bucket launches on it."""
-    saved, x_last, rstdf, nseq, slen = ctx
+    folded = ctx[5] if len(ctx) > 5 else None
+    saved, x_last, rstdf, nseq, slen = ctx[:5]
     M, D = dy.shape
     H, I = spec.H, spec.I
     dx = _empty((M, D), dy)
     ops.rmsnorm_bwd(x_last, W.norm, rstdf, dy, None, dx, G.norm, accumulate)
+    if folded is not None:  # the forward ran layer_forward_train_folded
+        for li in range(len(W.layers) - 1, -1, -1):
+            dx = layer_backward_folded(spec, W.layers[li], G.layers[li], folded[li], saved[li], dx, nseq, slen, rope, accumulate)
+            saved[li] = None
+            if on_layer_done is not None:
+                on_layer_done(li)
+        return dx
     for li in range(len(W.layers) - 1, -1, -1):
         lw, lg = W.layers[li], G.layers[li]
         x, rstd1, h1, qkv, o, lse, x2, rstd2, h2, gu, a = saved[li]
@@ -387,11 +501,30 @@ def fold_norm_weights(W: StackTensors, out=None):
     decode path's one-launch norm + projection (mh_gemm_skinny with norm_eps).  Derived data: with ``out`` (a list this
     function returned earlier) the copies are rewritten in place, which is how a decode session follows weight updates."""
     if out is None:
-        out = [(torch.empty_like(lw.wqkv), torch.empty_like(lw.wgu)) for lw in W.layers]
+        out = _FoldList((torch.empty_like(lw.wqkv), torch.empty_like(lw.wgu)) for lw in W.layers)
+    if W.layers and W.layers[0].wqkv.is_cuda and all(lw.wqkv.is_contiguous() and lw.wgu.is_contiguous() for lw in W.layers):
+        # ONE launch for the whole stack (the training step re-derives the fold after every optimizer step): the job table is
+        # built once per list -- the matrices are views of the flat parameter buffer and the copies are rewritten in place
+        jobs = getattr(out, "jobs", None)
+        key = (W.layers[0].wqkv.data_ptr(), out[0][0].data_ptr())
+        if jobs is None or jobs[0] != key:
+            trip = []
+            for lw, (fq, fg) in zip(W.layers, out):
+                trip += [(lw.wqkv, lw.n1, fq), (lw.wgu, lw.n2, fg)]
+            jobs = (key, ops.scale_cols_jobs(trip))
+            if isinstance(out, _FoldList):
+                out.jobs = jobs
+        ops.scale_cols_batched(jobs[1], W.layers[0].wqkv.shape[1], W.layers[0].wqkv)
+        return out
     for lw, (fq, fg) in zip(W.layers, out):
         fq.copy_(lw.wqkv.float() * lw.n1.float()[None, :])
         fg.copy_(lw.wgu.float() * lw.n2.float()[None, :])
     return out
+
+
+class _FoldList(list):
+    """fold_norm_weights' result: a list of (wqkv * n1, wgu * n2) that can carry the job table of its one-launch refresh"""
+    jobs = None
 
 
 def stack_decode(spec: StackSpec, W: StackTensors, x: torch.Tensor, rope: RopeTable, kv: KVState, pos_dev=None,

@@ -263,9 +263,10 @@ def dswiglu_ok(dx: torch.Tensor, I: int) -> bool:
     return dx.dtype == torch.bfloat16 and I % 8 == 0 and get_option("gemm") != 0 and (_FUSE & 2) != 0
 
 
-def gemm_dswiglu(dx: torch.Tensor, wd: torch.Tensor, gu: torch.Tensor, dgu: torch.Tensor) -> torch.Tensor:
+def gemm_dswiglu(dx: torch.Tensor, wd: torch.Tensor, gu: torch.Tensor, dgu: torch.Tensor,
+                 rowscale: Optional[torch.Tensor] = None) -> torch.Tensor:
     """dgu = SwiGLU'(gu) applied to (dx @ wd): dx [M, D], wd [D, I] (the down_proj weight, read contraction-major),
-    gu / dgu [M, 2I]"""
+    gu / dgu [M, 2I]; ``rowscale`` (fp32 [M]): row m of the result times rowscale[m] (the folded RMSNorm's d z)"""
     M, K = dx.shape
     I = wd.shape[1]
     assert wd.shape[0] == K and gu.shape == (M, 2 * I) and dgu.shape == (M, 2 * I) and dx.dtype == wd.dtype == gu.dtype
@@ -273,8 +274,13 @@ def gemm_dswiglu(dx: torch.Tensor, wd: torch.Tensor, gu: torch.Tensor, dgu: torc
     if prof is not None:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-    lib().call("mh_gemm_dswiglu", _p(dx), _rowmajor(dx), _p(wd), _rowmajor(wd), _p(gu), _rowmajor(gu), _p(dgu), _rowmajor(dgu),
-               M, I, K, dt(dx), _stream())
+    if rowscale is not None:
+        assert rowscale.shape == (M,) and rowscale.dtype == torch.float32 and rowscale.is_contiguous()
+        lib().call("mh_gemm_dswiglu_scaled", _p(dx), _rowmajor(dx), _p(wd), _rowmajor(wd), _p(gu), _rowmajor(gu), _p(dgu),
+                   _rowmajor(dgu), _p(rowscale), M, I, K, dt(dx), _stream())
+    else:
+        lib().call("mh_gemm_dswiglu", _p(dx), _rowmajor(dx), _p(wd), _rowmajor(wd), _p(gu), _rowmajor(gu), _p(dgu), _rowmajor(dgu),
+                   M, I, K, dt(dx), _stream())
     if prof is not None:
         e1.record()
         prof.append((e0, e1, 2.0 * M * I * K, (M, I, K, 1, 0, 1, "+dswiglu")))
@@ -441,6 +447,78 @@ def rmsnorm_bwd(x, w, rstd, dy, dres, dx, dw: torch.Tensor, accumulate: bool):
     return dx
 
 
+def rmsnorm_bwd_folded(x, rstd, t, dres, dx):
+    """the backward of a FOLDED RMSNorm: dx = t - x (rstd^2 / D) rowdot(t, x) + dres, t = d z @ W' (see mh_rmsnorm_bwd_folded)"""
+    M, D = x.shape
+    lib().call("mh_rmsnorm_bwd_folded", _p(x), _p(rstd), _p(t), _p(dres), _p(dx), M, D, dt(x), _stream())
+    return dx
+
+
+def scale_cols(W: torch.Tensor, w: torch.Tensor, out: torch.Tensor) -> torch.Tensor:
+    """out[n, k] = W[n, k] * w[k] (the norm weight folded into the projection that follows it)"""
+    N, K = W.shape
+    assert w.shape == (K,) and out.shape == (N, K) and W.dtype == w.dtype == out.dtype
+    lib().call("mh_scale_cols", _p(W), _rowmajor(W), _p(w), _p(out), _rowmajor(out), N, K, dt(W), _stream())
+    return out
+
+
+def scale_cols_jobs(triples) -> torch.Tensor:
+    """the device-side job table of scale_cols_batched for [(W, w, out), ...] (contiguous [rows, K] matrices of one K and dtype)"""
+    rows = []
+    for W, w, out in triples:
+        assert W.is_contiguous() and out.is_contiguous() and W.shape == out.shape and w.shape == (W.shape[1],)
+        rows.append([W.data_ptr(), w.data_ptr(), out.data_ptr(), W.shape[0]])
+    return torch.tensor(rows, dtype=torch.int64, device=triples[0][0].device)
+
+
+def scale_cols_batched(jobs: torch.Tensor, K: int, like: torch.Tensor) -> None:
+    """out_j[n, k] = W_j[n, k] * w_j[k] for every job of the table, one launch"""
+    lib().call("mh_scale_cols_batched", _p(jobs), jobs.shape[0], K, dt(like), _stream())
+
+
+def gemm_nt_scaled(a: torch.Tensor, b: torch.Tensor, out: torch.Tensor, rowscale: torch.Tensor) -> torch.Tensor:
+    """out[M, N] = rowscale[:, None] * (a @ b^T): the plain projection with the row scale of a folded RMSNorm"""
+    M, N = out.shape
+    K = a.shape[1]
+    assert b.shape == (N, K) and a.shape[0] == M and rowscale.shape == (M,) and rowscale.dtype == torch.float32
+    prof = gemm_profile
+    if prof is not None:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+    lib().call("mh_gemm_nt_scaled", _p(a), _rowmajor(a), _p(b), _rowmajor(b), _p(out), _rowmajor(out), _p(rowscale), M, N, K,
+               dt(a), _stream())
+    if prof is not None:
+        e1.record()
+        prof.append((e0, e1, 2.0 * M * N * K, (M, N, K, 1, 0, 0, "+rowscale")))
+    return out
+
+
+def wgrad_folded(dz: torch.Tensor, x: torch.Tensor, dw: torch.Tensor, wnorm: torch.Tensor, W: torch.Tensor,
+                 dnorm: torch.Tensor, accumulate: bool) -> None:
+    """The weight gradient of a projection behind a FOLDED RMSNorm: G' = dz^T @ x (split-K over the rows, operands read as they
+    lie), then in the reduction of the fp32 partials  dw (+)= G' * wnorm[None, :]  and  dnorm (+)= colsum(G' * W)
+    (mh_gemm_splitk_reduce_fold + mh_colsum).  dz [M, N], x [M, K], dw / W [N, K], wnorm / dnorm [K]."""
+    M = dz.shape[0]
+    N, K = dw.shape
+    assert dz.shape[1] == N and x.shape == (M, K) and W.shape == (N, K) and wnorm.shape == (K,) and dnorm.shape == (K,)
+    splitk = max(2, _pick_splitk(N, K, M))   # (the fold's chain rule lives in the reduction: always at least two slices)
+    ws = torch.empty((splitk, N, K), dtype=torch.float32, device=dw.device)
+    prof = gemm_profile
+    if prof is not None:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+    lib().call("mh_gemm", _p(dz), _rowmajor(dz), 1, _p(x), _rowmajor(x), 1, _p(dw), _rowmajor(dw), None, 0, N, K, M, 1.0, 0.0,
+               dt(dw), splitk, _p(ws), _stream())
+    nblk = lib().cdll.mh_splitk_fold_blocks(N)
+    colpart = torch.empty((nblk, K), dtype=torch.float32, device=dw.device)
+    lib().call("mh_gemm_splitk_reduce_fold", _p(ws), _p(dw), _rowmajor(dw), _p(dw) if accumulate else None, _rowmajor(dw) if accumulate else 0,
+               N, K, splitk, 1.0, 1.0 if accumulate else 0.0, _p(wnorm), _p(W), _rowmajor(W), _p(colpart), dt(dw), _stream())
+    lib().call("mh_colsum", _p(colpart), nblk, _p(dnorm), K, int(accumulate), dt(dnorm), _stream())
+    if prof is not None:
+        e1.record()
+        prof.append((e0, e1, 2.0 * M * N * K, (N, K, M, splitk, 1, 1, "+fold")))
+
+
 # ---------------------------------------------------------------------------------------------- RoPE
 def rope_(qkv: torch.Tensor, cos_t: torch.Tensor, sin_t: torch.Tensor, S: int, pos0: int, H: int, hd: int, direction: int = 1):
     M = qkv.shape[0]
@@ -469,13 +547,26 @@ def attn_fwd(qkv, o, lse, B: int, S: int, H: int, scale: float):
     return o
 
 
-def attn_bwd(qkv, o, dout, lse, dqkv, B: int, S: int, H: int, scale: float, cos_t=None, sin_t=None):
-    """cos_t/sin_t: return the gradient with respect to the UNROTATED q, k (see mh_attn_bwd)"""
+def attn_bwd_scaled_ok(qkv: torch.Tensor) -> bool:
+    """whether attn_bwd serves ``rowscale`` (the one-call third form of the bf16 backward kernels)"""
+    if _tl.attn_v3 is None:
+        _tl.attn_v3 = get_option("attn_v3")
+    return qkv.dtype == torch.bfloat16 and (_tl.attn_v3 & 46) == 46
+
+
+def attn_bwd(qkv, o, dout, lse, dqkv, B: int, S: int, H: int, scale: float, cos_t=None, sin_t=None, rowscale=None):
+    """cos_t/sin_t: return the gradient with respect to the UNROTATED q, k (see mh_attn_bwd); ``rowscale`` (fp32 [B * S]): row m
+    of dqkv times rowscale[m] in the kernels' stores (the folded RMSNorm's d z; attn_bwd_scaled_ok)"""
     if _tl.attn_v3 is None:
         _tl.attn_v3 = get_option("attn_v3")
     Sp = round_up(S, 64)
     fused = qkv.dtype == torch.bfloat16 and (_tl.attn_v3 & 14) == 14 and (_tl.attn_v3 & 32) != 0
     delta = torch.empty(((2 if fused else 1) * B * H * Sp,), dtype=torch.float32, device=qkv.device)
+    if rowscale is not None:
+        assert fused and rowscale.shape == (B * S,) and rowscale.dtype == torch.float32 and rowscale.is_contiguous()
+        lib().call("mh_attn_bwd_o_scaled", _p(qkv), _p(o), _p(dout), _p(lse), _p(delta), _p(dqkv), _p(rowscale), B, S, H, scale,
+                   _p(cos_t), _p(sin_t), dt(qkv), _stream())
+        return dqkv
     if fused:
         # (default) one call: the dQ kernel computes delta from its own rows and hands it (and -lse * log2 e) to the dK/dV kernel
         lib().call("mh_attn_bwd_o", _p(qkv), _p(o), _p(dout), _p(lse), _p(delta), _p(dqkv), B, S, H, scale, _p(cos_t), _p(sin_t),
@@ -500,7 +591,13 @@ def tokattn_fwd(qkv, o, N: int, T: int, H: int, scale: float, cos_t=None, sin_t=
     return o
 
 
-def tokattn_bwd(qkv, dout, dqkv, N: int, T: int, H: int, scale: float, cos_t=None, sin_t=None):
+def tokattn_bwd(qkv, dout, dqkv, N: int, T: int, H: int, scale: float, cos_t=None, sin_t=None, rowscale=None):
+    """``rowscale`` (fp32 [N * T]): row m of dqkv times rowscale[m] in the stores (the folded RMSNorm's d z)"""
+    if rowscale is not None:
+        assert rowscale.shape == (N * T,) and rowscale.dtype == torch.float32 and rowscale.is_contiguous()
+        lib().call("mh_tokattn_bwd_scaled", _p(qkv), _p(dout), _p(dqkv), _p(rowscale), N, T, H, scale, _p(cos_t), _p(sin_t),
+                   dt(qkv), _stream())
+        return dqkv
     lib().call("mh_tokattn_bwd", _p(qkv), _p(dout), _p(dqkv), N, T, H, scale, _p(cos_t), _p(sin_t), dt(qkv), _stream())
     return dqkv
 

@@ -195,6 +195,10 @@ class TrainMIDIModel(MIDIModel):
         # bits, one extra elementwise pass per layer: ~1 % of a step).  For shapes whose activations crowd the 288 GB -- the
         # 2x-hidden large shape at 16 x 4096 per GPU peaks at 306 of 309 GB without it, and RCCL needs room for its channel buffers
         self.lean_activations = False
+        # r06: the training forward / backward with the RMSNorms folded around the projections (engine.layer_forward_train_folded):
+        # no passes over the residual stream for the norms' forward, no normalised activations kept, the norm weights' gradients
+        # out of the weight-gradient reductions.  bf16 only (engine.train_fold_ok); False = the r01-r05 schedule.
+        self.fold_train_norms = True
         self.force_reduce = False  # run the bucketed exchange even with one rank (tests, bench.py's contention probe)
         self._lora = None          # LoraAdapter while fine-tuning adapters on a frozen base (add_adapter)
 
@@ -487,6 +491,15 @@ class TrainMIDIModel(MIDIModel):
         self.global_step += 1
         self._micro = 0
 
+    def _train_fold(self, spec, rows: torch.Tensor, backward: bool):
+        """the folded weights stack_forward should run with: this step's (re-derived after every update) when the training fold
+        applies, the kept inference fold for a forward-only pass over enough rows, else None"""
+        if backward:
+            if self.fold_train_norms and self._lora is None and engine.train_fold_ok(spec, rows):
+                return self.folded_weights(spec.name)
+            return None
+        return self._folded_for(spec, rows) if spec.kind == "event" else None
+
     def zero_grad(self, set_to_none: bool = False):
         if self._flat_grad is not None:
             self._flat_grad.zero_()
@@ -514,7 +527,8 @@ class TrainMIDIModel(MIDIModel):
         # ---- forward: event-level net
         e = torch.empty((M, D), dtype=dty, device=dev)
         ops.embed_sum_fwd(x.view(M, T), Wn.embed, e)
-        hidden, ctx_net = engine.stack_forward(spec, Wn, e, B, S, self.rope("net"), save=backward, lean=self.lean_activations)
+        hidden, ctx_net = engine.stack_forward(spec, Wn, e, B, S, self.rope("net"), save=backward, lean=self.lean_activations,
+                                               folded=self._train_fold(spec, e, backward))
         del e
         sel = None
         if self.sample_seq:  # train.py:172-175: keep the last position + up to 127 random others
@@ -532,7 +546,7 @@ class TrainMIDIModel(MIDIModel):
         seq = torch.empty((N, T, D), dtype=dty, device=dev)
         ops.concat_tok_fwd(hidden_t, y_t, Wt.embed, seq, T)
         h, ctx_tok = engine.stack_forward(tspec, Wt, seq.view(R, D), N, T, self.rope("net_token"), save=backward,
-                                          lean=self.lean_activations)
+                                          lean=self.lean_activations, folded=self._train_fold(tspec, seq.view(R, D), backward))
         del seq
 
         # ---- lm_head + cross-entropy (+ their backward), chunked over rows

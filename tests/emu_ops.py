@@ -99,10 +99,53 @@ def dswiglu_ok(dx, I):
     return dx.dtype == torch.bfloat16 and I % 8 == 0
 
 
-def gemm_dswiglu(dx, wd, gu, dgu):
+def gemm_dswiglu(dx, wd, gu, dgu, rowscale=None):
     da = torch.empty((dx.shape[0], wd.shape[1]), dtype=dx.dtype)
-    gemm_nt(dx, wd, da, tb=True)
+    if rowscale is not None:  # (mh_gemm_dswiglu_scaled: d a times rowscale[m] BEFORE it is rounded; SwiGLU' is linear in d a)
+        da.copy_((rowscale.float()[:, None] * (dx.float() @ wd.float())).to(da.dtype))
+    else:
+        gemm_nt(dx, wd, da, tb=True)
     return swiglu_bwd(gu, da, dgu)
+
+
+def gemm_nt_scaled(a, b, out, rowscale):
+    return _scaled_product(a, b, out, rowscale)
+
+
+def scale_cols(W, w, out):
+    out.copy_((W.float() * w.float()[None, :]).to(out.dtype))
+    return out
+
+
+def scale_cols_jobs(triples):
+    return list(triples)
+
+
+def scale_cols_batched(jobs, K, like):
+    for W, w, out in jobs:
+        scale_cols(W, w, out)
+
+
+def rmsnorm_bwd_folded(x, rstd, t, dres, dx):
+    """dx = t - x (rstd^2 / D) rowdot(t, x) + dres (mh_rmsnorm_bwd_folded)"""
+    xf, tf = x.float(), t.float()
+    cf = rstd.float() ** 2 * (tf * xf).sum(-1) / x.shape[1]
+    d = tf - xf * cf[:, None]
+    if dres is not None:
+        d = d + dres.float()
+    dx.copy_(d.to(dx.dtype))
+    return dx
+
+
+def wgrad_folded(dz, x, dw, wnorm, W, dnorm, accumulate):
+    """G' = dz^T x in fp32; dw (+)= G' * wnorm; dnorm (+)= colsum(G' * W)  (mh_gemm + mh_gemm_splitk_reduce_fold + mh_colsum)"""
+    G = dz.float().T @ x.float()
+    dw.copy_((G * wnorm.float()[None, :] + (dw.float() if accumulate else 0.0)).to(dw.dtype))
+    dnorm.copy_(((G * W.float()).sum(0) + (dnorm.float() if accumulate else 0.0)).to(dnorm.dtype))
+
+
+def attn_bwd_scaled_ok(qkv):
+    return qkv.dtype == torch.bfloat16
 
 
 def skinny_ok(x, K):
@@ -337,13 +380,16 @@ def _attn_grads(q, k, v, do, scale):
     return ds @ k, ds.transpose(-1, -2) @ q, dv
 
 
-def attn_bwd(qkv, o, dout, lse, dqkv, B, S, H, scale, cos_t=None, sin_t=None):
+def attn_bwd(qkv, o, dout, lse, dqkv, B, S, H, scale, cos_t=None, sin_t=None, rowscale=None):
     q, k, v = _split(qkv, B, S, H, 64)
     do = dout.float().view(B, S, H, 64).transpose(1, 2)
     dq, dk, dv = _attn_grads(q, k, v, do, scale)
     D = H * 64
     for i, t in enumerate((dq, dk, dv)):
-        dqkv[:, i * D:(i + 1) * D] = t.transpose(1, 2).reshape(B * S, D).to(dqkv.dtype)
+        t = t.transpose(1, 2).reshape(B * S, D)
+        if rowscale is not None:  # (the kernels scale the fp32 accumulators before the store's rounding)
+            t = t * rowscale.float()[:, None]
+        dqkv[:, i * D:(i + 1) * D] = t.to(dqkv.dtype)
     if cos_t is not None:
         rope_(dqkv, cos_t, sin_t, S, 0, H, 64, -1)
     return dqkv
@@ -358,7 +404,7 @@ def tokattn_fwd(qkv, o, N, T, H, scale, cos_t=None, sin_t=None):
     return o
 
 
-def tokattn_bwd(qkv, dout, dqkv, N, T, H, scale, cos_t=None, sin_t=None):
+def tokattn_bwd(qkv, dout, dqkv, N, T, H, scale, cos_t=None, sin_t=None, rowscale=None):
     if cos_t is not None:
         qkv = rope_(qkv.clone(), cos_t, sin_t, T, 0, H, 256, +1)
     q, k, v = _split(qkv, N, T, H, 256)
@@ -366,7 +412,10 @@ def tokattn_bwd(qkv, dout, dqkv, N, T, H, scale, cos_t=None, sin_t=None):
     dq, dk, dv = _attn_grads(q, k, v, do, scale)
     D = H * 256
     for i, t in enumerate((dq, dk, dv)):
-        dqkv[:, i * D:(i + 1) * D] = t.transpose(1, 2).reshape(N * T, D).to(dqkv.dtype)
+        t = t.transpose(1, 2).reshape(N * T, D)
+        if rowscale is not None:  # (a row scale commutes with the rotation back)
+            t = t * rowscale.float()[:, None]
+        dqkv[:, i * D:(i + 1) * D] = t.to(dqkv.dtype)
     if cos_t is not None:
         rope_(dqkv, cos_t, sin_t, T, 0, H, 256, -1)
     return dqkv

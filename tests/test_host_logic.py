@@ -10,6 +10,7 @@ import pytest
 import torch
 
 import midi_model_amd as mm
+from midi_model_amd import engine
 from midi_model_amd.train import TrainMIDIModel, lr_lambda
 
 import emu_ops
@@ -375,6 +376,47 @@ def test_lean_activation_saving_is_bit_identical(orc, tiny, tok):
             loss = m.training_step(batch)
             outs.append((loss.clone(), m.grad_buffer().clone()))
     assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+
+
+def test_training_fold_of_the_norms_is_the_same_gradient(orc, tiny, tok):
+    """The training step with the RMSNorms folded around the projections (engine.layer_forward_train_folded /
+    layer_backward_folded, r06) against the plain schedule on the same bf16 weights, through the stand-ins: the algebra of the
+    fold -- d z = rstd (.) d y from the producers, t = d z W', dx = t - x (rstd^2 / D) rowdot(t, x) + dres, dW = (d z^T x) (.) w,
+    dw = colsum((d z^T x) (.) W) -- must give the loss and EVERY gradient tensor of the unfolded graph up to bf16 rounding, the
+    norm weights' gradients included (norm weights drawn away from one so that the fold is not trivial), also inside an
+    accumulation window (second micro-batch added to the first)."""
+    shp, sd, batch = tiny
+    g = torch.Generator().manual_seed(7)
+    sd = {k: (v * (1.0 + 0.3 * torch.randn(v.shape, generator=g)) if "norm" in k else v) for k, v in sd.items()}
+    with emu_ops.install():
+        outs = []
+        for fold in (False, True):
+            m = TrainMIDIModel(tiny_config(), accumulate_grad_batches=2)
+            m.load_state_dict(sd)
+            m = m.to(torch.bfloat16)
+            m.fold_train_norms = fold
+            calls = []
+            real = engine.layer_backward_folded
+            engine.layer_backward_folded = lambda *a, **k: (calls.append(1), real(*a, **k))[1]
+            try:
+                l1 = m.training_step(batch)
+                l2 = m.training_step(batch.flip(0))
+            finally:
+                engine.layer_backward_folded = real
+            assert (len(calls) > 0) == fold, "the fold did not take the path it was asked for"
+            outs.append((l1.float().item(), l2.float().item(), {k: p.grad.float().clone() for k, p in m.named_parameters()}))
+    (a1, a2, ga), (b1, b2, gb) = outs
+    assert abs(a1 - b1) < 2e-2 and abs(a2 - b2) < 2e-2, (a1, b1, a2, b2)
+    worst = 0.0
+    for k in ga:
+        na, nb = ga[k].norm().item(), gb[k].norm().item()
+        if na < 1e-12:
+            assert nb < 1e-6, k
+            continue
+        cos = (ga[k] * gb[k]).sum().item() / (na * nb)
+        worst = max(worst, 1.0 - cos)
+        assert cos > 0.995 and abs(nb / na - 1.0) < 0.05, (k, cos, nb / na)
+    assert worst < 5e-3
 
 
 def test_generate_on_trained_weights_matches_reference(trained, tok):

@@ -337,6 +337,128 @@ def test_gemm_dswiglu(ops, main_loop, M, I, K):
     cmp(fused, two.cpu(), dt, k=8, what="gemm_dswiglu vs two launches")
 
 
+# ------------------------------------------------------------------------------ the training form of the folded RMSNorm (r06)
+@pytest.mark.parametrize("M,I,K", [(256, 256, 64), (1000, 4096, 1024), (516, 1024, 264)])
+def test_gemm_dswiglu_scaled(ops, M, I, K):
+    """mh_gemm_dswiglu_scaled: d a times rowscale[m] before its rounding, then SwiGLU' -- against the stand-in; with ones the
+    unscaled entry point bit for bit"""
+    dt = torch.bfloat16
+    dx, wd, gu = rnd((M, K), dt, 61, 0.5), rnd((K, I), dt, 62, 0.5), rnd((M, 2 * I), dt, 63, 2.0)
+    rs = (0.25 + 2.0 * torch.rand((M,), generator=torch.Generator().manual_seed(9)))
+    got = torch.full((M, 2 * I), 7.0, dtype=dt, device="cuda")
+    ops.gemm_dswiglu(dx.cuda(), wd.cuda(), gu.cuda(), got, rowscale=rs.cuda())
+    ref = emu.gemm_dswiglu(dx, wd, gu, torch.empty((M, 2 * I), dtype=dt), rowscale=rs)
+    cmp(got, ref, dt, k=2 * K, what="gemm_dswiglu_scaled vs emulation")
+    one, plain = torch.empty_like(got), torch.empty_like(got)
+    ops.gemm_dswiglu(dx.cuda(), wd.cuda(), gu.cuda(), one, rowscale=torch.ones((M,), device="cuda"))
+    ops.gemm_dswiglu(dx.cuda(), wd.cuda(), gu.cuda(), plain)
+    assert torch.equal(one, plain)
+
+
+@pytest.mark.parametrize("M,N,K", [(512, 3072, 1024), (1028, 768, 264), (260, 256, 64)])
+def test_gemm_nt_scaled(ops, M, N, K):
+    """mh_gemm_nt_scaled (the token-level q|k|v projection behind a folded norm): every row of the fp32 product times rowscale[m]
+    before the rounding; with ones mh_gemm_nt bit for bit"""
+    dt = torch.bfloat16
+    a, b = rnd((M, K), dt, 1, 0.5).cuda(), rnd((N, K), dt, 2, 0.5).cuda()
+    rs = (0.25 + 2.0 * torch.rand((M,), generator=torch.Generator().manual_seed(3))).cuda()
+    got = torch.full((M, N), 7.0, dtype=dt, device="cuda")
+    ops.gemm_nt_scaled(a, b, got, rs)
+    want = (rs[:, None] * (a.float() @ b.float().t()))
+    tol = 2.0 ** -8 * want.abs() + 2.0 ** -9 * want.abs().amax(-1, keepdim=True)
+    assert ((got.float() - want).abs() <= tol).all(), (got.float() - want).abs().max().item()
+    one, plain = torch.empty_like(got), torch.empty_like(got)
+    ops.gemm_nt_scaled(a, b, one, torch.ones((M,), device="cuda"))
+    ops.gemm_nt(a, b, plain, splitk=1)
+    assert torch.equal(one, plain)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("M,D", [(64, 1024), (1000, 2048), (33, 256), (20, 4096), (7, 520)])
+def test_rmsnorm_bwd_folded(ops, dtype, M, D):
+    x, t, dres = rnd((M, D), dtype, 21), rnd((M, D), dtype, 22), rnd((M, D), dtype, 23)
+    rstd = torch.rsqrt(x.float().pow(2).mean(-1) + 1e-6)
+    for res in (dres, None):
+        want = emu.rmsnorm_bwd_folded(x, rstd, t, res, torch.empty((M, D), dtype=dtype))
+        got = torch.full((M, D), float("nan"), dtype=dtype, device="cuda")
+        ops.rmsnorm_bwd_folded(x.cuda(), rstd.cuda(), t.cuda(), None if res is None else res.cuda(), got)
+        cmp(got, want, dtype, k=4, what="rmsnorm_bwd_folded")
+
+
+@pytest.mark.parametrize("M,N,K,acc", [(2048, 768, 256, False), (4096, 3072, 1024, True), (520, 1024, 1024, True), (33000, 256, 1024, False)])
+def test_wgrad_folded(ops, M, N, K, acc):
+    """the weight gradient behind a folded norm: dW (+)= (dz^T x) * w and dw (+)= colsum((dz^T x) * W), both out of the
+    split-K reduction (mh_gemm_splitk_reduce_fold + mh_colsum), against fp32 torch on the same bf16 operands"""
+    dt = torch.bfloat16
+    dz, x = rnd((M, N), dt, 31, 0.1).cuda(), rnd((M, K), dt, 32).cuda()
+    W, w = rnd((N, K), dt, 33, 0.05).cuda(), (1.0 + 0.3 * rnd((K,), torch.float32, 34)).to(dt).cuda()
+    dW0, dw0 = rnd((N, K), dt, 35, 0.5).cuda(), rnd((K,), dt, 36, 0.5).cuda()
+    dW, dw = dW0.clone(), dw0.clone()
+    ops.wgrad_folded(dz, x, dW, w, W, dw, acc)
+    G = dz.float().t() @ x.float()
+    want_W = G * w.float()[None, :] + (dW0.float() if acc else 0.0)
+    want_w = (G * W.float()).sum(0) + (dw0.float() if acc else 0.0)
+    eW = (dW.float() - want_W).abs()
+    assert (eW <= 2.0 ** -8 * want_W.abs() + 2e-3 * want_W.pow(2).mean().sqrt()).all(), eW.max().item()
+    ew = (dw.float() - want_w).abs()
+    assert (ew <= 2.0 ** -8 * want_w.abs() + 2e-3 * want_w.pow(2).mean().sqrt()).all(), ew.max().item()
+
+
+def test_scale_cols_and_vector_splitk_reduce(ops):
+    """mh_scale_cols = (W.float() * w.float()).to(dtype) exactly; the four-columns-per-thread split-K reduction = the sums of the
+    partials in slice order (against the single-slice launch within accumulation-order noise, and deterministic)"""
+    for dt in DTYPES:
+        W, w = rnd((300, 520), dt, 1).cuda(), rnd((520,), dt, 2).cuda()
+        out = torch.empty_like(W)
+        ops.scale_cols(W, w, out)
+        assert torch.equal(out, (W.float() * w.float()[None, :]).to(dt))
+        W2, w2 = rnd((64, 520), dt, 5).cuda(), rnd((520,), dt, 6).cuda()
+        o1, o2 = torch.empty_like(W), torch.empty_like(W2)
+        ops.scale_cols_batched(ops.scale_cols_jobs([(W, w, o1), (W2, w2, o2)]), 520, W)   # two matrices, one launch
+        assert torch.equal(o1, out) and torch.equal(o2, (W2.float() * w2.float()[None, :]).to(dt))
+    a, b = rnd((512, 4096), torch.bfloat16, 3).cuda(), rnd((1024, 4096), torch.bfloat16, 4).cuda()
+    o1, o4, o4b = (torch.empty((512, 1024), dtype=torch.bfloat16, device="cuda") for _ in range(3))
+    ops.gemm_nt(a, b, o1, splitk=1)
+    ops.gemm_nt(a, b, o4, splitk=4)
+    ops.gemm_nt(a, b, o4b, splitk=4)
+    assert torch.equal(o4, o4b)
+    cmp(o4, o1.cpu(), torch.bfloat16, k=16, what="split-K 4 vs 1")
+
+
+def test_attention_backward_row_scale(ops):
+    """mh_attn_bwd_o_scaled / mh_tokattn_bwd_scaled: row m of the stored gradient = rowscale[m] x the unscaled entry point's,
+    within the store's one rounding"""
+    from midi_model_amd.engine import RopeTable
+    dt = torch.bfloat16
+    B, S, H = 2, 321, 2
+    D = H * 64
+    qkv, do = rnd((B * S, 3 * D), dt, 18).cuda(), rnd((B * S, D), dt, 19).cuda()
+    Sp = (S + 63) // 64 * 64
+    o, lse = torch.empty((B * S, D), dtype=dt, device="cuda"), torch.zeros(B * H * Sp, device="cuda")
+    ops.attn_fwd(qkv, o, lse, B, S, H, 0.125)
+    tab = RopeTable(64, 10000.0, "cuda", S)
+    rs = (0.25 + 2.0 * torch.rand((B * S,), generator=torch.Generator().manual_seed(5))).cuda()
+    plain, scaled = torch.empty_like(qkv), torch.full_like(qkv, float("nan"))
+    ops.attn_bwd(qkv, o, do, lse, plain, B, S, H, 0.125, tab.cos, tab.sin)
+    ops.attn_bwd(qkv, o, do, lse, scaled, B, S, H, 0.125, tab.cos, tab.sin, rowscale=rs)
+    want = plain.float() * rs[:, None]
+    err = (scaled.float() - want).abs()
+    # (the rotation back works on bf16-rounded pairs: an element's error is a rounding step of its LARGER partner)
+    assert (err <= 2.0 ** -6 * want.abs() + 2.0 ** -7 * want.abs().amax(-1, keepdim=True)).all(), err.max().item()
+    assert err.pow(2).mean().sqrt().item() <= 2.0 ** -8 * want.pow(2).mean().sqrt().item()
+    N, T, Ht = 37, 8, 2
+    Dt = Ht * 256
+    qkv, do = rnd((N * T, 3 * Dt), dt, 28).cuda(), rnd((N * T, Dt), dt, 29).cuda()
+    tabt = RopeTable(256, 10000.0, "cuda", T)
+    rs = (0.25 + 2.0 * torch.rand((N * T,), generator=torch.Generator().manual_seed(6))).cuda()
+    plain, scaled = torch.empty_like(qkv), torch.full_like(qkv, float("nan"))
+    ops.tokattn_bwd(qkv, do, plain, N, T, Ht, 256 ** -0.5, tabt.cos, tabt.sin)
+    ops.tokattn_bwd(qkv, do, scaled, N, T, Ht, 256 ** -0.5, tabt.cos, tabt.sin, rowscale=rs)
+    want = plain.float() * rs[:, None]
+    err = (scaled.float() - want).abs()
+    assert (err <= 2.0 ** -7 * want.abs() + 2.0 ** -8 * want.abs().amax(-1, keepdim=True)).all(), err.max().item()
+
+
 @pytest.mark.parametrize("n_rows,n_cols,ld,V", [(5, 7, 8, 3406), (293, 7, 8, 3406), (4096, 8, 8, 3406), (32768, 7, 8, 3406), (1, 1, 1, 5),
                                                 (3000, 3, 5, 17)])
 def test_token_segments_is_a_grouping_of_the_occurrences_by_id(ops, n_rows, n_cols, ld, V):
