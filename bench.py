@@ -931,7 +931,7 @@ def main():
             H, hd, L = nc.num_attention_heads, nc.hidden_size // nc.num_attention_heads, nc.num_hidden_layers
             fwd_fl = 4.0 * hd * S * (S + 1) / 2 * B * H * L * fam_steps          # QK^T + PV on the lower triangle
             fwd_ms = sum(by_name.get(k, (0.0, 0))[0] for k in ("mh_attn_fwd", "mh_attn_prep_fwd"))
-            bwd_ms = sum(by_name.get(k, (0.0, 0))[0] for k in ("mh_attn_bwd", "mh_attn_bwd_o", "mh_attn_prep_bwd"))
+            bwd_ms = sum(by_name.get(k, (0.0, 0))[0] for k in ("mh_attn_bwd", "mh_attn_bwd_o", "mh_attn_bwd_o_scaled", "mh_attn_prep_bwd"))
             out["attention"] = {"what": "event-level causal flash attention, head_dim 64 (prep kernels included)",
                                 "fwd_us_per_layer": 1e3 * fwd_ms / (L * fam_steps), "bwd_us_per_layer": 1e3 * bwd_ms / (L * fam_steps),
                                 "fwd_tflops": fwd_fl / (fwd_ms * 1e-3) / 1e12 if fwd_ms else None,

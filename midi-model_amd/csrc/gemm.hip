@@ -317,7 +317,7 @@ static int splitk_reduce_launch(const void* workspace, void* C, int64_t ldc, con
     // a training step, 4.2 GB of partials, ran at 4.1 TB/s); same sums in the same order
     if (N % 4 == 0 && ldc % 4 == 0 && (R == nullptr || ldr % 4 == 0) && (((uintptr_t)C | (uintptr_t)R) & 7) == 0 &&
         ((uintptr_t)workspace & 15) == 0) {
-      const int64_t rows_y = M < 1024 ? M : 1024;
+      const int64_t rows_y = M < 2048 ? M : 2048;
       dim3 grid((unsigned)((N / 4 + 255) / 256), (unsigned)rows_y);
       splitk_reduce4_kernel<false><<<grid, 256, 0, st>>>((const float*)workspace, (bf16*)C, ldc, (const bf16*)R, ldr, M, N, splitk, alpha,
                                                          beta, nullptr, nullptr, 0, nullptr);
@@ -480,7 +480,7 @@ extern "C" int mh_gemm_nt_scaled(const void* A, int64_t lda, const void* B, int6
 // the same pass:  dW[n,k] = alpha G'[n,k] w[k] (+ beta R[n,k]),  and block partials of  dw[k] = sum_n alpha G'[n,k] W[n,k]  (fp32,
 // [mh_splitk_fold_blocks(M)][N]; mh_colsum folds them, deterministic).  Rows of the output are the projection's output features.
 // Also the vectorised form of the plain reduction: four columns per thread, 16-byte partial loads.
-constexpr int SKF_MAX_BLOCKS = 256;
+constexpr int SKF_MAX_BLOCKS = 1024;  // (256 row blocks -- one workgroup per CU -- left the reduction latency-bound: +10 % on the weight-gradient launches)
 extern "C" int mh_splitk_fold_blocks(int64_t M) { return (int)(M < SKF_MAX_BLOCKS ? (M < 1 ? 1 : M) : SKF_MAX_BLOCKS); }
 
 template <bool FOLD>
@@ -500,10 +500,23 @@ __global__ __launch_bounds__(256) void splitk_reduce4_kernel(const float* __rest
   const bool use_r = (R != nullptr && beta != 0.f);
   for (int64_t m = blockIdx.y; m < M; m += gridDim.y) {
     f32x4 s = *reinterpret_cast<const f32x4*>(ws + m * N + c);
-    for (int z = 1; z < splitk; ++z) {
-      const f32x4 p = *reinterpret_cast<const f32x4*>(ws + (int64_t)z * total + m * N + c);
+    if (splitk <= 8) {  // (all slices requested before the first addition; same order of additions)
+      f32x4 p[7];
 #pragma unroll
-      for (int e = 0; e < 4; ++e) s[e] += p[e];
+      for (int z = 1; z < 8; ++z)
+        if (z < splitk) p[z - 1] = *reinterpret_cast<const f32x4*>(ws + (int64_t)z * total + m * N + c);
+#pragma unroll
+      for (int z = 1; z < 8; ++z)
+        if (z < splitk) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) s[e] += p[z - 1][e];
+        }
+    } else {
+      for (int z = 1; z < splitk; ++z) {
+        const f32x4 p = *reinterpret_cast<const f32x4*>(ws + (int64_t)z * total + m * N + c);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) s[e] += p[e];
+      }
     }
     float x[4];
 #pragma unroll
