@@ -188,6 +188,15 @@ __device__ inline bf16x8 as_bf16x8(const u32x4& v) {
 // ~6 TB/s, the memory side's write rate.  Starting the XCDs out of phase changed nothing (the drain is bound per XCD), and
 // PERSISTENT workgroups (one per CU walking its XCD's tiles, the next tile's LDS-DMA issued while the stores drain) measured
 // +-0 on every shape: the dispatcher already overlaps teardown and fill; the drain itself is what a K = 1024 tile waits for.
+// r06, two more closed: (1) the first workgroup of every CU started (index within its XCD) x 0.25 .. 2 us late, so that an XCD's 32
+// CUs reach their epilogues one after the other instead of together: +-1 % on every K = 1024 shape of the step (the drain is not a
+// synchronised burst either).  (2) This loop for the WEIGHT GRADIENTS (both operands contraction-major; A regions k-major, 64
+// k-rows x 256 B, fragments by ds_read_b64_tr_b16 as B's): bit-identical to the K-step-32 loop and 5-10 % SLOWER on every
+// weight-gradient shape of the step (1054 against 1165 TFLOP/s at [8192 x 1024 x 32768]) -- 32 transposing reads in P1's load slot
+// against 32 MFMAs; the K-step-32 loop lets its two groups drift (one barrier per step), which is what those shapes want.  Its
+// ablation builds on [8192 x 1024 x 32768]: complete 497 us, MFMAs + barriers alone 337, fragment reads alone 212 (113 B/clk of
+// the LDS's 128), LDS-DMA + reads 324: LDS bandwidth (96 KiB of reads + 32 KiB of DMA writes per 32-deep step) and the matrix pipe
+// (1024 cycles per step and SIMD) are co-limits of the 8-wave 256x256 tile.
 constexpr int P8_REGION = 128 * 128;  // 16 KiB
 constexpr int P8_BUF = 4 * P8_REGION;
 constexpr int P8_DBG_BYTES = 8 * 2048;  // timeline builds (ABL bit 7): 256 stamps per wave behind the two K-tile buffers
