@@ -125,3 +125,29 @@ def test_bf16_forward_tracks_the_oracle_on_fuzzed_shapes(orc, tok, ci):
         a, b = named[n].grad.float().cpu().flatten(), sdg[n].grad.flatten()
         cos = torch.dot(a, b) / (a.norm() * b.norm() + 1e-30)
         assert cos.item() > 0.97, (case, n, cos.item())
+
+
+GEN_CASES = [  # (CASES index for the widths, batch, prompt kind, prompt events, max_len, mask options)
+    (0, 1, None, 0, 20, {}), (2, 3, "shared2d", 5, 18, {}), (4, 2, "per_row", 9, 16, {}), (6, 5, "short_octets", 3, 12, {}),
+    (7, 2, "one_row_3d", 4, 14, {"disable_patch_change": True, "disable_control_change": True, "disable_channels": [0, 3, 9]}),
+    (3, 4, "per_row", 1, 10, {"ban_eos": True}),
+]
+
+
+@pytest.mark.parametrize("gi", range(len(GEN_CASES)))
+def test_fp32_greedy_generate_ids_match_oracle_on_fuzzed_prompts(orc, tok, gi):
+    """generate() over the prompt forms midi_model.py:171-188 accepts -- None, (n, 8) shared, (1, n, 8), (B, n, 8), octets shorter
+    than 8 -- at odd batch sizes, with and without the serving loop's mask options: fp32 greedy (top_k = 1: the draw is the arg-max
+    whatever the generator) ids equal the oracle's, id for id."""
+    ci, B, kind, n, max_len, opts = GEN_CASES[gi]
+    case = CASES[ci]
+    shp, sd, _, cfg = _mk(orc, tok, case, 300 + gi)
+    ev = orc.synthetic_events(tok, B, max(n, 1) + 1, seed=400 + gi).numpy()  # row 0 of each sequence is BOS
+    prompt = {None: None, "shared2d": ev[0, :n], "per_row": ev[:, :n], "one_row_3d": ev[:1, :n], "short_octets": ev[:1, :n, :6]}[kind]
+    ref = orc.generate(sd, shp, tok, prompt=prompt, batch_size=B, max_len=max_len, top_k=1, **opts)
+    model = mm.MIDIModel(cfg)
+    model.load_state_dict(sd, strict=True)
+    model = model.to("cuda", torch.float32)
+    out = model.generate(prompt, batch_size=B, max_len=max_len, top_k=1, **opts)
+    assert out.shape == ref.shape, (out.shape, ref.shape)
+    assert (out == ref).all(), (GEN_CASES[gi], np.argwhere(out != ref)[:5])
