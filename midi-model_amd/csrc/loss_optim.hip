@@ -70,17 +70,25 @@ __global__ __launch_bounds__(256) void cross_entropy_kernel(const T* logits, int
 
 // bf16 rows of 16-byte-aligned stride up to NCH * 512 elements: the row is loaded once with 16-byte loads and stays in
 // registers for both passes (statistics, gradient); same arithmetic as cross_entropy_kernel up to summation order.
-template <int NCH>
+// r06: the kernel was bound by its VALU, not by HBM (3.3 TB/s; ~40 lane-cycles per element: three bf16 -> fp32 conversions,
+// a `c < V` compare + select per element and pass, the target compare + select per gradient element, the arg-max bookkeeping
+// nobody reads in a training step).  Now the row is converted ONCE into fp32 registers with its padding columns set to -inf
+// (exp2 of -inf is +0: every later pass is unconditional -- the sum gains exact zeros, the gradient of the padding is +0 as
+// before), the one chunk that can hold padding and the one chunk that holds the target are found with wave-uniform tests, an
+// ignored row stores zeros without computing anything, and the arg-max bookkeeping is its own instantiation (ARG, validation).
+// Per element: 1 convert, 1 max, sub-mul-exp-add, sub-mul-exp-mul-convert.  Results are bit-identical to the previous form
+// (same operations on the same values in the same order; profiles/r06_ce_ab.txt).
+template <int NCH, bool ARG>
 __global__ __launch_bounds__(256) void cross_entropy_vec_kernel(const bf16* logits, int64_t ldl, const int64_t* __restrict__ target,
                                                                 float* __restrict__ row_loss, bf16* dlogits,
                                                                 const float* __restrict__ scale_dev,
                                                                 int64_t* __restrict__ argmax_out, int64_t R, int V,
                                                                 int64_t ignore) {
+  constexpr float LOG2E_F = 1.44269502162933349609375f;  // 0x3fb8aa3b: the constant __expf multiplies by
   const int lane = threadIdx.x & 63;
   const float scale = (dlogits != nullptr && scale_dev != nullptr) ? scale_dev[0] : 1.f;
   const int nchunk = (int)(ldl / 8);
-  // the next row of the wave is requested before the current one is worked on (two rows of loads in flight per wave: the
-  // kernel holds ~200 VGPRs, i.e. 8 waves per CU, and one 6.9 KB row each did not cover the HBM latency: 2.4 TB/s)
+  // the next row of the wave is requested before the current one is worked on (two rows of loads in flight per wave)
   auto load_row = [&](int64_t r, bf16x8 (&dst)[NCH]) {
     const bf16* row = logits + r * ldl;
 #pragma unroll
@@ -96,63 +104,88 @@ __global__ __launch_bounds__(256) void cross_entropy_vec_kernel(const bf16* logi
   for (; r < R; r += rstep) {
     const bf16* row = logits + r * ldl;
     if (r + rstep < R) load_row(r + rstep, vn);
+    // (wave-uniform by construction -- one row per wave; the readfirstlane makes the tests below scalar branches)
+    const int64_t tgt64 = target[r];
+    const int tgt = __builtin_amdgcn_readfirstlane((int)tgt64);
+    const bool keep = __builtin_amdgcn_readfirstlane((int)(tgt64 != ignore)) != 0;
+    float f[NCH][8];
+#pragma unroll
+    for (int k = 0; k < NCH; ++k) {
+      const int rem = V - (k * 64 + lane) * 8;  // columns of this chunk inside the vocabulary (<= 0: none)
+#pragma unroll
+      for (int e = 0; e < 8; ++e) f[k][e] = (float)v[k][e];
+      if (__builtin_amdgcn_ballot_w64(rem < 8) != 0) {  // some lane of this chunk holds padding: at most two chunks of a row
+#pragma unroll
+        for (int e = 0; e < 8; ++e) f[k][e] = (e < rem) ? f[k][e] : -INFINITY;
+      }
+    }
     float mx = -INFINITY;
     int amax = 0x7fffffff;
+    if constexpr (ARG) {
 #pragma unroll
-    for (int k = 0; k < NCH; ++k)
+      for (int k = 0; k < NCH; ++k)
 #pragma unroll
-      for (int e = 0; e < 8; ++e) {
-        const int c = (k * 64 + lane) * 8 + e;
-        const float x = (float)v[k][e];
-        if (c < V && x > mx) {  // ascending c within the lane: the first maximum stays
-          mx = x;
-          amax = c;
+        for (int e = 0; e < 8; ++e) {
+          const int c = (k * 64 + lane) * 8 + e;
+          if (f[k][e] > mx) {  // ascending c within the lane: the first maximum stays (padding is -inf: never greater)
+            mx = f[k][e];
+            amax = c;
+          }
+        }
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) {
+        const float omx = __shfl_xor(mx, o, 64);
+        const int oam = __shfl_xor(amax, o, 64);
+        if (omx > mx || (omx == mx && oam < amax)) {
+          mx = omx;
+          amax = oam;
         }
       }
+    } else {
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-      const float omx = __shfl_xor(mx, o, 64);
-      const int oam = __shfl_xor(amax, o, 64);
-      if (omx > mx || (omx == mx && oam < amax)) {
-        mx = omx;
-        amax = oam;
-      }
+      for (int k = 0; k < NCH; ++k)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) mx = fmaxf(mx, f[k][e]);
+      mx = wave_max(mx);
     }
     float sum = 0.f;
 #pragma unroll
     for (int k = 0; k < NCH; ++k)
 #pragma unroll
-      for (int e = 0; e < 8; ++e) {
-        const int c = (k * 64 + lane) * 8 + e;
-        if (c < V) sum += __expf((float)v[k][e] - mx);
-      }
+      for (int e = 0; e < 8; ++e) sum += __builtin_amdgcn_exp2f((f[k][e] - mx) * LOG2E_F);
     sum = wave_sum(sum);
     const float lse = mx + __logf(sum);
-    const int64_t tgt = target[r];
-    const bool keep = (tgt != ignore);
     if (lane == 0) {
       row_loss[r] = keep ? (lse - (float)row[tgt]) : 0.f;
-      if (argmax_out != nullptr) argmax_out[r] = amax;
+      if constexpr (ARG) argmax_out[r] = amax;
     }
     if (dlogits != nullptr) {
       bf16* drow = dlogits + r * ldl;
+      if (!keep) {  // (scalar branch) an ignored row: zeros, nothing to compute
+        bf16x8 z;
 #pragma unroll
-      for (int k = 0; k < NCH; ++k) {
-        const int ch = k * 64 + lane;
-        if (ch < nchunk) {
+        for (int e = 0; e < 8; ++e) z[e] = (bf16)0.f;
+#pragma unroll
+        for (int k = 0; k < NCH; ++k) {
+          const int ch = k * 64 + lane;
+          if (ch < nchunk) *reinterpret_cast<bf16x8*>(drow + ch * 8) = z;
+        }
+      } else {
+        const int tk = tgt >> 9, tl = (tgt >> 3) & 63, te = tgt & 7;  // the target's chunk index k, lane and element
+#pragma unroll
+        for (int k = 0; k < NCH; ++k) {
+          const int ch = k * 64 + lane;
+          float g[8];
+#pragma unroll
+          for (int e = 0; e < 8; ++e) g[e] = __builtin_amdgcn_exp2f((f[k][e] - lse) * LOG2E_F);
+          if (k == tk) {  // (scalar branch: one chunk of the row)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) g[e] = (lane == tl && e == te) ? g[e] - 1.f : g[e];
+          }
           bf16x8 g8;
 #pragma unroll
-          for (int e = 0; e < 8; ++e) {
-            const int c = ch * 8 + e;
-            float g = 0.f;
-            if (keep && c < V) {
-              g = __expf((float)v[k][e] - lse);
-              if (c == (int)tgt) g -= 1.f;
-              g *= scale;
-            }
-            g8[e] = (bf16)g;
-          }
-          *reinterpret_cast<bf16x8*>(drow + ch * 8) = g8;
+          for (int e = 0; e < 8; ++e) g8[e] = (bf16)(g[e] * scale);
+          if (ch < nchunk) *reinterpret_cast<bf16x8*>(drow + ch * 8) = g8;
         }
       }
     }
@@ -169,19 +202,25 @@ extern "C" int mh_cross_entropy(const void* logits, int64_t ldl, const int64_t* 
   if (g > 65536) g = 65536;
   const bool vec = dtype == MH_BF16 && ldl % 8 == 0 && ldl <= 4096 && ((uintptr_t)logits & 15) == 0 &&
                    (dlogits == nullptr || ((uintptr_t)dlogits & 15) == 0);
-  if (vec && g > 512) g = 512;  // two resident blocks per CU, every wave walks ~R / 2048 rows with the next one prefetched
-  if (vec && ldl > 3584) {
-    cross_entropy_vec_kernel<8><<<(int)g, 256, 0, (hipStream_t)stream>>>((const bf16*)logits, ldl, target, row_loss,
-                                                                         (bf16*)dlogits, scale_dev, argmax_out, R, V, ignore);
-  } else if (vec && ldl > 2048) {
-    cross_entropy_vec_kernel<7><<<(int)g, 256, 0, (hipStream_t)stream>>>((const bf16*)logits, ldl, target, row_loss,
-                                                                         (bf16*)dlogits, scale_dev, argmax_out, R, V, ignore);
-  } else if (vec) {
-    cross_entropy_vec_kernel<4><<<(int)g, 256, 0, (hipStream_t)stream>>>((const bf16*)logits, ldl, target, row_loss,
-                                                                         (bf16*)dlogits, scale_dev, argmax_out, R, V, ignore);
-  } else
+  // two resident blocks per CU, every wave walks ~R / 2048 rows with the next one prefetched (r06, the 132-VGPR form: 768 blocks
+  // 90.7 us against 93.0 on the step's chunk, the arg-max form 119.8 against 104.7: left at 512)
+  if (vec && g > 512) g = 512;
+#define MH_CE_VEC(NCH_)                                                                                                   \
+  do {                                                                                                                    \
+    if (argmax_out != nullptr)                                                                                            \
+      cross_entropy_vec_kernel<NCH_, true><<<(int)g, 256, 0, (hipStream_t)stream>>>(                                       \
+          (const bf16*)logits, ldl, target, row_loss, (bf16*)dlogits, scale_dev, argmax_out, R, V, ignore);               \
+    else                                                                                                                  \
+      cross_entropy_vec_kernel<NCH_, false><<<(int)g, 256, 0, (hipStream_t)stream>>>(                                      \
+          (const bf16*)logits, ldl, target, row_loss, (bf16*)dlogits, scale_dev, argmax_out, R, V, ignore);               \
+  } while (0)
+  if (vec && ldl > 3584) MH_CE_VEC(8);
+  else if (vec && ldl > 2048) MH_CE_VEC(7);
+  else if (vec) MH_CE_VEC(4);
+  else
   DISPATCH_T(dtype, (cross_entropy_kernel<T><<<(int)g, 256, 0, (hipStream_t)stream>>>(
                         (const T*)logits, ldl, target, row_loss, (T*)dlogits, scale_dev, argmax_out, R, V, ignore)));
+#undef MH_CE_VEC
   MH_LAUNCH_CHECK();
   return MH_OK;
 }
