@@ -50,7 +50,9 @@ int mh_ab_builds(void);
  * "skinny_mb" / "skinny_nbt" = 16-row activation blocks / 16-column blocks per workgroup of mh_gemm_skinny (0 = default);
  * "attn_v3" / "attn_v3_wps" = forms of the event-level attention kernels (attention_mfma3.hip; default 255: bit 7 = the
  * forward's lazy reference maximum; values that select a first-form kernel: A/B library only); "attn_passes" = in how many
- * chunks of tile ranks those kernels walk their (batch, head) pairs, light chunks last (default 5; 1 = pair after pair). */
+ * chunks of tile ranks those kernels walk their (batch, head) pairs, light chunks last (default 5; 1 = pair after pair);
+ * "tokattn_bwd_batched" = 1 (mh_tokattn_bwd at T = 8 reduces its dot products four per wave reduction) | 0 (one by one; the
+ * same values up to fp32 summation order). */
 int mh_set_option(const char* name, int value);
 int mh_get_option(const char* name);
 

@@ -40,6 +40,7 @@ thread_local int g_mh_gemm_k64 = env_int("MH_GEMM_K64", 1);
 // epilogues (descriptor addressing, packed arithmetic), 0 = the general forms everywhere (bit-identical results; A/B runs)
 thread_local int g_mh_gemm_lean_epi = env_int("MH_GEMM_LEAN_EPI", 1);
 extern thread_local int g_skinny_mb, g_skinny_nbt;  // gemm_skinny.hip
+extern thread_local int g_tokattn_bwd_batched;      // attention_small.hip
 extern thread_local int g_attn_v3, g_attn_v3_wps, g_attn_passes;      // attention_mfma3.hip
 
 extern "C" int mh_set_option(const char* name, int value) {
@@ -57,6 +58,10 @@ extern "C" int mh_set_option(const char* name, int value) {
   }
   if (strcmp(name, "gemm_lean_epi") == 0) {
     g_mh_gemm_lean_epi = value;
+    return 0;
+  }
+  if (strcmp(name, "tokattn_bwd_batched") == 0) {
+    g_tokattn_bwd_batched = value;
     return 0;
   }
   if (strcmp(name, "skinny_mb") == 0) {  // 16-row blocks of the activation per workgroup of mh_gemm_skinny (0 = default)
@@ -94,6 +99,7 @@ extern "C" int mh_get_option(const char* name) {
   if (strcmp(name, "gemm_k64") == 0) return g_mh_gemm_k64;
   if (strcmp(name, "gemm_ablate") == 0) return g_mh_gemm_ablate;
   if (strcmp(name, "gemm_lean_epi") == 0) return g_mh_gemm_lean_epi;
+  if (strcmp(name, "tokattn_bwd_batched") == 0) return g_tokattn_bwd_batched;
   return -1;
 }
 

@@ -164,6 +164,31 @@ __device__ inline float wave_sum_fast(float v) {
   return __int_as_float(b[0]) + __int_as_float(b[1]);
 }
 
+// FOUR all-lanes sums at the price of about one and a half (r06): the two swap levels come first and each folds TWO values --
+// permlane32_swap(x0, x1) leaves [x0.lo | x1.lo], [x0.hi | x1.hi], whose sum holds x0's lane-pair sums in lanes 0-31 and x1's in
+// lanes 32-63; permlane16_swap does the same to the rows of two such registers -- so four values end up in the four 16-lane rows
+// of ONE register, and the four DPP steps inside a row finish all of them at once.  Row r of the result holds (in every lane)
+// the total of x0, x2, x1, x3 for r = 0, 1, 2, 3: wave_sum4_get<j> reads value j back as a wave-uniform scalar (v_readlane).
+// 3 swaps + 7 adds + 4 readlanes for four values against 4 x (2 swaps + 6 adds) -- the token-level attention backward spent
+// 28 % of its VALU instructions in 72 single reductions per (sequence, head).  Summation order differs from wave_sum_fast's.
+__device__ inline float wave_sum4(float x0, float x1, float x2, float x3) {
+  auto a = __builtin_amdgcn_permlane32_swap(__float_as_int(x0), __float_as_int(x1), false, false);
+  auto b = __builtin_amdgcn_permlane32_swap(__float_as_int(x2), __float_as_int(x3), false, false);
+  const float y0 = __int_as_float(a[0]) + __int_as_float(a[1]);  // rows 0,1: x0, rows 2,3: x1
+  const float y1 = __int_as_float(b[0]) + __int_as_float(b[1]);  // rows 0,1: x2, rows 2,3: x3
+  auto c = __builtin_amdgcn_permlane16_swap(__float_as_int(y0), __float_as_int(y1), false, false);
+  float v = __int_as_float(c[0]) + __int_as_float(c[1]);         // row 0: x0, row 1: x2, row 2: x1, row 3: x3
+  v += dpp_move<0xB1>(v);   // quad_perm(1,0,3,2)
+  v += dpp_move<0x4E>(v);   // quad_perm(2,3,0,1)
+  v += dpp_move<0x141>(v);  // row_half_mirror
+  v += dpp_move<0x140>(v);  // row_mirror
+  return v;
+}
+template <int J> __device__ inline float wave_sum4_get(float v) {
+  constexpr int ROW = (J == 0) ? 0 : (J == 1) ? 2 : (J == 2) ? 1 : 3;
+  return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 16 * ROW));
+}
+
 // max over the wave of 64-bit keys (every lane gets it).  Same DPP / permlane ladder as wave_sum_fast, no LDS round
 // trips.  An arg-max with a tie rule is a max over keys (value bits << 32 | rank of the index), see the sampler.
 template <int CTRL> __device__ inline uint32_t dpp_move_u(uint32_t v) {

@@ -787,6 +787,37 @@ def test_tokattn(ops, dtype, N, T, H):
     cmp(dq, dq_ref, dtype, k=3, what="tokattn+rope dqkv")
 
 
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_tokattn_backward_forms_agree(ops, dtype):
+    """r06: the octet backward reduces its dot products four per wave reduction (option tokattn_bwd_batched, default 1).  Against
+    the one-by-one form: the same values up to fp32 summation order -- fp32 within 1e-5 of the range, bf16 the same but for a
+    handful of elements one rounding step apart -- with RoPE, with and without the folded norm's row scale; the oracle-pinned
+    comparison of the default form is test_tokattn above."""
+    from midi_model_amd.engine import RopeTable
+    N, T, H = 301, 8, 4
+    D = H * 256
+    scale = 256 ** -0.5
+    qkv, do = rnd((N * T, 3 * D), dtype, 41).cuda(), rnd((N * T, D), dtype, 42).cuda()
+    rs = (0.5 + torch.rand((N * T,), generator=torch.Generator().manual_seed(43))).cuda()
+    tab = RopeTable(256, 10000.0, "cuda", 8)
+    assert ops.get_option("tokattn_bwd_batched") == 1
+    for rowscale in (None, rs):
+        out = {}
+        for v in (0, 1):
+            ops.set_option("tokattn_bwd_batched", v)
+            try:
+                out[v] = ops.tokattn_bwd(qkv, do, torch.empty_like(qkv), N, T, H, scale, tab.cos, tab.sin, rowscale=rowscale).float()
+            finally:
+                ops.set_option("tokattn_bwd_batched", 1)
+        d = (out[0] - out[1]).abs()
+        amax = out[0].abs().max().item()
+        if dtype == torch.float32:
+            assert d.max().item() <= 1e-5 * amax, (d.max().item(), amax)
+        else:
+            assert (d <= 2.0 ** -7 * out[0].abs() + 1e-6 * amax).all(), d.max().item()   # one bf16 rounding step at most
+            assert (d > 0).float().mean().item() < 2e-3
+
+
 # ----------------------------------------------------------------------------------------------- SwiGLU
 @pytest.mark.parametrize("dtype", DTYPES)
 def test_swiglu(ops, dtype):
