@@ -149,53 +149,95 @@ extern "C" int mh_embed_scatter_bwd(const int64_t* tok, int64_t ldtok, int T_, c
 // Equal pieces matter: with one block per id the 29.5k rows of "note" were a serial chain of dependent index -> row
 // loads and the launch took 1.05 ms for 0.5 GB (profiles/r01_run9), ten times the HBM time.
 // Roofline: HBM; algorithmic bytes = n_occ * D * sizeof(T) (every occurrence's row once).
-template <typename T, int NCH>
-__global__ __launch_bounds__(256) void embed_segment_bwd_kernel(const int64_t* __restrict__ src, const int64_t* __restrict__ seg,
+// r06: ~2600 ids x two runs each x 1024 fp32 atomics, executed at the memory side, sat behind every run.  The cuts between
+// the waves' pieces are now SNAPPED to segment starts: the piece of wave w begins at snap(128 w), where snap(p) = the start of
+// the segment holding p when that segment has at most SEG_OWN occurrences, else p itself.  Every segment of <= SEG_OWN occurrences
+// then lies inside exactly one wave's piece (the last wave whose nominal cut falls inside it, or the one whose piece it falls
+// in whole) and is added to the table with plain loads + stores; only the few longer ones (the event ids, "note" first) keep
+// one atomic per element per 128-occurrence run.  seg_start is searched in LDS (V + 1 32-bit counts; < 2^31 occurrences).
+// The long segments' chains of atomics on one address (the 29.5 k occurrences of "note" were 230 runs adding to the same 1024
+// floats) are cut as well: the waves of a workgroup (NW = 8: 1024 consecutive occurrences) meet in LDS before they touch the
+// table -- every wave leaves the run it ends with in its LDS slot, and the first wave of each group of consecutive waves ending
+// in the same id adds the group's slots and writes once: 29 links for "note" instead of 230 (ids are sorted, so a wave that ends
+// in the id its predecessor ends in holds nothing else).  Measured (tools/embed_bwd_once.py, the step's two calls): 246 -> 238 us
+// (token-level: 229 k rows of d seq gathered in id order, 2 TB/s -- what 2 KiB random gathers get) and 273 -> 191 us (event-level:
+// every event's row read by its 8 tokens).  With ALL table traffic compiled out the launches take 238 / 190 us: the writes are
+// no longer what they wait for, the gather is.
+constexpr int SEG_OWN = 1024;
+
+template <typename T, int NCH, bool SL, int NW>
+__global__ __launch_bounds__(NW * 64) void embed_segment_bwd_kernel(const int64_t* __restrict__ src, const int64_t* __restrict__ seg,
                                                                 const T* __restrict__ dout, int64_t ld,
                                                                 float* __restrict__ dtab, int V, int D, int64_t n_occ,
                                                                 int pad_id) {
   constexpr int N = Pack<T>::N;
-  constexpr int RW = 64, NPASS = 2, G = 4;  // occurrences per pass (one per lane), passes per wave, rows in flight
+  constexpr int RW = 64, G = 4;  // occurrences per pass (one per lane), rows in flight; a nominal piece is 2 RW occurrences
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-  const int64_t w0 = ((int64_t)blockIdx.x * 4 + wv) * (RW * NPASS);
-  if (w0 >= n_occ) return;
+  extern __shared__ __attribute__((aligned(16))) int seg_l[];  // SL: seg_start[0 .. V] for the binary searches; behind it the waves' slots
+  constexpr int SLOT = NCH * 64 * N;                            // floats of one wave's run
+  const int seg_words = SL ? ((V + 1 + 3) & ~3) : 0;
+  float* part = reinterpret_cast<float*>(seg_l + seg_words);   // [NW][SLOT]
+  int* fin_id = reinterpret_cast<int*>(part + NW * SLOT);      // [NW]: the id of the run a wave ended with (-1: none)
+  if constexpr (SL) {
+    for (int v = threadIdx.x; v <= V; v += NW * 64) seg_l[v] = (int)seg[v];
+    __syncthreads();
+  }
+  auto seg_at = [&](int v) -> int64_t { return SL ? (int64_t)seg_l[v] : seg[v]; };
+  auto owner = [&](int64_t p) {  // the largest v in [0, V) with seg[v] <= p
+    int lo = 0, hi = V;
+    while (hi - lo > 1) {
+      const int mid = (lo + hi) >> 1;
+      if (seg_at(mid) <= p) lo = mid; else hi = mid;
+    }
+    return lo;
+  };
+  const int64_t n_in = (seg_at(V) < n_occ) ? seg_at(V) : n_occ;  // (occurrences of ids outside [0, V) sit behind seg[V]: skipped)
+  auto snap = [&](int64_t p) -> int64_t {
+    if (p >= n_in) return n_in;
+    const int v = owner(p);
+    return (seg_at(v + 1) - seg_at(v) <= SEG_OWN) ? seg_at(v) : p;
+  };
+  const int64_t w = (int64_t)blockIdx.x * NW + wv;
+  const int64_t p_beg = snap(w * (2 * RW)), p_end = snap((w + 1) * (2 * RW));  // (wave-uniform; an empty piece still meets the others below)
   float acc[NCH][N];
 #pragma unroll
   for (int ch = 0; ch < NCH; ++ch)
 #pragma unroll
     for (int e = 0; e < N; ++e) acc[ch][e] = 0.f;
   int cur = -1;
+  bool own = false;  // the run's id belongs to this wave alone
   auto flush = [&]() {
     float* dst = dtab + (int64_t)cur * D;
 #pragma unroll
     for (int ch = 0; ch < NCH; ++ch) {
       const int c = (ch * 64 + lane) * N;
       if (c < D) {
+        if (own) {
 #pragma unroll
-        for (int e = 0; e < N; ++e) {
-          atomicAdd(dst + c + e, acc[ch][e]);
-          acc[ch][e] = 0.f;
+          for (int e = 0; e < N; e += 4) {
+            float4 t = *reinterpret_cast<float4*>(dst + c + e);
+            t.x += acc[ch][e]; t.y += acc[ch][e + 1]; t.z += acc[ch][e + 2]; t.w += acc[ch][e + 3];
+            *reinterpret_cast<float4*>(dst + c + e) = t;
+          }
+        } else {
+#pragma unroll
+          for (int e = 0; e < N; ++e) atomicAdd(dst + c + e, acc[ch][e]);
         }
+#pragma unroll
+        for (int e = 0; e < N; ++e) acc[ch][e] = 0.f;
       }
     }
   };
 #pragma unroll 1
-  for (int pass = 0; pass < NPASS; ++pass) {
-  const int64_t p0 = w0 + pass * RW;
-  if (p0 >= n_occ) break;
-  const int cnt = (n_occ - p0 < RW) ? (int)(n_occ - p0) : RW;
+  for (int64_t p0 = p_beg; p0 < p_end; p0 += RW) {
+  const int cnt = (p_end - p0 < RW) ? (int)(p_end - p0) : RW;
   int row_lo = 0, row_hi = 0, my_id = -1;
   if (lane < cnt) {
     const int64_t p = p0 + lane;
     const int64_t r = src[p];
     row_lo = (int)(uint32_t)r;
     row_hi = (int)(r >> 32);
-    int lo = 0, hi = V;  // seg[lo] <= p < seg[hi]: the largest v with seg[v] <= p owns occurrence p
-    while (hi - lo > 1) {
-      const int mid = (lo + hi) >> 1;
-      if (seg[mid] <= p) lo = mid; else hi = mid;
-    }
-    my_id = lo;
+    my_id = owner(p);
   }
 #pragma unroll
   for (int j0 = 0; j0 < RW; j0 += G) {
@@ -204,7 +246,7 @@ __global__ __launch_bounds__(256) void embed_segment_bwd_kernel(const int64_t* _
       int idj[G];
 #pragma unroll
       for (int g = 0; g < G; ++g) {
-        idj[g] = __builtin_amdgcn_readlane(my_id, j0 + g);  // -1 past the end of the list
+        idj[g] = __builtin_amdgcn_readlane(my_id, j0 + g);  // -1 past the end of the piece
         const int64_t row = ((int64_t)__builtin_amdgcn_readlane(row_hi, j0 + g) << 32) |
                             (uint32_t)__builtin_amdgcn_readlane(row_lo, j0 + g);
         if (idj[g] >= 0 && idj[g] != pad_id) {
@@ -221,6 +263,7 @@ __global__ __launch_bounds__(256) void embed_segment_bwd_kernel(const int64_t* _
         if (idj[g] != cur) {
           if (cur >= 0) flush();
           cur = idj[g];
+          own = seg_at(cur + 1) - seg_at(cur) <= SEG_OWN;
         }
 #pragma unroll
         for (int ch = 0; ch < NCH; ++ch) {
@@ -234,7 +277,27 @@ __global__ __launch_bounds__(256) void embed_segment_bwd_kernel(const int64_t* _
     }
   }
   }
-  if (cur >= 0) flush();
+  // ---- the run this wave ended with: through LDS, one write per group of waves that ended in the same id
+  if (cur >= 0) {
+#pragma unroll
+    for (int ch = 0; ch < NCH; ++ch)
+#pragma unroll
+      for (int e = 0; e < N; e += 4)
+        *reinterpret_cast<float4*>(part + wv * SLOT + (ch * 64 + lane) * N + e) = float4{acc[ch][e], acc[ch][e + 1], acc[ch][e + 2], acc[ch][e + 3]};
+  }
+  if (lane == 0) fin_id[wv] = cur;
+  __syncthreads();
+  if (cur < 0 || (wv > 0 && fin_id[wv - 1] == cur)) return;  // nothing to write / a member of an earlier wave's group
+  for (int k = wv + 1; k < NW && fin_id[k] == cur; ++k) {
+#pragma unroll
+    for (int ch = 0; ch < NCH; ++ch)
+#pragma unroll
+      for (int e = 0; e < N; e += 4) {
+        const float4 t = *reinterpret_cast<const float4*>(part + k * SLOT + (ch * 64 + lane) * N + e);
+        acc[ch][e] += t.x; acc[ch][e + 1] += t.y; acc[ch][e + 2] += t.z; acc[ch][e + 3] += t.w;
+      }
+  }
+  flush();
 }
 
 extern "C" int mh_embed_segment_bwd(const int64_t* src_rows, const int64_t* seg_start, const void* dout, int64_t ld,
@@ -243,18 +306,30 @@ extern "C" int mh_embed_segment_bwd(const int64_t* src_rows, const int64_t* seg_
   MH_REQUIRE(V > 0 && V < (1 << 30) && D % 8 == 0 && D <= 4096 && n_occ >= 0, "embed_segment_bwd: bad args");
   MH_REQUIRE(dtype != MH_F32 || D <= 2048, "embed_segment_bwd: fp32 supports D <= 2048");
   if (n_occ == 0) return MH_OK;
-  const int64_t nblk = (n_occ + 511) / 512;  // 4 waves x 128 occurrences
-  MH_REQUIRE(nblk < (1ll << 31), "embed_segment_bwd: too many occurrences");
+  MH_REQUIRE(n_occ < (1ll << 31), "embed_segment_bwd: too many occurrences");
+  const bool sl = (V + 1) * 4 <= 16 * 1024;  // seg_start fits the LDS beside the waves' slots (every vocabulary of the reference: 3406 / 3408 ids)
+  const int seg_words = sl ? (int)((V + 1 + 3) & ~3) : 0;
   const int per = 64 * (dtype == MH_F32 ? 4 : 8);
   const int nch = (D + per - 1) / per;
+  // 8 waves (1024 occurrences) per workgroup while the waves' slots (NCH x 64 lanes x 16 or 32 bytes each) fit beside seg_start
+  // in 64 KiB of LDS, else 4, else 1 (D = 4096: no meeting, the r01 form)
+#define MH_SEG3(NCH_, SL_, NW_)                                                                                           \
+  DISPATCH_T(dtype, (embed_segment_bwd_kernel<T, NCH_, SL_, NW_>                                                          \
+                     <<<(unsigned)((n_occ + NW_ * 128 - 1) / (NW_ * 128)), NW_ * 64,                                       \
+                        (size_t)seg_words * 4 + (size_t)NW_ * NCH_ * 64 * Pack<T>::N * 4 + NW_ * 4, (hipStream_t)stream>>>( \
+                         src_rows, seg_start, (const T*)dout, ld, dtable_f32, (int)V, D, n_occ, (int)pad_id)))
 #define MH_SEG(NCH_)                                                                                                      \
-  DISPATCH_T(dtype, (embed_segment_bwd_kernel<T, NCH_><<<(unsigned)nblk, 256, 0, (hipStream_t)stream>>>(                   \
-                        src_rows, seg_start, (const T*)dout, ld, dtable_f32, (int)V, D, n_occ, (int)pad_id)))
+  do {                                                                                                                    \
+    if (NCH_ <= 2) { if (sl) MH_SEG3(NCH_, true, 8); else MH_SEG3(NCH_, false, 8); }                                       \
+    else if (NCH_ <= 4) { if (sl) MH_SEG3(NCH_, true, 4); else MH_SEG3(NCH_, false, 4); }                                  \
+    else { if (sl) MH_SEG3(NCH_, true, 1); else MH_SEG3(NCH_, false, 1); }                                                 \
+  } while (0)
   if (nch <= 1) MH_SEG(1);
   else if (nch <= 2) MH_SEG(2);
   else if (nch <= 4) MH_SEG(4);
   else MH_SEG(8);
 #undef MH_SEG
+#undef MH_SEG3
   MH_LAUNCH_CHECK();
   return MH_OK;
 }
