@@ -329,9 +329,11 @@ def pmc_traffic(kind: str = "gemm"):
     """memory-side bytes per gemm_pp256 launch (kind "gemm", tools/gpu_pmc_bench.sh) or per generated event (kind "generate",
     tools/gpu_decode_profile.sh) from the newest committed rocprofv3 PMC pass; counters need their own rocprofv3 runs, so the
     bench line cites the file it read"""
-    def run_key(path):  # r02_run23_... -> (2, 23), r05_final_... -> (5, 10**6): newest by round and run number, not by string order
-        m = re.match(r"r(\d+)_(?:run(\d+)|final)_", os.path.basename(path))
-        return (int(m.group(1)), int(m.group(2)) if m.group(2) else 10 ** 6) if m else (-1, -1)
+    def run_key(path):  # r02_run23_... -> (2, 23), r05_final_... -> (5, 10**6), r06_final4_... -> (6, 10**6 + 4): newest by round and run number
+        m = re.match(r"r(\d+)_(?:run(\d+)|final(\d*))_", os.path.basename(path))
+        if not m:
+            return (-1, -1)
+        return (int(m.group(1)), int(m.group(2)) if m.group(2) else 10 ** 6 + int(m.group(3) or 0))
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", f"r*_pmc_{kind}_traffic.json")), key=run_key)
     if not files:
         return None, None
