@@ -493,6 +493,51 @@ def test_token_segments_is_a_grouping_of_the_occurrences_by_id(ops, n_rows, n_co
 
 # ------------------------------------------------------------------------------------------ embeddings
 @pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("D", [256, 1024, 2048, 4096])
+@pytest.mark.parametrize("dist", ["one_id", "edge_1024_1025", "skewed", "wide_vocab", "pad_heavy", "tiny"])
+def test_embed_segment_bwd_adversarial_id_distributions(ops, dtype, D, dist):
+    """r06 form of mh_embed_segment_bwd (pieces snapped to segment starts, owned segments written without atomics, the waves of a
+    workgroup meeting in LDS): id distributions chosen against its case analysis -- one id for everything (every wave of every
+    workgroup in one group chain), segments of exactly SEG_OWN and SEG_OWN + 1 occurrences side by side, a skewed mix of a few
+    long and many short segments, a vocabulary too wide for the LDS copy of seg_start, mostly padding, fewer occurrences than one
+    wave's piece -- at every chunk count (D = 256 .. 4096), against index_add in fp32."""
+    if dtype == torch.float32 and D > 2048:
+        pytest.skip("fp32 rows of the segment form stop at D = 2048")
+    g = torch.Generator().manual_seed(D + sum(map(ord, dist)))
+    V, n = 3406, 40000
+    if dist == "one_id":
+        ids = torch.full((n,), 7, dtype=torch.long)
+    elif dist == "edge_1024_1025":
+        ids = torch.cat([torch.full((1024,), 5), torch.full((1025,), 6), torch.full((1024,), 9), torch.full((1023,), 11),
+                         torch.full((130,), 12), torch.full((2048,), 13), torch.arange(20, 20 + 300)]).long()
+    elif dist == "skewed":
+        ids = torch.cat([torch.full((17000,), 3), torch.full((5000,), 140), torch.randint(9, V, (18000,), generator=g)]).long()
+    elif dist == "wide_vocab":
+        V = 6000
+        ids = torch.randint(0, V, (n,), generator=g)
+    elif dist == "pad_heavy":
+        ids = torch.where(torch.rand(n, generator=g) < 0.8, torch.zeros(n, dtype=torch.long), torch.randint(1, V, (n,), generator=g))
+    else:
+        ids = torch.randint(0, V, (37,), generator=g)
+    ids = ids[torch.randperm(ids.numel(), generator=g)]
+    n = ids.numel()
+    nrows = 3000
+    rows = torch.randint(0, nrows, (n,), generator=g)
+    dout = rnd((nrows, D), dtype, 77)
+    src, seg = ops.token_segments(ids.cuda(), V)          # src = occurrence indices grouped by id
+    acc = torch.zeros((V, D), device="cuda")
+    ops.embed_segment_bwd(rows.cuda()[src].contiguous(), seg, dout.cuda(), D, acc, 0)
+    ref = torch.zeros((V, D), device="cuda").index_add_(0, ids.cuda(), dout.cuda().float()[rows.cuda()])
+    ref[0] = 0
+    tol = 2e-6 * max(1.0, float(torch.bincount(ids).max())) ** 0.5 * ref.abs().max().item() + 1e-6
+    assert (acc - ref).abs().max().item() <= tol, ((acc - ref).abs().max().item(), tol)
+    assert acc[0].abs().max() == 0
+    # accumulate semantics: a second call adds to the table
+    ops.embed_segment_bwd(rows.cuda()[src].contiguous(), seg, dout.cuda(), D, acc, 0)
+    assert (acc - 2 * ref).abs().max().item() <= 2 * tol
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("D,M", [(256, 77), (1024, 700), (2048, 150)])
 def test_embeddings(ops, dtype, D, M):
     V, T = 3406, 8
