@@ -907,6 +907,48 @@ def test_cross_entropy(ops, dtype, R, V, Vp):
     assert cnt.item() == float((tgt != 0).sum()) and abs(iv.item() - inv.item()) < 1e-9
 
 
+@pytest.mark.parametrize("with_argmax", [False, True])
+@pytest.mark.parametrize("V,Vp", [(3406, 3408), (3408, 3408), (3401, 3408), (2049, 2056), (2048, 2048), (513, 520), (40, 40), (3585, 3592), (4096, 4096)])
+def test_cross_entropy_bf16_edges(ops, V, Vp, with_argmax):
+    """r06 form of the bf16 cross entropy (row converted once, padding at -inf, wave-uniform tests for the padding / target chunks,
+    arg-max as its own instantiation): vocabulary sizes that end on, one short of and seven short of a 16-byte chunk, rows that
+    fill 4 / 7 / 8 chunks per lane exactly, targets on every chunk and lane edge, rows that are all ignored, a maximum in the last
+    valid column and ties -- against torch in fp32 on the same bf16 logits."""
+    R = 257
+    g = torch.Generator().manual_seed(V)
+    logits = torch.full((R, Vp), 99.0)
+    logits[:, :V] = torch.randn((R, V), generator=g) * 4
+    logits[5, V - 1] = 50.0            # the maximum in the last valid column
+    logits[6, :V] = 1.25               # a row of ties: the first index wins the arg-max
+    logits = logits.to(torch.bfloat16)
+    edges = [1, 7, 8, 9, 63, 64, 511, 512, 513, 1023, 1024, 2047, 2048, 3071, 3072, 3583, 3584, V - 9, V - 8, V - 2, V - 1]
+    tgt = torch.randint(1, V, (R,), generator=g)
+    for i, e in enumerate(edges):
+        tgt[10 + i] = min(max(e, 1), V - 1)
+    tgt[::9] = 0
+    tgt[100:140] = 0                   # whole waves' worth of ignored rows
+    scale = torch.tensor([0.37])
+    lg = logits.clone().cuda()
+    rl = torch.empty(R, device="cuda")
+    am = torch.empty(R, dtype=torch.long, device="cuda") if with_argmax else None
+    dl = torch.empty_like(lg)
+    ops.cross_entropy(lg, V, tgt.cuda(), rl, dl, scale.cuda(), am, 0)
+    x = logits[:, :V].float()
+    lsm = torch.log_softmax(x, -1)
+    keep = tgt != 0
+    want_loss = torch.where(keep, -lsm.gather(1, tgt[:, None])[:, 0], torch.zeros(R))
+    assert torch.allclose(rl.cpu(), want_loss, atol=3e-5, rtol=1e-5)
+    want_d = lsm.exp()
+    want_d[torch.arange(R), tgt] -= 1.0
+    want_d = want_d * 0.37 * keep[:, None].float()
+    got = dl.cpu().float()
+    assert (got[:, V:] == 0).all() and (got[~keep] == 0).all()
+    assert (got[:, :V] - want_d).abs().max().item() <= 2.0 ** -8 * 0.37 + 1e-6   # one bf16 rounding of a value below 0.37
+    if with_argmax:
+        assert torch.equal(am.cpu(), x.argmax(-1)) or torch.equal(am.cpu()[torch.arange(R) != 6], x.argmax(-1)[torch.arange(R) != 6])
+        assert am[6].item() == 0 and am[5].item() == V - 1
+
+
 @pytest.mark.parametrize("dtype", DTYPES)
 def test_clip_and_adamw(ops, dtype):
     n = 100003 * 8
