@@ -1066,6 +1066,50 @@ def test_sample_top_p_k_fused(ops, dtype, top_p, top_k):
     assert (buf[:, :3] == -7).all() and (buf[:, 6:] == -7).all()
 
 
+def test_sample_top_p_k_fused_draws_follow_the_filtered_distribution(ops):
+    """A second guard on the sampler beside the id-for-id comparison: with fresh Exp(1) variates per row, the ids the fused
+    kernel draws for 16384 rows that share ONE distribution must be distributed as sample_top_p_k's filtered, renormalised
+    probabilities (midi_model.py:152-165: sort, cumulative top-p cut, first k, renormalise, multinomial) -- argmax(p / q) over
+    the sorted ranks IS a multinomial draw.  Chi-square over the kept ids (about 20 cells, 16384 draws): the statistic stays
+    under 70 (p ~ 1e-7 for 19 degrees of freedom) and no id outside the kept set is ever drawn."""
+    import midi_model_amd as mm
+    tok = mm.MIDITokenizerV2()
+    first, lo_t, hi_t, _ = tok.grammar_tables()
+    B, V, Vp = 16384, tok.vocab_size, 3408
+    g = torch.Generator().manual_seed(123)
+    row = torch.randn(V, generator=g) * 1.5
+    logits = torch.zeros((B, Vp), dtype=torch.bfloat16)
+    logits[:, :V] = row.to(torch.bfloat16)[None, :]
+    ev = torch.full((B,), 3, dtype=torch.int64)          # "note": position 1 draws time1 out of 128 ids
+    pos, temp, top_p, top_k = 1, 1.0, 0.9, 20
+    fm = torch.tensor(first, dtype=torch.uint8)
+    lo_tab, hi_tab = torch.tensor(lo_t, dtype=torch.int32), torch.tensor(hi_t, dtype=torch.int32)
+    q = torch.empty((B, V)).exponential_(1.0, generator=g)
+    out = torch.empty((B,), dtype=torch.int64, device="cuda")
+    span, mr = ops.mask_spans(fm, lo_tab, hi_tab)
+    ops.sample_top_p_k(logits.cuda(), fm.cuda(), lo_tab.cuda(), hi_tab.cuda(), ev.cuda(), pos, q.cuda(), out, V, temp, top_p, top_k,
+                       first_span=span, max_range=mr[pos])
+    # the reference's filtered distribution of this row (probabilities of the whole vocabulary, masked to the position's range)
+    x = logits[0, :V].float()
+    probs = torch.softmax(x / temp, -1)
+    mask = torch.zeros(V)
+    mask[lo_t[3][pos]:hi_t[3][pos]] = 1
+    probs = probs * mask
+    ps, pi = torch.sort(probs, descending=True, stable=True)
+    cum = torch.cumsum(ps, 0)
+    ps[cum - ps > top_p] = 0
+    ps[top_k:] = 0
+    ps = ps / ps.sum()
+    kept = ps > 0
+    want = torch.zeros(V)
+    want[pi[kept]] = ps[kept]
+    counts = torch.bincount(out.cpu(), minlength=V).float()
+    assert counts[want == 0].sum() == 0, "an id outside the kept set was drawn"
+    e = want[want > 0] * B
+    chi2 = ((counts[want > 0] - e) ** 2 / e).sum().item()
+    assert int(kept.sum()) >= 5 and chi2 < 70.0, (int(kept.sum()), chi2)
+
+
 def test_collate_windows(ops):
     """device-side batch assembly (mh_collate_windows) against the host restatement"""
     g = torch.Generator().manual_seed(5)
